@@ -1,0 +1,354 @@
+"""CPU oracle for the GCN-forward + local-greedy MWIS hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy/SciPy restatement of the reference's algorithm for the path
+named in BASELINE.json.  It exists to *check* the HIP implementation; it must never be
+imported by the product package (``distgcn_amd``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may use it.
+
+Pinning status
+--------------
+* ``normalize_adj`` / ``simple_polynomials`` / ``preprocess_features`` (A1-A3) and every
+  ``local_greedy_search*`` / ``greedy_search`` variant (A8, A8', A9) are **pinned**: the
+  reference's own functions (``gcn/utils.py``, ``heuristics.py``) were imported in the build
+  container and their outputs stored in ``tests/golden/`` by ``oracle/make_golden.py``;
+  ``tests/test_oracle_golden.py`` replays them.  ``greedy_utility`` stored in the reference's
+  ``.mat`` files is a second, reference-authored pin for A9.
+* The GCN forward (A4-A6: ``gcn/layers.py``, ``gcn/models.py``) executes inside TensorFlow
+  in the reference.  TensorFlow is not installable here and the reference ships no stored
+  activations, so that part is a restatement of ``gcn/layers.py:189-216`` and
+  ``gcn/models.py:536-573 / 670-708`` that is **parity unpinned** at the TF boundary
+  (anchored only by the closed form for l=1 and by end-to-end approximation ratios).
+
+Every function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+LEAKY_ALPHA = 0.2  # tf.nn.leaky_relu default; never overridden (gcn/models.py:553,562,583)
+
+
+# =============================================================================
+# A1-A3: graph preprocessing  (gcn/utils.py)
+# =============================================================================
+def normalize_adj(adj):
+    """D^-1/2 A D^-1/2 with 0 for isolated vertices  (gcn/utils.py:120-127).
+
+    The reference evaluates ``(A . Dinv)^T . Dinv`` in float64; the product order per entry is
+    (A_vu * dinv[u]) * dinv[v], kept here so the float64 bits agree.
+    """
+    a = sp.coo_matrix(adj)
+    deg = np.asarray(a.sum(axis=1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5)
+    dinv[np.isinf(dinv)] = 0.0
+    scale = sp.diags(dinv)
+    return ((a @ scale).T @ scale).tocoo()
+
+
+def simple_polynomials(adj, k):
+    """[I, L, L^2, ...] with L = I - normalize_adj(adj) as COO triples  (gcn/utils.py:258-274)."""
+    n = adj.shape[0]
+    lap = sp.eye(n) - normalize_adj(adj)
+    mats = [sp.eye(n), lap]
+    while len(mats) < k + 1:
+        mats.append(mats[-1] * lap)
+    return [sparse_to_tuple(m) for m in mats]
+
+
+def sparse_to_tuple(mx):
+    """(coords[nnz,2], values[nnz], shape)  (gcn/utils.py:79-95)."""
+    coo = mx if sp.isspmatrix_coo(mx) else mx.tocoo()
+    coords = np.stack([coo.row, coo.col], axis=1)
+    return coords, coo.data, coo.shape
+
+
+def preprocess_features(features):
+    """Row-normalise a sparse feature matrix, inf -> 0  (gcn/utils.py:98-106)."""
+    rowsum = np.asarray(features.sum(axis=1)).ravel()
+    with np.errstate(divide="ignore"):
+        rinv = np.power(rowsum, -1.0)
+    rinv[np.isinf(rinv)] = 0.0
+    return sparse_to_tuple(sp.diags(rinv).dot(features))
+
+
+def makestate(adj, wts_nn, feature_size, max_degree=1, flavour="dqn_call", predict="mwis"):
+    """The three ``makestate`` flavours of the reference.
+
+    * ``dqn_call``  - mwis_dqn_call.py:129-138  (ones * w/||w||, row-normalised)
+    * ``dqn_test``  - mwis_dqn_test.py:162-169  (ones * w, row-normalised)
+    * ``gdpg``      - mwis_gdpg_call.py:82-97   (plain ones when predict=='mwis', row-normalised;
+                       otherwise ones * w/(max w + 1e-9), not normalised)
+    """
+    n = wts_nn.shape[0]
+    w = np.reshape(wts_nn, (n, -1))
+    ones = np.ones([n, feature_size])
+    if flavour == "dqn_call":
+        feats = preprocess_features(sp.lil_matrix(ones * (w / np.linalg.norm(w))))
+    elif flavour == "dqn_test":
+        feats = preprocess_features(sp.lil_matrix(ones * w))
+    elif flavour == "gdpg":
+        if predict == "mwis":
+            feats = preprocess_features(sp.lil_matrix(ones))
+        else:
+            feats = sparse_to_tuple(sp.lil_matrix(ones * (w / (np.amax(w) + 1e-9))))
+    else:
+        raise ValueError(flavour)
+    return {"features": feats, "support": simple_polynomials(adj, max_degree)}
+
+
+# =============================================================================
+# A4-A6: GCN forward (restatement of the TF graph; parity unpinned at the TF boundary)
+# =============================================================================
+def _tuple_to_csr(tup, dtype):
+    coords, vals, shape = tup
+    return sp.csr_matrix((np.asarray(vals).astype(dtype), (coords[:, 0], coords[:, 1])), shape=shape)
+
+
+def _act(name, x):
+    if name == "leaky_relu":
+        return np.where(x > 0, x, x.dtype.type(LEAKY_ALPHA) * x)
+    if name == "relu":
+        return np.maximum(x, 0)
+    if name in ("linear", "identity", None):
+        return x
+    raise ValueError(name)
+
+
+def graph_convolution(x, supports, weights, bias=None, act="leaky_relu"):
+    """One GraphConvolution layer  (gcn/layers.py:189-216).
+
+    out = act( sum_i S_i . (x . W_i) [+ b] ): transform first, then aggregate (202-206);
+    supports are summed in index order (208); dropout is the identity at inference.
+    ``x`` is dense here; the reference's first layer holds it as a sparse tensor, which only
+    changes the kernel TF picks, not the arithmetic.
+    """
+    out = None
+    for s, w in zip(supports, weights):
+        term = s @ (x @ w)
+        out = term if out is None else out + term
+    if bias is not None:
+        out = out + bias
+    return _act(act, out)
+
+
+def gcn_layer_specs(params, model="GCN_DQN", scope="gcn_dqn", num_supports=2):
+    """Turn a {variable name: array} dict (checkpoint naming, A11: mwis_dqn_call.py:188-192;
+    layer uid reset at gcn/models.py:538) into an ordered list of layer dicts.
+
+    GCN_DQN   (gcn/models.py:536-573): hidden layers leaky_relu, last layer identity.
+    GCN2_DQN  (gcn/models.py:670-708): every layer, including the last, uses ``act``.
+    """
+    layers = []
+    k = 1
+    while True:
+        base = "%s/graphconvolution_%d_vars" % (scope, k)
+        if base + "/weights_0" not in params:
+            break
+        ws = [np.asarray(params["%s/weights_%d" % (base, i)]) for i in range(num_supports)]
+        b = params.get(base + "/bias")
+        layers.append({"weights": ws, "bias": None if b is None else np.asarray(b)})
+        k += 1
+    if not layers:
+        raise KeyError("no graphconvolution variables under scope %r" % scope)
+    for i, lyr in enumerate(layers):
+        last = i == len(layers) - 1
+        lyr["act"] = "linear" if (last and model == "GCN_DQN") else "leaky_relu"
+    return layers
+
+
+def gcn_forward(layers, state, dtype=np.float32, is_dual=False):
+    """``sess.run([model.outputs_softmax, model.pred])``  (mwis_dqn_call.py:140-143).
+
+    Returns (act_values[N, out] of ``dtype``, action = argmax over nodes, axis 0).
+    TF casts the float64 feed to float32 (sparse placeholders are tf.float32), hence
+    ``dtype=np.float32`` is the reference behaviour; ``np.float64`` gives the error yardstick.
+    """
+    supports = [_tuple_to_csr(t, dtype) for t in state["support"]]
+    x = _tuple_to_csr(state["features"], dtype).toarray().astype(dtype)
+    for lyr in layers:
+        ws = [w.astype(dtype) for w in lyr["weights"]]
+        b = None if lyr["bias"] is None else lyr["bias"].astype(dtype)
+        x = graph_convolution(x, supports, ws, b, lyr["act"])
+    if is_dual:  # gcn/models.py:651-653
+        x = x[:, 0].mean(axis=0) + (x[:, 1:] - x[:, 1:].mean(axis=0))
+    return x, np.argmax(x, axis=0)
+
+
+def priority(act_vals, wts_nn, predict="mwis"):
+    """``gcn_wts``  (mwis_dqn_call.py:230-235; mwis_gdpg_call.py:211-216): f32 * f64 -> f64."""
+    if predict == "mwis":
+        return np.multiply(np.asarray(act_vals).flatten(), np.asarray(wts_nn).flatten())
+    return np.asarray(act_vals).flatten()
+
+
+# =============================================================================
+# A8 / A8': local greedy search and its instrumented twins  (heuristics.py:77-305)
+# =============================================================================
+def _lgs_core(adj, wts, nstep=None, want_overhead=False):
+    """Shared body of the five reference variants.
+
+    Per round, for every vertex still in ``remain`` (heuristics.py:90-114):
+      nb = neighbours(v) & remain                              (94-95)
+      nb empty                      -> v joins                 (96-98)
+      w[v] > max w[nb]              -> v joins, nb excluded    (103-105)
+      w[v] == max w[nb]             -> v joins iff v < the lowest-index
+                                       neighbour holding that max      (106-111)
+    then remain -= joined | excluded (114).  Decisions inside a round read only the
+    round-start ``remain``.  Counters follow _stats (184-208) and _overhead (236-262).
+    """
+    w = np.array(wts).flatten()
+    n = w.size
+    mwis = set()
+    nb_is = set()
+    remain = set(range(n))
+    rounds = p2p = bst = 0
+    oh = np.zeros_like(w) if want_overhead else None
+    budget = nstep
+    while remain and (budget is None or budget):
+        bst += len(remain)
+        for v in remain:
+            _, cols = np.nonzero(adj[v])
+            nbrs = set(cols) & remain
+            p2p += len(nbrs)
+            if oh is not None:
+                oh[v] += len(nbrs)
+            if not nbrs:
+                mwis.add(v)
+                continue
+            order = sorted(nbrs)
+            w_nb = w[order]
+            top = w_nb.max()
+            wins = False
+            if w[v] > top:
+                wins = True
+            elif w[v] == top:
+                first = order[list(w_nb).index(w[v])]
+                wins = v < first
+            if wins:
+                mwis.add(v)
+                nb_is |= nbrs
+                if oh is not None:
+                    oh[v] += 1  # "mute signaling"
+        remain = remain - mwis - nb_is
+        rounds += 1
+        if budget is not None:
+            budget -= 1
+    total = np.sum(w[list(mwis)])
+    bst += len(mwis)
+    return mwis, total, rounds, p2p, bst, oh, nb_is
+
+
+def local_greedy_search(adj, wts):
+    """heuristics.py:77-116 -> (set, total)."""
+    r = _lgs_core(adj, wts)
+    return r[0], r[1]
+
+
+def local_greedy_search_count(adj, wts):
+    """heuristics.py:119-160 -> (set, total, rounds)."""
+    r = _lgs_core(adj, wts)
+    return r[0], r[1], r[2]
+
+
+def local_greedy_search_stats(adj, wts):
+    """heuristics.py:163-209 -> (set, total, rounds, p2p, bst)."""
+    r = _lgs_core(adj, wts)
+    return r[0], r[1], r[2], r[3], r[4]
+
+
+def local_greedy_search_overhead(adj, wts):
+    """heuristics.py:212-263 -> (set, total, rounds, p2p, bst, overhead vector)."""
+    r = _lgs_core(adj, wts, want_overhead=True)
+    return r[0], r[1], r[2], r[3], r[4], r[5]
+
+
+def local_greedy_search_nstep(adj, wts, nstep=1):
+    """heuristics.py:266-305 -> (set, total, excluded-neighbour set) after at most nstep rounds."""
+    r = _lgs_core(adj, wts, nstep=nstep)
+    return r[0], r[1], r[6]
+
+
+def lgs_vectorised(indptr, indices, wts, max_rounds=None):
+    """Array form of the same rule, used to check big batches quickly.
+
+    Key order (w desc, index asc): v joins iff it beats every residual neighbour.
+    Returns (state[N] uint8: 1 joined / 2 excluded / 0 still remaining, rounds).
+    """
+    w = np.asarray(wts, dtype=np.float64).ravel()
+    n = w.size
+    indptr = np.asarray(indptr)
+    indices = np.asarray(indices)
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    state = np.zeros(n, dtype=np.uint8)
+    rounds = 0
+    while (state == 0).any() and (max_rounds is None or rounds < max_rounds):
+        live = (state[rows] == 0) & (state[indices] == 0)
+        r, c = rows[live], indices[live]
+        beaten = (w[c] > w[r]) | ((w[c] == w[r]) & (c < r))
+        lose = np.zeros(n, dtype=bool)
+        lose[r[beaten]] = True
+        win = (state == 0) & ~lose
+        excl = np.zeros(n, dtype=bool)
+        excl[c[win[r]]] = True
+        state[win] = 1
+        state[excl & (state == 0)] = 2
+        rounds += 1
+    return state, rounds
+
+
+# =============================================================================
+# A9: centralised greedy  (heuristics.py:13-35)
+# =============================================================================
+def greedy_search(adj, wts):
+    """Sort by weight descending, sweep, skip vertices adjacent to an earlier pick.
+
+    The reference's ``np.argsort(-w)`` is an unstable sort: the order of equal weights is
+    unspecified there.  This restatement uses a stable sort (ties by ascending index), which
+    is the order under which the sweep equals ``local_greedy_search``.
+    """
+    w = np.array(wts).flatten()
+    ranks = np.argsort(-w, kind="stable")
+    mwis = set()
+    blocked = set()
+    for i in ranks:
+        if i in blocked:
+            continue
+        _, cols = np.nonzero(adj[i])
+        mwis.add(i)
+        blocked |= set(cols)
+    return mwis, np.sum(w[list(mwis)])
+
+
+# =============================================================================
+# A10: solve_mwis orchestration
+# =============================================================================
+def solve_mwis_gdpg(layers, adj, wts, feature_size=1, max_degree=1, predict="mwis", dtype=np.float32):
+    """mwis_gdpg_call.py:200-235 -> (set, total_wt)."""
+    adj = sp.csr_matrix(adj)
+    wts_nn = np.reshape(wts, (np.asarray(wts).shape[0], feature_size))
+    state = makestate(adj, wts_nn, feature_size, max_degree, "gdpg", predict)
+    act_vals, _ = gcn_forward(layers, state, dtype)
+    gcn_wts = priority(act_vals, wts_nn, predict)
+    mwis, _ = local_greedy_search(adj, gcn_wts)
+    return mwis, np.sum(wts_nn[list(mwis), 0])
+
+
+def solve_mwis_dqn(layers, adj, wts, feature_size=1, max_degree=1, predict="mwis", dtype=np.float32):
+    """mwis_dqn_call.py:198-261 (inference branch) -> (set of original ids, total_wt, 1.0).
+
+    Zero-weight vertices are deleted first and indices mapped back through ``kp_nodes``
+    (202-207, 241).
+    """
+    adj = sp.csr_matrix(adj)
+    w0 = np.asarray(wts).flatten()
+    keep = np.where(w0 > 0)[0]
+    sub = adj[keep][:, keep]
+    wts_nn = w0[keep].reshape(len(keep), 1)
+    state = makestate(sub, wts_nn, feature_size, max_degree, "dqn_call", predict)
+    act_vals, _ = gcn_forward(layers, state, dtype)
+    gcn_wts = priority(act_vals, wts_nn, predict)
+    mwis, _ = local_greedy_search(sub, gcn_wts)
+    solu = list(mwis)
+    return set(keep[solu]), np.sum(wts_nn[solu, 0]), 1.0
