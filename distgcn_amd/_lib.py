@@ -1,0 +1,110 @@
+"""ctypes binding of libdgcn.so (include/dgcn.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing the
+import fails loudly with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgcn.so")
+
+OK = 0
+ACT_LINEAR, ACT_LEAKY_RELU, ACT_RELU = 0, 1, 2
+FAULT_SELF_LOOP, FAULT_NAN_PRIORITY, FAULT_DEGREE_RANGE, FAULT_BAD_COLUMN = 1, 2, 4, 8
+FAULT_NAMES = {
+    FAULT_SELF_LOOP: "adjacency has a self-loop (heuristics.py:94 would never terminate)",
+    FAULT_NAN_PRIORITY: "NaN priority (heuristics.py:103-111 would never terminate)",
+    FAULT_DEGREE_RANGE: "vertex degree outside the d^-1/2 table",
+    FAULT_BAD_COLUMN: "column index outside its graph's vertex range",
+}
+
+# every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
+SYMBOLS = (
+    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_spmm_batch", "dgcn_transform_batch",
+    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_argmax_batch", "dgcn_lgs_batch",
+    "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
+)
+
+
+class DgcnError(RuntimeError):
+    pass
+
+
+class DgcnBatch(C.Structure):
+    _fields_ = [
+        ("num_graphs", C.c_int32), ("num_nodes", C.c_int32), ("num_edges", C.c_int32),
+        ("max_nodes", C.c_int32), ("max_graph_edges", C.c_int32),
+        ("graph_ptr", C.c_void_p), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+    ]
+
+
+class DgcnCsr(C.Structure):
+    _fields_ = [
+        ("num_rows", C.c_int32), ("nnz", C.c_int32),
+        ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("values", C.c_void_p),
+    ]
+
+
+class DgcnLayer(C.Structure):
+    _fields_ = [
+        ("in_dim", C.c_int32), ("out_dim", C.c_int32),
+        ("weights", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int32),
+    ]
+
+
+class DgcnModel(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("num_supports", C.c_int32), ("layers_host", C.POINTER(DgcnLayer))]
+
+
+_lib = None
+
+
+def load():
+    """Return the loaded library (cached).  Raises DgcnError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DgcnError(
+            "%s is missing: the HIP extension has not been built. Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, targets gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    lib.dgcn_version.restype = C.c_int
+    lib.dgcn_last_error.restype = C.c_char_p
+    lib.dgcn_supports_batch.restype = C.c_int
+    lib.dgcn_supports_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
+    lib.dgcn_spmm_batch.restype = C.c_int
+    lib.dgcn_spmm_batch.argtypes = [C.POINTER(DgcnCsr), vp, i32, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, vp]
+    lib.dgcn_transform_batch.restype = C.c_int
+    lib.dgcn_transform_batch.argtypes = [vp, i32, f32, i32, i32, vp, i32, vp, i32, vp]
+    lib.dgcn_gcn_forward_workspace.restype = sz
+    lib.dgcn_gcn_forward_workspace.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), i32]
+    lib.dgcn_gcn_forward_batch.restype = C.c_int
+    lib.dgcn_gcn_forward_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnCsr), C.POINTER(DgcnModel),
+                                           vp, f32, vp, vp, sz, i32, vp]
+    lib.dgcn_argmax_batch.restype = C.c_int
+    lib.dgcn_argmax_batch.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.dgcn_lgs_batch.restype = C.c_int
+    lib.dgcn_lgs_batch.argtypes = [C.POINTER(DgcnBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dgcn_timing_enable.restype = C.c_int
+    lib.dgcn_timing_enable.argtypes = [i32]
+    lib.dgcn_timing_reset.restype = C.c_int
+    lib.dgcn_timing_read.restype = C.c_int
+    lib.dgcn_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "libdgcn") -> None:
+    if rc != OK:
+        msg = load().dgcn_last_error()
+        raise DgcnError("%s failed (%d): %s" % (what, rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def fault_text(bits: int) -> str:
+    return "; ".join(txt for bit, txt in FAULT_NAMES.items() if bits & bit) or "unknown fault %d" % bits

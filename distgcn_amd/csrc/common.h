@@ -1,0 +1,42 @@
+// Shared host-side helpers for libdgcn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/dgcn.h"
+
+namespace dgcn {
+
+constexpr int kWave = 64;        // CDNA wavefront width
+constexpr float kLeakyAlpha = 0.2f;
+
+// thread-local error text behind dgcn_last_error()
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+// kernel-family timing (dgcn_timing_*): RAII pair of events around one launch
+struct TimedLaunch {
+    TimedLaunch(const char* family, hipStream_t stream);
+    ~TimedLaunch();
+    int slot;
+    hipStream_t stream;
+};
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return DGCN_OK;
+}
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == DGCN_ACT_LEAKY_RELU) return x > 0.0f ? x : kLeakyAlpha * x;
+    if (act == DGCN_ACT_RELU) return x > 0.0f ? x : 0.0f;
+    return x;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dgcn

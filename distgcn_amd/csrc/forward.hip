@@ -1,0 +1,136 @@
+// GCN forward over a batch: the layer stack of GCN_DQN / GCN2_DQN (gcn/models.py:536-573, 670-708),
+// i.e. what sess.run(model.outputs_softmax) returns (mwis_dqn_call.py:140-143), plus
+// pred = argmax(outputs, axis 0) (gcn/models.py:526, 660).
+//
+// mode 0 (layer-by-layer): per layer one transform launch (Z = H.[W0|W1]) and one SpMM launch with
+// the add_n / bias / activation epilogue.  mode 1 (fused, one workgroup per graph) lives in fused.hip.
+#include "common.h"
+
+namespace dgcn {
+
+int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
+                  const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s);
+int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
+                       int ldz, hipStream_t s);
+size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m);
+int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
+                  float* scores, void* ws, size_t ws_bytes, hipStream_t s);
+
+static int model_check(const DgcnModel* m, const char* who) {
+    if (!m || !m->layers_host || m->num_layers <= 0) return fail(DGCN_ERR_ARG, "%s: bad model", who);
+    if (m->num_supports != 2)
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: num_supports=%d; only [I, L] (max_degree=1) is implemented", who,
+                    m->num_supports);
+    for (int l = 0; l < m->num_layers; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        if (L.in_dim <= 0 || L.out_dim <= 0 || !L.weights) return fail(DGCN_ERR_ARG, "%s: layer %d malformed", who, l);
+        if (l && L.in_dim != m->layers_host[l - 1].out_dim)
+            return fail(DGCN_ERR_ARG, "%s: layer %d in_dim %d != previous out_dim %d", who, l, L.in_dim,
+                        m->layers_host[l - 1].out_dim);
+    }
+    return DGCN_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static void layered_dims(const DgcnModel* m, int* max_out) {
+    int mo = 0;
+    for (int l = 0; l < m->num_layers; ++l) mo = max(mo, m->layers_host[l].out_dim);
+    *max_out = mo;
+}
+
+__global__ __launch_bounds__(256) void k_argmax(const float* __restrict__ scores, int ld,
+                                                const int32_t* __restrict__ graph_ptr, int32_t* __restrict__ out) {
+    const int g = blockIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    bool any = false;
+    for (int v = n0 + threadIdx.x; v < n1; v += 256) {
+        const float x = scores[(size_t)v * ld];
+        // first maximum wins (numpy / tf.argmax semantics); NaN compares false and is skipped
+        if (!any || x > best) { best = x; arg = v - n0; any = true; }
+    }
+    __shared__ float sb[256];
+    __shared__ int sa[256];
+    sb[threadIdx.x] = any ? best : -INFINITY;
+    sa[threadIdx.x] = any ? arg : 0x7fffffff;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const float ob = sb[threadIdx.x + off];
+            const int oa = sa[threadIdx.x + off];
+            const float mb = sb[threadIdx.x];
+            const int ma = sa[threadIdx.x];
+            if (oa != 0x7fffffff && (ma == 0x7fffffff || ob > mb || (ob == mb && oa < ma))) {
+                sb[threadIdx.x] = ob;
+                sa[threadIdx.x] = oa;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[g] = (sa[0] == 0x7fffffff) ? 0 : sa[0];
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" size_t dgcn_gcn_forward_workspace(const DgcnBatch* b, const DgcnModel* m, int32_t mode) {
+    if (!b || model_check(m, "dgcn_gcn_forward_workspace") != DGCN_OK) return 0;
+    if (mode == 1) return fused_workspace(b, m);
+    int mo;
+    layered_dims(m, &mo);
+    const size_t n = (size_t)max(b->num_nodes, 1);
+    return align256(n * 2 * mo * sizeof(float)) + align256(n * mo * sizeof(float));
+}
+
+extern "C" int dgcn_gcn_forward_batch(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X,
+                                      float x_const, float* scores, void* workspace, size_t workspace_bytes,
+                                      int32_t mode, void* stream) {
+    if (!b || !lap || !scores) return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_batch: null argument");
+    int rc = model_check(m, "dgcn_gcn_forward_batch");
+    if (rc) return rc;
+    if (b->num_nodes <= 0) return DGCN_OK;
+    if (lap->num_rows != b->num_nodes) return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_batch: support/batch row mismatch");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = dgcn_gcn_forward_workspace(b, m, mode);
+    if (!workspace || workspace_bytes < need)
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_gcn_forward_batch: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (mode == 1) return fused_forward(b, lap, m, X, x_const, scores, workspace, workspace_bytes, s);
+    if (mode != 0) return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_batch: unknown mode %d", mode);
+
+    int mo;
+    layered_dims(m, &mo);
+    const size_t n = (size_t)b->num_nodes;
+    float* Zbuf = reinterpret_cast<float*>(workspace);
+    float* Hbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256(n * 2 * mo * sizeof(float)));
+
+    const float* H = X;  // NULL -> constant features
+    int ldh = m->layers_host[0].in_dim;
+    for (int l = 0; l < m->num_layers; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        const int ctot = 2 * L.out_dim;
+        // K2/K3: Z[:, 0:out] = H.W0, Z[:, out:2out] = H.W1  (weights stored [support][in][out] -> the
+        // host shim passes them pre-concatenated as [in][2*out]; see distgcn_amd/gcn/models.py)
+        rc = transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
+        if (rc) return rc;
+        const bool last = l == m->num_layers - 1;
+        float* out = last ? scores : Hbuf;
+        // K4-K7: out = act(Z0 + L.Z1 + b)
+        rc = spmm_dispatch(lap, b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + L.out_dim, ctot, L.out_dim, Zbuf,
+                           ctot, L.bias, L.act, out, L.out_dim, s);
+        if (rc) return rc;
+        H = out;
+        ldh = L.out_dim;
+    }
+    return DGCN_OK;
+}
+
+extern "C" int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr, int32_t num_graphs,
+                                 int32_t* arg_out, void* stream) {
+    if (!scores || !graph_ptr || !arg_out || ld <= 0) return fail(DGCN_ERR_ARG, "dgcn_argmax_batch: bad argument");
+    if (num_graphs <= 0) return DGCN_OK;
+    hipLaunchKernelGGL(k_argmax, dim3(num_graphs), dim3(256), 0, (hipStream_t)stream, scores, ld, graph_ptr, arg_out);
+    return check_launch("k_argmax");
+}

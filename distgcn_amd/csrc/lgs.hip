@@ -1,0 +1,270 @@
+// Local greedy MWIS search over a batch of graphs: one workgroup per graph, state in LDS.
+// Replaces heuristics.py:77-116 local_greedy_search and its instrumented twins (:119-305), and -
+// because the lexicographically-first independent set under the order (priority desc, index asc)
+// is unique - heuristics.py:13-35 greedy_search as well.  Also folds in the priority product
+// gcn_wts = act_vals * wts (mwis_dqn_call.py:232; f32 x f64 -> f64).
+//
+// Per round (heuristics.py:90-114), synchronously for every vertex still remaining:
+//   phase A  v wins iff no remaining neighbour u has (p[u] > p[v]) or (p[u] == p[v] and u < v)
+//   phase B  winners join the set (state 1) and push state 2 ("nb_is") onto remaining neighbours
+// Integer/compare work only: results are bit-identical to the reference for identical priorities.
+// Signed priorities, +-0.0 and +-inf follow IEEE compares exactly as NumPy does; NaN (on which the
+// reference never terminates) raises DGCN_FAULT_NAN_PRIORITY instead.
+//
+// gfx950 mapping: LPV lanes share one vertex and stride over its adjacency list; the per-vertex
+// "lost" verdict is the OR over those lanes, taken from one wave-wide __ballot (64-bit mask, the
+// lanes of a vertex are adjacent bits) instead of a shuffle tree.  Priorities (f64), state bytes and
+// the graph's column ids (as 16-bit local ids) sit in LDS for all rounds, so HBM is touched once:
+// nnz*4 + N*(8..12) bytes in, N*1 + 4 bytes out per graph.  Latency-bound at N~200, not HBM-bound.
+#include "common.h"
+
+namespace dgcn {
+
+struct LgsArgs {
+    const int32_t* graph_ptr;
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const double* prio;
+    const float* scores;
+    const double* weights;
+    int max_rounds;
+    uint8_t* state;
+    int32_t* rounds;
+    int64_t* stats;
+    int32_t* overhead;
+    const double* sum_weights;
+    double* totals;
+    int32_t* status;
+    int max_nodes;   // LDS carve-up
+    int cols_cap;    // 16-bit column slots in LDS (0 = read col_idx from global memory)
+};
+
+template <bool COLS_LDS>
+__device__ __forceinline__ int nbr_at(const uint16_t* cl, const int32_t* cg, int j, int e0, int n0) {
+    if (COLS_LDS) return cl[j - e0];
+    return cg[j] - n0;
+}
+
+template <int LPV, bool STATS, bool COLS_LDS>
+__device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int ng, int e0, double* pr, uint8_t* st,
+                                           uint8_t* nw, const uint16_t* cl, unsigned long long* acc64) {
+    constexpr int kVerts = 256 / LPV;
+    const int lane = threadIdx.x & 63;
+    const int slot = threadIdx.x / LPV, sub = threadIdx.x % LPV;
+    const int gshift = lane & ~(LPV - 1);
+    const unsigned long long gmask = (LPV == 64) ? ~0ull : ((1ull << LPV) - 1ull);
+    const int passes = (ng + kVerts - 1) / kVerts;
+    unsigned long long p2p = 0, bst = 0;
+    int rounds = 0;
+    int remaining = ng;
+    while (remaining > 0 && (a.max_rounds <= 0 || rounds < a.max_rounds)) {
+        if (STATS && threadIdx.x == 0) bst += (unsigned long long)remaining;
+        // ---------------- phase A: who wins this round
+        for (int p = 0; p < passes; ++p) {
+            const int v = p * kVerts + slot;
+            const bool live = v < ng && st[v] == 0;
+            bool lost = false;
+            int resid = 0;
+            if (live) {
+                const double pv = pr[v];
+                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+                for (int j = rs + sub; j < re; j += LPV) {
+                    const int u = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                    if (st[u] == 0) {
+                        const double pu = pr[u];
+                        lost |= (pu > pv) || (pu == pv && u < v);
+                        ++resid;
+                    }
+                }
+            }
+            if (LPV > 1) {
+                const unsigned long long m = __ballot(lost);
+                lost = ((m >> gshift) & gmask) != 0ull;
+            }
+            if (STATS) {
+#pragma unroll
+                for (int off = 1; off < LPV; off <<= 1) resid += __shfl_xor(resid, off);
+            }
+            if (live && sub == 0) {
+                nw[v] = lost ? 0 : 1;
+                if (STATS) {
+                    p2p += (unsigned long long)resid;
+                    if (a.overhead) a.overhead[n0 + v] += resid + ((!lost && resid > 0) ? 1 : 0);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- phase B: winners join, their remaining neighbours are excluded
+        for (int p = 0; p < passes; ++p) {
+            const int v = p * kVerts + slot;
+            if (v < ng && st[v] == 0 && nw[v]) {
+                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+                for (int j = rs + sub; j < re; j += LPV) {
+                    const int u = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                    if (st[u] == 0) st[u] = 2;  // same value from every writer: benign
+                }
+            }
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int v = threadIdx.x; v < ng; v += 256) {
+            if (st[v] == 0) {
+                if (nw[v]) st[v] = 1; else ++mine;
+            }
+            nw[v] = 0;
+        }
+        remaining = __syncthreads_count(mine > 0) ? 1 : 0;
+        if (remaining) {
+            // exact count only matters for bst (stats); otherwise "some remain" is enough
+            if (STATS) {
+                if (threadIdx.x == 0) acc64[2] = 0;
+                __syncthreads();
+                if (mine) atomicAdd(&acc64[2], (unsigned long long)mine);
+                __syncthreads();
+                remaining = (int)acc64[2];
+            }
+        }
+        ++rounds;
+    }
+    if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+    if (STATS) {
+        if (threadIdx.x == 0) { acc64[0] = 0; acc64[1] = 0; }
+        __syncthreads();
+        if (p2p) atomicAdd(&acc64[0], p2p);
+        int members = 0;
+        for (int v = threadIdx.x; v < ng; v += 256) members += st[v] == 1;
+        if (members) atomicAdd(&acc64[1], (unsigned long long)members);
+        __syncthreads();
+        if (threadIdx.x == 0 && a.stats) {
+            a.stats[2 * g + 0] = (int64_t)acc64[0];
+            a.stats[2 * g + 1] = (int64_t)(bst + acc64[1]);  // bst += len(mwis) (heuristics.py:208)
+        }
+    }
+}
+
+template <int LPV, bool STATS>
+__global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int g = blockIdx.x;
+    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
+    const int ng = n1 - n0;
+    // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | u8 st | u8 nw | u16 cols]
+    double* pr = reinterpret_cast<double*>(lds_raw);
+    double* red = pr + a.max_nodes;
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 256);
+    uint8_t* st = reinterpret_cast<uint8_t*>(acc64 + 4);
+    uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
+    uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
+    if (ng <= 0) {
+        if (threadIdx.x == 0) {
+            if (a.rounds) a.rounds[g] = 0;
+            if (a.stats) { a.stats[2 * g] = 0; a.stats[2 * g + 1] = 0; }
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        return;
+    }
+    int bad = 0;
+    for (int v = threadIdx.x; v < ng; v += 256) {
+        double p;
+        if (a.prio) p = a.prio[n0 + v];
+        else if (a.weights) p = (double)a.scores[n0 + v] * a.weights[n0 + v];
+        else p = (double)a.scores[n0 + v];
+        bad |= (p != p);
+        pr[v] = p;
+        st[v] = 0;
+        nw[v] = 0;
+        if (STATS && a.overhead) a.overhead[n0 + v] = 0;
+    }
+    const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
+    const bool cols_lds = (e1 - e0) <= a.cols_cap && ng <= 65536;
+    if (cols_lds)
+        for (int j = e0 + threadIdx.x; j < e1; j += 256) cl[j - e0] = (uint16_t)(a.col_idx[j] - n0);
+    if (__syncthreads_or(bad)) {
+        // the reference would spin forever on a NaN priority: report instead
+        if (threadIdx.x == 0) {
+            atomicOr(a.status, DGCN_FAULT_NAN_PRIORITY);
+            if (a.rounds) a.rounds[g] = -1;
+            if (a.stats) { a.stats[2 * g] = 0; a.stats[2 * g + 1] = 0; }
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = 0;
+        return;
+    }
+    if (cols_lds) lgs_rounds<LPV, STATS, true>(a, g, n0, ng, e0, pr, st, nw, cl, acc64);
+    else lgs_rounds<LPV, STATS, false>(a, g, n0, ng, e0, pr, st, nw, cl, acc64);
+
+    for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = st[v];
+    if (a.totals) {
+        // fixed-shape reduction: strided partials, then a binary tree over the 256 slots
+        const double* sw = a.sum_weights;
+        double part = 0.0;
+        for (int v = threadIdx.x; v < ng; v += 256)
+            if (st[v] == 1) part += sw ? sw[n0 + v] : pr[v];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.totals[g] = red[0];
+    }
+}
+
+static size_t lgs_lds_bytes(int max_nodes, int cols_cap) {
+    const size_t pad = (size_t)((max_nodes + 15) & ~15);
+    return (size_t)max_nodes * 8 + 256 * 8 + 4 * 8 + 2 * pad + (size_t)cols_cap * 2;
+}
+
+template <int LPV, bool STATS>
+static int launch_lgs(const LgsArgs& a, int B, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lgs<LPV, STATS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_lgs: cannot reserve %zu bytes of LDS", lds);
+    }
+    TimedLaunch t("lgs", s);
+    hipLaunchKernelGGL((k_lgs<LPV, STATS>), dim3(B), dim3(256), lds, s, a);
+    return check_launch("k_lgs");
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const float* scores, const double* weights,
+                              int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                              const double* sum_weights, double* totals, int32_t* status, void* stream) {
+    if (!b || !state || !status) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: null argument");
+    if (!prio && !scores) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: need prio or scores");
+    if (b->num_graphs <= 0) return DGCN_OK;
+    if (b->max_nodes <= 0) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: max_nodes must be positive");
+    constexpr size_t kLdsMax = 156 * 1024;
+    if (lgs_lds_bytes(b->max_nodes, 0) > kLdsMax)
+        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_lgs_batch: graphs of %d vertices exceed the per-workgroup LDS state",
+                    b->max_nodes);
+    LgsArgs a;
+    a.graph_ptr = b->graph_ptr; a.row_ptr = b->row_ptr; a.col_idx = b->col_idx;
+    a.prio = prio; a.scores = scores; a.weights = weights; a.max_rounds = max_rounds;
+    a.state = state; a.rounds = rounds; a.stats = stats; a.overhead = overhead;
+    a.sum_weights = sum_weights; a.totals = totals; a.status = status;
+    a.max_nodes = b->max_nodes;
+    // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
+    // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
+    int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;
+    if (cap > 0 && lgs_lds_bytes(b->max_nodes, cap) > kLdsMax) cap = 0;
+    a.cols_cap = cap;
+    const size_t lds = lgs_lds_bytes(b->max_nodes, cap);
+    hipStream_t s = (hipStream_t)stream;
+    const bool want_stats = stats != nullptr || overhead != nullptr;
+    static const int lpv_env = getenv("DGCN_LGS_LPV") ? atoi(getenv("DGCN_LGS_LPV")) : 0;
+    int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 64 ? 4 : (b->max_nodes <= 128 ? 2 : 1));
+#define DGCN_LGS_CASE(L)                                                      \
+    if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs, lds, s) \
+                                    : launch_lgs<L, false>(a, b->num_graphs, lds, s)
+    DGCN_LGS_CASE(1);
+    DGCN_LGS_CASE(2);
+    DGCN_LGS_CASE(4);
+    DGCN_LGS_CASE(8);
+#undef DGCN_LGS_CASE
+    return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: DGCN_LGS_LPV must be 1, 2, 4 or 8");
+}

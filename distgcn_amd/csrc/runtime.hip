@@ -1,0 +1,99 @@
+// Error reporting, version and per-kernel-family event timing for libdgcn.so.
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace dgcn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Timing: when enabled, each TimedLaunch records (start, stop) events on the launch stream.
+// Nothing is synchronised until dgcn_timing_read().
+struct TimingSlot {
+    std::string family;
+    hipEvent_t start, stop;
+    bool used;
+};
+static std::mutex g_tmu;
+static std::vector<TimingSlot> g_slots;
+static size_t g_live = 0;  // slots [0, g_live) carry a recorded pair
+static bool g_timing = false;
+
+TimedLaunch::TimedLaunch(const char* family, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (g_live == g_slots.size()) {
+        TimingSlot t;
+        t.used = false;
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
+        g_slots.push_back(t);
+    }
+    slot = (int)g_live++;
+    g_slots[slot].family = family;
+    g_slots[slot].used = true;
+    (void)hipEventRecord(g_slots[slot].start, stream);
+}
+
+TimedLaunch::~TimedLaunch() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    (void)hipEventRecord(g_slots[slot].stop, stream);
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_version(void) { return DGCN_VERSION; }
+extern "C" const char* dgcn_last_error(void) { return g_err; }
+
+extern "C" int dgcn_timing_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timing = on != 0;
+    return DGCN_OK;
+}
+
+extern "C" int dgcn_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_live = 0;
+    return DGCN_OK;
+}
+
+extern "C" int dgcn_timing_read(const char* kernel, double* total_ms, int64_t* launches) {
+    if (!kernel || !total_ms || !launches) return fail(DGCN_ERR_ARG, "dgcn_timing_read: null argument");
+    std::lock_guard<std::mutex> lk(g_tmu);
+    double ms = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i < g_live; ++i) {
+        if (g_slots[i].family != kernel) continue;
+        if (hipEventSynchronize(g_slots[i].stop) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "dgcn_timing_read: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_slots[i].start, g_slots[i].stop) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "dgcn_timing_read: elapsed failed");
+        ms += t;
+        ++n;
+    }
+    *total_ms = ms;
+    *launches = n;
+    return DGCN_OK;
+}

@@ -1,0 +1,152 @@
+// Feature transform Z = H . [W_0 | W_1 | ...] for every node of the batch.
+// Replaces dot(x, W_i) of GraphConvolution._call (gcn/layers.py:202-203; tf.matmul / cuBLAS SGEMM
+// in the reference, K2/K3 of SURVEY 2.2).
+//
+// The hidden 32x32 (c32) product is a dense contraction -> fp32 MFMA (v_mfma_f32_32x32x2_f32),
+// which on gfx950 is bit-for-bit a k-ordered fmaf chain, so the VALU fallback (first layer,
+// last layer, odd widths) and oracle/dgcn_oracle.c produce identical bits with a plain
+// "acc = fmaf(h[k], w[k][n], acc)" loop.  No bf16/fp16: the 1e-5 score tolerance forbids it.
+//
+// Per launch the kernel is HBM-bound (reads rows*cin*4, writes rows*ctot*4 bytes); the MFMA work
+// (rows*cin*ctot*2 flop) is ~3x below the fp32 matrix peak at that byte rate.
+#include "common.h"
+
+namespace dgcn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// One wave = one 32-row tile x all CTOT columns.  256 threads = 4 waves = 128 rows per block.
+template <int CIN, int CTOT>
+__global__ __launch_bounds__(256) void k_transform_mfma(const float* __restrict__ H, int ldh, int rows,
+                                                        const float* __restrict__ W, float* __restrict__ Z,
+                                                        int ldz) {
+    constexpr int KS = CIN / 2;      // MFMA k-steps (2 k per instruction)
+    constexpr int CT = CTOT / 32;    // column tiles
+    constexpr int LDS_LD = CIN + 1;  // +1 float: conflict-free column reads (ds_read_b32, 32 banks)
+    __shared__ float tile[4][32 * LDS_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, idx = lane & 31;
+
+    // B fragments for every (k-step, column tile): lane holds W[2s + half][ct*32 + idx]
+    float bfrag[KS][CT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bfrag[s][ct] = W[(2 * s + half) * CTOT + ct * 32 + idx];
+
+    float* my = tile[wave];
+    for (int row0 = (blockIdx.x * 4 + wave) * 32; row0 < rows; row0 += gridDim.x * 128) {
+        // ---- stage the 32 x CIN tile of H: coalesced float4 loads -> padded LDS
+        constexpr int Q = CIN / 4;
+#pragma unroll
+        for (int t = 0; t < (32 * Q + 63) / 64; ++t) {
+            const int i = lane + 64 * t;
+            if (i < 32 * Q) {
+                const int r = i / Q, q = i - r * Q;
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < rows) h = *reinterpret_cast<const float4*>(H + (size_t)(row0 + r) * ldh + q * 4);
+                float* dst = my + r * LDS_LD + q * 4;
+                dst[0] = h.x; dst[1] = h.y; dst[2] = h.z; dst[3] = h.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+        // A fragments: lane holds H[row0 + idx][2s + half]
+        float afrag[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) afrag[s] = my[idx * LDS_LD + 2 * s + half];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[s], bfrag[s][ct], acc, 0, 0, 0);
+            // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                if (r < rows) Z[(size_t)r * ldz + ct * 32 + idx] = acc[reg];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // tile is overwritten by the next iteration
+    }
+}
+
+// VALU fallback: one thread per output element, k-ordered fmaf chain (same bits as the MFMA path).
+__global__ __launch_bounds__(256) void k_transform_valu(const float* __restrict__ H, int ldh, float h_const, int rows,
+                                                        int cin, const float* __restrict__ W, int ctot,
+                                                        float* __restrict__ Z, int ldz) {
+    const long total = (long)rows * ctot;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / ctot), n = (int)(i - (long)r * ctot);
+        float acc = 0.f;
+        if (H) {
+            const float* h = H + (size_t)r * ldh;
+            for (int k = 0; k < cin; ++k) acc = fmaf(h[k], W[k * ctot + n], acc);
+        } else {
+            for (int k = 0; k < cin; ++k) acc = fmaf(h_const, W[k * ctot + n], acc);
+        }
+        Z[(size_t)r * ldz + n] = acc;
+    }
+}
+
+// Narrow outputs (last layer: ctot = num_supports * 1): one thread per row keeps the H row in
+// registers and produces all ctot chains, so H is read once.
+template <int CTOT>
+__global__ __launch_bounds__(256) void k_transform_narrow(const float* __restrict__ H, int ldh, int rows, int cin,
+                                                          const float* __restrict__ W, float* __restrict__ Z,
+                                                          int ldz) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const float* h = H + (size_t)r * ldh;
+        float acc[CTOT];
+#pragma unroll
+        for (int n = 0; n < CTOT; ++n) acc[n] = 0.f;
+        for (int k = 0; k < cin; ++k) {
+            const float hk = h[k];
+#pragma unroll
+            for (int n = 0; n < CTOT; ++n) acc[n] = fmaf(hk, W[k * CTOT + n], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < CTOT; ++n) Z[(size_t)r * ldz + n] = acc[n];
+    }
+}
+
+int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
+                       int ldz, hipStream_t s) {
+    if (rows <= 0) return DGCN_OK;
+    TimedLaunch t("transform", s);
+    const bool aligned = H && (ldh % 4 == 0) && ((uintptr_t)H % 16 == 0);
+    const int mfma_blocks = min(ceil_div(rows, 128), 256 * 8);
+#define DGCN_TF_CASE(CI, CO)                                                                                     \
+    if (aligned && cin == CI && ctot == CO) {                                                                    \
+        hipLaunchKernelGGL((k_transform_mfma<CI, CO>), dim3(mfma_blocks), dim3(256), 0, s, H, ldh, rows, W, Z, ldz); \
+        return check_launch("k_transform_mfma");                                                                 \
+    }
+    DGCN_TF_CASE(32, 64)
+    DGCN_TF_CASE(32, 32)
+    DGCN_TF_CASE(16, 32)
+    DGCN_TF_CASE(16, 64)
+    DGCN_TF_CASE(64, 128)
+    DGCN_TF_CASE(64, 64)
+    DGCN_TF_CASE(8, 32)
+#undef DGCN_TF_CASE
+    if (H && ctot == 2) {
+        hipLaunchKernelGGL((k_transform_narrow<2>), dim3(min(ceil_div(rows, 256), 4096)), dim3(256), 0, s, H, ldh, rows,
+                           cin, W, Z, ldz);
+        return check_launch("k_transform_narrow");
+    }
+    const long total = (long)rows * ctot;
+    const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
+    hipLaunchKernelGGL(k_transform_valu, dim3(blocks), dim3(256), 0, s, H, ldh, h_const, rows, cin, W, ctot, Z, ldz);
+    return check_launch("k_transform_valu");
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_transform_batch(const float* H, int32_t ldh, float h_const, int32_t rows, int32_t cin,
+                                    const float* W, int32_t ctot, float* Z, int32_t ldz, void* stream) {
+    if (!W || !Z) return fail(DGCN_ERR_ARG, "dgcn_transform_batch: null argument");
+    if (cin <= 0 || ctot <= 0 || ldz < ctot || (H && ldh < cin)) return fail(DGCN_ERR_ARG, "dgcn_transform_batch: bad sizes");
+    return transform_dispatch(H, ldh, h_const, rows, cin, W, ctot, Z, ldz, (hipStream_t)stream);
+}

@@ -1,0 +1,161 @@
+/*
+ * dgcn.h - C ABI of libdgcn.so: the MI355X (gfx950) implementation of distgcn's
+ * GCN-forward + local-greedy MWIS hot path.
+ *
+ * The reference (zhongyuanzhao/distgcn) is pure Python and has no native ABI; each entry point
+ * below names the reference Python interface it replaces (file:line relative to the reference
+ * root).  The Python shim in distgcn_amd/ binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller unless its name ends in _host.
+ *    The library allocates nothing per call and keeps no caller pointer after returning.
+ *  - All launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream).  No entry point synchronises the device.
+ *  - Return value: 0 = ok, < 0 = error; dgcn_last_error() gives the thread-local message.
+ *  - A batch of graphs is ONE block-diagonal CSR: graph g owns global node ids
+ *    [graph_ptr[g], graph_ptr[g+1]); col_idx holds GLOBAL node ids; indices are int32.
+ *    The adjacency is symmetric, has no self-loops and implicit values 1.0 (what
+ *    Data_Generation.py:218 stores and heuristics.py:77-116 requires).
+ *  - Data-dependent faults (self-loop, NaN priority, degree beyond the table) cannot be
+ *    returned synchronously; kernels OR a bit into the caller's device word `status`
+ *    (DGCN_FAULT_*), which the caller reads together with the results.
+ */
+#ifndef DGCN_H
+#define DGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGCN_VERSION 100 /* 0.1.0 */
+
+enum { DGCN_OK = 0, DGCN_ERR_ARG = -1, DGCN_ERR_LAUNCH = -2, DGCN_ERR_UNSUPPORTED = -3, DGCN_ERR_WORKSPACE = -4 };
+
+/* activation codes (gcn/layers.py:216; tf.nn.leaky_relu alpha = 0.2, gcn/models.py:553) */
+enum { DGCN_ACT_LINEAR = 0, DGCN_ACT_LEAKY_RELU = 1, DGCN_ACT_RELU = 2 };
+
+/* bits OR-ed into *status by kernels */
+enum {
+    DGCN_FAULT_SELF_LOOP = 1,    /* adjacency has a diagonal entry (heuristics.py:94 would loop forever) */
+    DGCN_FAULT_NAN_PRIORITY = 2, /* NaN priority (heuristics.py:103-111 never selects it: infinite loop) */
+    DGCN_FAULT_DEGREE_RANGE = 4, /* vertex degree >= dinv_table length */
+    DGCN_FAULT_BAD_COLUMN = 8    /* column id outside the owning graph's node range */
+};
+
+/* Block-diagonal adjacency of a batch (host struct holding device pointers). */
+typedef struct DgcnBatch {
+    int32_t num_graphs;       /* B */
+    int32_t num_nodes;        /* sum of N_g */
+    int32_t num_edges;        /* sum of nnz(A_g) (directed count, = 2 x undirected edges) */
+    int32_t max_nodes;        /* max N_g (sizes LDS tiles and launch geometry) */
+    int32_t max_graph_edges;  /* max nnz(A_g) over the batch (sizes the LDS copy of one graph's columns) */
+    const int32_t* graph_ptr; /* [B+1]   node offsets */
+    const int32_t* row_ptr;   /* [num_nodes+1] */
+    const int32_t* col_idx;   /* [num_edges]   global node ids */
+} DgcnBatch;
+
+/* A support matrix S (T1 = L = I - D^-1/2 A D^-1/2) in CSR, block-diagonal like the batch.
+ * Row v stores its diagonal entry FIRST, then the neighbours in adjacency order:
+ * row_ptr[v] = batch.row_ptr[v] + v, nnz = num_edges + num_nodes. */
+typedef struct DgcnCsr {
+    int32_t num_rows;
+    int32_t nnz;
+    const int32_t* row_ptr; /* [num_rows+1] */
+    const int32_t* col_idx; /* [nnz] global ids */
+    const float* values;    /* [nnz] */
+} DgcnCsr;
+
+/* One GraphConvolution layer (gcn/layers.py:149-216). */
+typedef struct DgcnLayer {
+    int32_t in_dim;
+    int32_t out_dim;
+    const float* weights; /* [in_dim][num_supports * out_dim] row-major: column block i is weights_i of
+                             layers.py:174-182, so one product H.weights yields every pre_sup of :202 */
+    const float* bias;    /* [out_dim] or NULL (layers.py:183-184) */
+    int32_t act;          /* DGCN_ACT_* */
+} DgcnLayer;
+
+/* GCN_DQN / GCN2_DQN layer stack (gcn/models.py:536-573, 670-708). */
+typedef struct DgcnModel {
+    int32_t num_layers;
+    int32_t num_supports;          /* 1 + max_degree; this library implements 2 ([I, L]) */
+    const DgcnLayer* layers_host;  /* HOST array of num_layers descriptors */
+} DgcnModel;
+
+int dgcn_version(void);
+const char* dgcn_last_error(void);
+
+/* ---- A1/A2: gcn/utils.py:120-127 normalize_adj + :258-274 simple_polynomials (k = 1) ----------
+ * Builds L = I - D^-1/2 A D^-1/2 for the whole batch.  dinv_table[d] must hold the float64 value
+ * numpy.power(d, -0.5) with inf -> 0 (table built once by the host so the float64 bits equal the
+ * reference's); each off-diagonal is (float)(-(dinv[deg u] * dinv[deg v])), the diagonal 1.0f -
+ * exactly the float32 the reference feeds TF after its float64 -> float32 cast.
+ * Outputs (caller-allocated): lap_row_ptr[num_nodes+1], lap_col[num_edges+num_nodes],
+ * lap_val[num_edges+num_nodes].  Faults: SELF_LOOP, DEGREE_RANGE, BAD_COLUMN. */
+int dgcn_supports_batch(const DgcnBatch* batch, const double* dinv_table, int32_t table_len,
+                        int32_t* lap_row_ptr, int32_t* lap_col, float* lap_val,
+                        int32_t* status, void* stream);
+
+/* ---- K4 (+K5-K7): gcn/layers.py:206 sparse_tensor_dense_matmul, :208 add_n, :211 bias, :216 act
+ * Y[v, 0:C] = act( Y0[v, 0:C] + sum_j S.values[j] * Z[S.col_idx[j], 0:C] + bias[0:C] )
+ * for every row v of the block-diagonal S; the row sum is a float32 fmaf chain in CSR order
+ * starting from 0, then "+ Y0", then "+ bias".  Y0 and bias may be NULL (plain SpMM: K4 alone).
+ * ldz / ldy / ldy0 are row strides in floats.  graph_ptr/num_graphs/max_nodes let a workgroup
+ * keep its graph's slice of Z in LDS; pass graph_ptr = NULL to force the global-gather path. */
+int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
+                    const float* Z, int32_t ldz, int32_t C,
+                    const float* Y0, int32_t ldy0, const float* bias, int32_t act,
+                    float* Y, int32_t ldy, void* stream);
+
+/* ---- K2/K3: gcn/layers.py:29-31 dot(x, W_i) for all supports at once -------------------------
+ * Z[r, 0:ctot] = sum_k H[r, k] * W[k, 0:ctot], a float32 fmaf chain over k = 0..cin-1 starting
+ * from 0 (bit-identical between the MFMA and the VALU code paths).  W is [cin][ctot] row-major
+ * (the per-support weights_i concatenated along columns).  H == NULL means every entry of H
+ * equals h_const (the reference's row-normalised all-ones features, gcn/utils.py:98-106). */
+int dgcn_transform_batch(const float* H, int32_t ldh, float h_const, int32_t rows, int32_t cin,
+                         const float* W, int32_t ctot, float* Z, int32_t ldz, void* stream);
+
+/* ---- A4-A6: sess.run(model.outputs_softmax) for a batch (mwis_dqn_call.py:140-143) ------------
+ * scores[num_nodes * out_dim] = GCN forward over the batch.  X is the dense row-normalised
+ * feature matrix [num_nodes][in_dim] or NULL for "every entry = x_const".
+ * workspace: dgcn_gcn_forward_workspace() bytes of device scratch.
+ * mode: 0 = layer-by-layer (transform + SpMM kernels), 1 = fused per-graph persistent kernel. */
+size_t dgcn_gcn_forward_workspace(const DgcnBatch* batch, const DgcnModel* model, int32_t mode);
+int dgcn_gcn_forward_batch(const DgcnBatch* batch, const DgcnCsr* lap, const DgcnModel* model,
+                           const float* X, float x_const, float* scores,
+                           void* workspace, size_t workspace_bytes, int32_t mode, void* stream);
+
+/* ---- models.py:526/660  pred = argmax(outputs, axis 0), per graph, first maximum wins ---------*/
+int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr, int32_t num_graphs,
+                      int32_t* arg_out, void* stream);
+
+/* ---- A7 + A8/A8'/A9: heuristics.py:77-305 local_greedy_search{,_count,_stats,_overhead,_nstep}
+ * and heuristics.py:13-35 greedy_search (same set under the (w desc, index asc) order) ----------
+ * Priority of vertex v: prio[v] if prio != NULL, else (double)scores[v] * weights[v]
+ * (mwis_dqn_call.py:232, f32 x f64 -> f64) or (double)scores[v] when weights == NULL.
+ * Rounds run until no vertex remains or max_rounds (> 0) rounds have run (_nstep, :280).
+ * Outputs (any may be NULL except state):
+ *   state[num_nodes]    1 = in the set, 2 = excluded as neighbour of a member (nb_is), 0 = still remaining
+ *   rounds[B]           rounds executed (:160)
+ *   stats[B][2]         {p2p, bst} of _stats (:184-208)
+ *   overhead[num_nodes] per-vertex message count of _overhead (:236-262)
+ *   totals[B]           sum of sum_weights[v] over members (:115; float64)
+ * Faults: NAN_PRIORITY (that graph is left untouched: state 0, rounds -1). */
+int dgcn_lgs_batch(const DgcnBatch* batch, const double* prio, const float* scores, const double* weights,
+                   int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                   const double* sum_weights, double* totals, int32_t* status, void* stream);
+
+/* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
+ * enable(1) makes every launch of the named kernel families record an event pair;
+ * read() synchronises those events and returns the summed milliseconds and launch count. */
+int dgcn_timing_enable(int32_t on);
+int dgcn_timing_reset(void);
+int dgcn_timing_read(const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGCN_H */
