@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: GCN forward + local-greedy MWIS on a batch of conflict graphs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the whole hot path over one batch already resident in HBM:
+support construction (L = I - D^-1/2 A D^-1/2) -> 20-layer c32 GCN forward -> priority product ->
+local greedy search.  Workload at every N: BASELINE.json configs[2] (C3), 500 ER graphs
+G(200, 0.1) per GPU (weak scaling: each rank owns its own 500 graphs; no data-path collective, the
+only collective is the final gather of memberships, outside nothing - it is inside the timed step).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU")
+    ap.add_argument("--nodes", type=int, default=200)
+    ap.add_argument("--p", type=float, default=0.1)
+    ap.add_argument("--layers", type=int, default=20)
+    ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--mode", choices=["layered", "fused", "auto"], default="auto")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step membership gather at N>1")
+    return ap.parse_args()
+
+
+def load_layers(args):
+    """Trained weights of the shipped IS4SAT l20/c32 checkpoint when the fixture copy is present
+    (tests/golden/models.npz), random Glorot weights of the same architecture otherwise."""
+    from distgcn_amd import datagen
+    from distgcn_amd.gcn.models import layers_from_params
+    path = os.path.join(ROOT, "tests", "golden", "models.npz")
+    name = "result_IS4SAT_deep_ld1_c%d_l%d_cheb1_diver1_mwis_dqn" % (args.hidden, args.layers)
+    if os.path.isfile(path):
+        z = np.load(path)
+        pre = name + "|"
+        params = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+        if params:
+            return layers_from_params(params), "trained weights (fixture of the reference's %s)" % name
+    return datagen.random_model(args.layers, args.hidden), "random-init weights"
+
+
+def spmm_algorithmic_bytes(hb, layers):
+    """SURVEY 8d formula per SpMM launch, summed over the layers of one forward:
+    sum_g[nnz_g*(4+4) + (N_g+1)*4] + 2*4*C*sum N_g, plus 4*C*sum N_g for the fused '+ Z0' read."""
+    n, nnz_l = hb.num_nodes, hb.num_edges + hb.num_nodes
+    csr = nnz_l * 8 + (n + hb.num_graphs) * 4
+    per_launch = []
+    for lyr in layers:
+        c = lyr["weights"][0].shape[1]
+        per_launch.append(csr + 3 * 4 * c * n)
+    return per_launch
+
+
+def cpu_baseline(hb, layers, budget_s):
+    """The oracle restatement of the reference path (SciPy supports -> NumPy forward -> Python-set
+    local greedy, oracle/ref_numpy.py), one process / one core like the reference, on a bounded
+    sample of the same batch.  Reported beside the GPU number; never part of it."""
+    from oracle import ref_numpy as orc
+    done = 0
+    t0 = time.perf_counter()
+    while done < hb.num_graphs:
+        adj = hb.scipy_graph(done)
+        n0, n1 = hb.graph_slices()[done]
+        orc.solve_mwis_gdpg(layers, adj, hb.weights[n0:n1], feature_size=1)
+        done += 1
+        if time.perf_counter() - t0 > budget_s and done >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "graphs/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the %d graphs of rank 0's batch, %.1f s, python oracle/ref_numpy.solve_mwis_gdpg"
+                      % (done, hb.num_graphs, dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import Engine, DeviceModel, MODE_LAYERED, MODE_FUSED
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
+    layers, weights_note = load_layers(args)
+    eng = Engine(dev)
+    db = eng.upload(hb)
+    model = DeviceModel(layers, dev)
+    mode_name = args.mode
+    if mode_name == "auto":
+        mode_name = os.environ.get("DGCN_BENCH_MODE", "layered")
+    mode = MODE_FUSED if mode_name == "fused" else MODE_LAYERED
+
+    gather_buf = None
+    if world > 1 and not args.no_gather:
+        gather_buf = torch.empty(world * hb.num_nodes, dtype=torch.uint8, device=dev)
+
+    def step():
+        db.lap = None  # supports are part of the path: rebuild them every step
+        res = eng.solve(db, model, mode=mode)
+        if gather_buf is not None:  # the batch gather of SURVEY 8e (membership only; every rank has equal N)
+            dist.all_gather_into_tensor(gather_buf, res["state"])
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    eng.check_status(res["status"])
+
+    eng.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    eng.timing(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the
+    # timed region (on the launch stream), against algorithmic bytes
+    fam_ms = {}
+    for fam in ("supports", "transform", "spmm", "lgs", "fused_forward", "fused_solve"):
+        ms, n = eng.timing_read(fam)
+        if n:
+            fam_ms[fam] = (ms, n)
+    roofline = None
+    if fam_ms:
+        dom = max(fam_ms, key=lambda k: fam_ms[k][0])
+        ms, n = fam_ms[dom]
+        avg_s = ms / n * 1e-3
+        if dom == "spmm":
+            per = spmm_algorithmic_bytes(hb, layers)
+            avg_bytes = sum(per) / len(per)
+            ach = avg_bytes / avg_s / 1e9
+            roofline = {"kernel": "k_spmm_lds (all %d launches per step)" % len(per), "bound": "hbm",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": avg_bytes}
+        elif dom in ("fused_forward", "fused_solve"):
+            flops = 0.0
+            n_nodes, nnz_l = hb.num_nodes, hb.num_edges + hb.num_nodes
+            for lyr in layers:
+                cin, cout = lyr["weights"][0].shape
+                flops += 2.0 * n_nodes * cin * 2 * cout + 2.0 * nnz_l * cout
+            ach = flops / avg_s / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_TF, "traffic": None,
+                        "avg_launch_us": avg_s * 1e6, "algorithmic_flops_per_launch": flops}
+        else:
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": None, "traffic": None, "avg_launch_us": avg_s * 1e6}
+    kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
+
+    if rank == 0:
+        out = {
+            "metric": "graphs/sec (GCN fwd + greedy MWIS) on ER N=%d p=%g" % (args.nodes, args.p),
+            "value": world * args.graphs * args.steps / dt,
+            "unit": "graphs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic ER graphs (seeded), uniform(0,1) weights; " + weights_note,
+            "config": {"workload": "C3: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN forward + local greedy, "
+                                   "supports rebuilt every step" % (args.graphs, args.nodes, args.p, args.layers, args.hidden),
+                       "forward_mode": mode_name, "graphs_per_gpu": args.graphs, "parallelism": "graph-sharded x%d" % world},
+            "roofline": roofline,
+            "kernels": kernel_us,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(hb, layers, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

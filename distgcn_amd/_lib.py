@@ -23,7 +23,7 @@ FAULT_NAMES = {
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
-    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_spmm_batch", "dgcn_transform_batch",
+    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
     "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_argmax_batch", "dgcn_lgs_batch",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
@@ -43,7 +43,7 @@ class DgcnBatch(C.Structure):
 
 class DgcnCsr(C.Structure):
     _fields_ = [
-        ("num_rows", C.c_int32), ("nnz", C.c_int32),
+        ("num_rows", C.c_int32), ("nnz", C.c_int32), ("max_graph_nnz", C.c_int32),
         ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("values", C.c_void_p),
     ]
 
@@ -72,12 +72,18 @@ def load():
             "%s is missing: the HIP extension has not been built. Run "
             "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, targets gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  It must be in the process first so
+    # that libdgcn.so binds to THAT runtime; loading ours first would put two HIP runtimes in one
+    # process and every launch would fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
     lib.dgcn_version.restype = C.c_int
     lib.dgcn_last_error.restype = C.c_char_p
     lib.dgcn_supports_batch.restype = C.c_int
     lib.dgcn_supports_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
+    lib.dgcn_spmm_split.restype = C.c_int
+    lib.dgcn_spmm_split.argtypes = [i32]
     lib.dgcn_spmm_batch.restype = C.c_int
     lib.dgcn_spmm_batch.argtypes = [C.POINTER(DgcnCsr), vp, i32, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, vp]
     lib.dgcn_transform_batch.restype = C.c_int

@@ -1,0 +1,120 @@
+"""Block-diagonal CSR batches of conflict graphs (host build + device residency).
+
+The reference handles one SciPy matrix per call (``mwis_dqn_call.py:198-261``); here many graphs are
+packed into one block-diagonal CSR so a single launch covers the whole batch.  Layout (see
+``include/dgcn.h``): ``graph_ptr[B+1]`` node offsets, ``row_ptr[N+1]``, ``col_idx[nnz]`` with GLOBAL
+node ids, int32 everywhere; adjacency values are implicit 1.0.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+class HostBatch:
+    """Host-side block-diagonal CSR (NumPy only; no GPU needed)."""
+
+    def __init__(self, graph_ptr, row_ptr, col_idx, weights=None):
+        self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self.num_graphs = int(self.graph_ptr.size - 1)
+        self.num_nodes = int(self.graph_ptr[-1]) if self.graph_ptr.size else 0
+        self.num_edges = int(self.row_ptr[-1]) if self.row_ptr.size else 0
+        sizes = np.diff(self.graph_ptr)
+        self.max_nodes = int(sizes.max()) if sizes.size else 0
+        gedges = self.row_ptr[self.graph_ptr[1:]] - self.row_ptr[self.graph_ptr[:-1]] if self.num_graphs else np.zeros(0)
+        self.max_graph_edges = int(gedges.max()) if self.num_graphs else 0
+        deg = np.diff(self.row_ptr)
+        self.max_degree = int(deg.max()) if deg.size else 0
+        if self.row_ptr.size != self.num_nodes + 1:
+            raise ValueError("row_ptr has %d entries, expected %d" % (self.row_ptr.size, self.num_nodes + 1))
+        if self.weights is not None and self.weights.size != self.num_nodes:
+            raise ValueError("weights has %d entries, expected %d" % (self.weights.size, self.num_nodes))
+
+    @staticmethod
+    def from_csr_lists(indptrs: Sequence[np.ndarray], indices: Sequence[np.ndarray],
+                       weights: Optional[Sequence[np.ndarray]] = None) -> "HostBatch":
+        sizes = np.array([p.size - 1 for p in indptrs], dtype=np.int64)
+        nnzs = np.array([int(p[-1]) for p in indptrs], dtype=np.int64)
+        graph_ptr = np.zeros(len(indptrs) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=graph_ptr[1:])
+        edge_ptr = np.zeros(len(indptrs) + 1, dtype=np.int64)
+        np.cumsum(nnzs, out=edge_ptr[1:])
+        if graph_ptr[-1] >= 2 ** 31 or edge_ptr[-1] >= 2 ** 31 - graph_ptr[-1]:
+            raise ValueError("batch too large for int32 indices")
+        row_ptr = np.empty(graph_ptr[-1] + 1, dtype=np.int32)
+        col_idx = np.empty(edge_ptr[-1], dtype=np.int32)
+        row_ptr[0] = 0
+        for g, (p, c) in enumerate(zip(indptrs, indices)):
+            n0, e0 = graph_ptr[g], edge_ptr[g]
+            row_ptr[n0 + 1:n0 + p.size] = p[1:] + e0
+            col_idx[e0:e0 + c.size] = c + n0
+        w = None
+        if weights is not None:
+            w = np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in weights]) if len(weights) else np.zeros(0)
+        return HostBatch(graph_ptr, row_ptr, col_idx, w)
+
+    @staticmethod
+    def from_scipy(adjs: Sequence, weights: Optional[Sequence] = None) -> "HostBatch":
+        """Pack SciPy matrices (any format; ``loadmat`` gives COO/CSC) into one batch."""
+        ps, cs = [], []
+        for a in adjs:
+            a = sp.csr_matrix(a)
+            if a.shape[0] != a.shape[1]:
+                raise ValueError("adjacency must be square")
+            a.sum_duplicates()
+            a.sort_indices()
+            ps.append(a.indptr.astype(np.int64))
+            cs.append(a.indices.astype(np.int64))
+        return HostBatch.from_csr_lists(ps, cs, weights)
+
+    def graph_slices(self):
+        return [(int(self.graph_ptr[g]), int(self.graph_ptr[g + 1])) for g in range(self.num_graphs)]
+
+    def subset(self, lo: int, hi: int) -> "HostBatch":
+        """Graphs [lo, hi) as their own batch (used to shard a batch over ranks)."""
+        n0, n1 = int(self.graph_ptr[lo]), int(self.graph_ptr[hi])
+        e0, e1 = int(self.row_ptr[n0]), int(self.row_ptr[n1])
+        w = None if self.weights is None else self.weights[n0:n1]
+        return HostBatch(self.graph_ptr[lo:hi + 1] - n0, self.row_ptr[n0:n1 + 1] - e0, self.col_idx[e0:e1] - n0, w)
+
+    def scipy_graph(self, g: int):
+        n0, n1 = int(self.graph_ptr[g]), int(self.graph_ptr[g + 1])
+        e0, e1 = int(self.row_ptr[n0]), int(self.row_ptr[n1])
+        n = n1 - n0
+        return sp.csr_matrix((np.ones(e1 - e0), self.col_idx[e0:e1] - n0, self.row_ptr[n0:n1 + 1] - e0), shape=(n, n))
+
+
+class DeviceBatch:
+    """A HostBatch resident in HBM, plus the C struct the library takes."""
+
+    def __init__(self, host: HostBatch, device="cuda"):
+        import torch
+        self.host = host
+        self.device = torch.device(device)
+        self.graph_ptr = torch.from_numpy(host.graph_ptr).to(self.device, non_blocking=True)
+        self.row_ptr = torch.from_numpy(host.row_ptr).to(self.device, non_blocking=True)
+        # torch refuses zero-size from_numpy().to() only on some builds; keep one slot at least
+        col = host.col_idx if host.col_idx.size else np.zeros(1, dtype=np.int32)
+        self.col_idx = torch.from_numpy(col).to(self.device, non_blocking=True)
+        self.weights = None
+        if host.weights is not None:
+            self.weights = torch.from_numpy(host.weights).to(self.device, non_blocking=True)
+        self.c = _lib.DgcnBatch(host.num_graphs, host.num_nodes, host.num_edges, host.max_nodes,
+                                host.max_graph_edges, self.graph_ptr.data_ptr(), self.row_ptr.data_ptr(),
+                                self.col_idx.data_ptr())
+        self.lap = None  # filled by Engine.supports()
+
+    @property
+    def num_graphs(self):
+        return self.host.num_graphs
+
+    @property
+    def num_nodes(self):
+        return self.host.num_nodes

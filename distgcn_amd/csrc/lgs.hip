@@ -256,7 +256,8 @@ extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const floa
     const size_t lds = lgs_lds_bytes(b->max_nodes, cap);
     hipStream_t s = (hipStream_t)stream;
     const bool want_stats = stats != nullptr || overhead != nullptr;
-    static const int lpv_env = getenv("DGCN_LGS_LPV") ? atoi(getenv("DGCN_LGS_LPV")) : 0;
+    const char* lpv_s = getenv("DGCN_LGS_LPV");  // tuning / test knob
+    const int lpv_env = lpv_s ? atoi(lpv_s) : 0;
     int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 64 ? 4 : (b->max_nodes <= 128 ? 2 : 1));
 #define DGCN_LGS_CASE(L)                                                      \
     if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs, lds, s) \

@@ -39,6 +39,7 @@ static size_t g_live = 0;  // slots [0, g_live) carry a recorded pair
 static bool g_timing = false;
 
 TimedLaunch::TimedLaunch(const char* family, hipStream_t s) : slot(-1), stream(s) {
+    (void)hipGetLastError();  // drop any stale error so check_launch() reports this launch only
     if (!g_timing) return;
     std::lock_guard<std::mutex> lk(g_tmu);
     if (g_live == g_slots.size()) {

@@ -40,30 +40,39 @@ template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type vzero();
 template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 
-// One output row: sequential fmaf chain over [rs, re) in CSR order.
-// cols/vals are indexed with (j - cbase); zrow(u) returns the address of Z's row for column id u.
-template <int VEC, typename ColP, typename ValP, typename ZRow>
-__device__ __forceinline__ typename VecT<VEC>::type row_sum(ColP cols, ValP vals, int rs, int re, int foff,
-                                                            ZRow zrow) {
+// (col, val) of one nonzero packed in 8 bytes: the LDS copy is read with one ds_read_b64.
+struct __attribute__((aligned(8))) ColVal { int col; float val; };
+
+__device__ __forceinline__ float4 vshfl_xor(float4 a, int off) {
+    return make_float4(__shfl_xor(a.x, off), __shfl_xor(a.y, off), __shfl_xor(a.z, off), __shfl_xor(a.w, off));
+}
+__device__ __forceinline__ float vshfl_xor(float a, int off) { return __shfl_xor(a, off); }
+
+// Row sum with the row's nonzeros dealt round-robin to G lane groups (group g takes entries
+// rs+g, rs+g+G, ...: a sequential fmaf chain each), then a butterfly over the groups:
+//   for off = G/2 .. 1:  p[g] = p[g] + p[g ^ off]
+// G = 1 is the plain sequential chain.  `meta(j)` returns the (offset-of-Z-row, value) of entry j.
+// Every lane of the wave must call this (the butterfly is a wave-wide shuffle); lanes without work
+// pass rs == re.
+template <int VEC, int G, typename Meta, typename ZRow>
+__device__ __forceinline__ typename VecT<VEC>::type row_sum_split(Meta meta, int rs, int re, int g, int foff,
+                                                                  int lane_stride, ZRow zrow) {
     using V = typename VecT<VEC>::type;
     V acc = vzero<VEC>();
-    int j = rs;
-    for (; j + 4 <= re; j += 4) {
-        const int c0 = cols[j], c1 = cols[j + 1], c2 = cols[j + 2], c3 = cols[j + 3];
-        const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
-        const V z0 = *reinterpret_cast<const V*>(zrow(c0) + foff);
-        const V z1 = *reinterpret_cast<const V*>(zrow(c1) + foff);
-        const V z2 = *reinterpret_cast<const V*>(zrow(c2) + foff);
-        const V z3 = *reinterpret_cast<const V*>(zrow(c3) + foff);
-        acc = vfma(a0, z0, acc);
-        acc = vfma(a1, z1, acc);
-        acc = vfma(a2, z2, acc);
-        acc = vfma(a3, z3, acc);
+    int j = rs + g;
+    for (; j + G < re; j += 2 * G) {
+        const ColVal m0 = meta(j), m1 = meta(j + G);
+        const V z0 = *reinterpret_cast<const V*>(zrow(m0.col) + foff);
+        const V z1 = *reinterpret_cast<const V*>(zrow(m1.col) + foff);
+        acc = vfma(m0.val, z0, acc);
+        acc = vfma(m1.val, z1, acc);
     }
-    for (; j < re; ++j) {
-        const V z = *reinterpret_cast<const V*>(zrow(cols[j]) + foff);
-        acc = vfma(vals[j], z, acc);
+    if (j < re) {
+        const ColVal m = meta(j);
+        acc = vfma(m.val, *reinterpret_cast<const V*>(zrow(m.col) + foff), acc);
     }
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) acc = vadd(acc, vshfl_xor(acc, off * lane_stride));
     return acc;
 }
 
@@ -77,15 +86,36 @@ __device__ __forceinline__ void epilogue_store(typename VecT<VEC>::type acc, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS variant: blockIdx.x = graph * tiles + tile
-template <int VEC, int LPR>
-__global__ __launch_bounds__(256) void k_spmm_lds(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-                                                  const float* __restrict__ values, const int32_t* __restrict__ graph_ptr,
-                                                  int tiles, int rows_per_tile, const float* __restrict__ Z, int ldz,
-                                                  int C, int zs, int csr_cap, const float* __restrict__ Y0, int ldy0,
-                                                  const float* __restrict__ bias, int act, float* __restrict__ Y,
-                                                  int ldy) {
+// LDS variant: blockIdx.x = graph * tiles + tile.  BLOCK threads = BLOCK/LPR row groups.
+// The three staging streams (Z slice, tile (col,val), nothing else) are issued as batches of
+// independent loads (U per thread in flight) before their LDS stores: at ~1 us per dependent
+// HBM/L2 round trip a one-load-per-iteration loop would dominate the kernel.
+template <int U, int BLOCK, typename T, typename LoadF, typename StoreF>
+__device__ __forceinline__ void staged_copy(int total, LoadF load, StoreF store) {
+    for (int base = threadIdx.x; base < total; base += BLOCK * U) {
+        T tmp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * BLOCK;
+            if (i < total) tmp[u] = load(i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * BLOCK;
+            if (i < total) store(i, tmp[u]);
+        }
+    }
+}
+
+template <int VEC, int LPR, int G, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_spmm_lds(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                    const float* __restrict__ values, const int32_t* __restrict__ graph_ptr,
+                                                    int tiles, int rows_per_tile, const float* __restrict__ Z, int ldz,
+                                                    int C, int zs, int csr_cap, const float* __restrict__ Y0, int ldy0,
+                                                    const float* __restrict__ bias, int act, float* __restrict__ Y,
+                                                    int ldy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    using V = typename VecT<VEC>::type;
     const int g = blockIdx.x / tiles;
     const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
     const int r0 = n0 + (blockIdx.x % tiles) * rows_per_tile;
@@ -93,49 +123,73 @@ __global__ __launch_bounds__(256) void k_spmm_lds(const int32_t* __restrict__ ro
     const int r1 = min(r0 + rows_per_tile, n1);
     const int ng = n1 - n0;
     float* zsm = smem;
-    // ---- stage this graph's slice of Z: coalesced VEC-wide loads, LDS row stride zs
-    {
-        using V = typename VecT<VEC>::type;
-        const int per_row = C / VEC;
-        const int total = ng * per_row;
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int row = i / per_row, q = i - row * per_row;
-            *reinterpret_cast<V*>(zsm + row * zs + q * VEC) =
-                *reinterpret_cast<const V*>(Z + (size_t)(n0 + row) * ldz + q * VEC);
-        }
-    }
+    ColVal* cvs = reinterpret_cast<ColVal*>(smem + (size_t)((ng * zs + 3) & ~3));
     const int e0 = row_ptr[r0], e1 = row_ptr[r1];
     const bool csr_in_lds = (e1 - e0) <= csr_cap;
-    int32_t* csm = reinterpret_cast<int32_t*>(smem + (size_t)((ng * zs + 3) & ~3));
-    float* vsm = reinterpret_cast<float*>(csm + csr_cap);
+    // ---- stage this graph's slice of Z (coalesced VEC-wide loads, LDS row stride zs) ...
+    {
+        const int per_row = C / VEC;
+        staged_copy<4, BLOCK, V>(
+            ng * per_row,
+            [&](int i) { const int row = i / per_row, q = i - row * per_row;
+                         return *reinterpret_cast<const V*>(Z + (size_t)(n0 + row) * ldz + q * VEC); },
+            [&](int i, V v) { const int row = i / per_row, q = i - row * per_row;
+                              *reinterpret_cast<V*>(zsm + row * zs + q * VEC) = v; });
+    }
+    // ---- ... and the tile's (col, val) range, columns as graph-local ids
     if (csr_in_lds) {
-        for (int i = e0 + threadIdx.x; i < e1; i += 256) {
-            csm[i - e0] = col_idx[i] - n0;  // local ids
-            vsm[i - e0] = values[i];
+        staged_copy<4, BLOCK, ColVal>(
+            e1 - e0, [&](int i) { ColVal m; m.col = (col_idx[e0 + i] - n0) * zs; m.val = values[e0 + i]; return m; },
+            [&](int i, ColVal m) { cvs[i] = m; });  // col pre-multiplied by the LDS row stride
+    }
+    // ---- row bounds and the "+ Y0" operand of this thread's rows: issued now, together with the staging
+    // loads, so the row loop below starts without another dependent global round trip.
+    // Lane map inside a wave: lane = g * (R * LPR) + r * LPR + sub  (R = 64 / (LPR * G) rows per wave).
+    constexpr int R = 64 / (LPR * G);
+    constexpr int kSlots = (BLOCK / 64) * R;  // rows in flight per pass
+    constexpr int kPre = 4;                   // passes held in registers (tile <= kPre * kSlots rows, by launch)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rw = (lane / LPR) % R, gq = lane / (LPR * R);
+    const int slot = wave * R + rw;
+    const int foff = sub * VEC;
+    const bool lane_on = foff < C;
+    int rs[kPre], re[kPre];
+    V y0[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int v = r0 + slot + k * kSlots;
+        rs[k] = re[k] = 0;
+        y0[k] = vzero<VEC>();
+        if (v < r1 && lane_on) {
+            rs[k] = row_ptr[v];
+            re[k] = row_ptr[v + 1];
+            if (Y0 && gq == 0) y0[k] = *reinterpret_cast<const V*>(Y0 + (size_t)v * ldy0 + foff);
         }
     }
+    V bv = vzero<VEC>();
+    if (bias && lane_on) bv = *reinterpret_cast<const V*>(bias + foff);
     __syncthreads();
-    const int grp = threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    const int foff = sub * VEC;
-    if (foff >= C) return;
-    constexpr int kGroups = 256 / LPR;
-    auto zrow_local = [&](int u) -> const float* { return zsm + u * zs; };
-    for (int v = r0 + grp; v < r1; v += kGroups) {
-        const int rs = row_ptr[v], re = row_ptr[v + 1];
-        typename VecT<VEC>::type acc;
-        if (csr_in_lds) {
-            acc = row_sum<VEC>(csm - e0, vsm - e0, rs, re, foff, zrow_local);
-        } else {
-            auto zrow_glob = [&](int u) -> const float* { return zsm + (u - n0) * zs; };
-            acc = row_sum<VEC>(col_idx, values, rs, re, foff, zrow_glob);
+    auto zrow_scaled = [&](int off) -> const float* { return zsm + off; };
+    auto meta_lds = [&](int j) -> ColVal { return cvs[j - e0]; };
+    auto meta_glob = [&](int j) -> ColVal { ColVal m; m.col = (col_idx[j] - n0) * zs; m.val = values[j]; return m; };
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        if (r0 + wave * R + k * kSlots >= r1) break;  // wave-uniform: the whole wave is past the tile
+        const int v = r0 + slot + k * kSlots;
+        V acc;
+        if (csr_in_lds) acc = row_sum_split<VEC, G>(meta_lds, rs[k], re[k], gq, foff, LPR * R, zrow_scaled);
+        else acc = row_sum_split<VEC, G>(meta_glob, rs[k], re[k], gq, foff, LPR * R, zrow_scaled);
+        if (v < r1 && lane_on && gq == 0) {
+            if (Y0) acc = vadd(y0[k], acc);
+            if (bias) acc = vadd(acc, bv);
+            *reinterpret_cast<V*>(Y + (size_t)v * ldy + foff) = vact(acc, act);
         }
-        epilogue_store<VEC>(acc, v, foff, Y0, ldy0, bias, act, Y, ldy);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Global-gather variant: no graph structure needed.
-template <int VEC, int LPR>
+template <int VEC, int LPR, int G>
 __global__ __launch_bounds__(256) void k_spmm_global(const int32_t* __restrict__ row_ptr,
                                                      const int32_t* __restrict__ col_idx,
                                                      const float* __restrict__ values, int num_rows,
@@ -143,15 +197,21 @@ __global__ __launch_bounds__(256) void k_spmm_global(const int32_t* __restrict__
                                                      const float* __restrict__ Y0, int ldy0,
                                                      const float* __restrict__ bias, int act,
                                                      float* __restrict__ Y, int ldy) {
-    constexpr int kGroups = 256 / LPR;
-    const int grp = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    using V = typename VecT<VEC>::type;
+    constexpr int R = 64 / (LPR * G);
+    constexpr int kSlots = 4 * R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rw = (lane / LPR) % R, gq = lane / (LPR * R);
     const int foff = sub * VEC;
-    if (foff >= C) return;
+    const bool lane_on = foff < C;
     auto zrow = [&](int u) -> const float* { return Z + (size_t)u * ldz; };
-    for (int v = blockIdx.x * kGroups + grp; v < num_rows; v += gridDim.x * kGroups) {
-        const int rs = row_ptr[v], re = row_ptr[v + 1];
-        auto acc = row_sum<VEC>(col_idx, values, rs, re, foff, zrow);
-        epilogue_store<VEC>(acc, v, foff, Y0, ldy0, bias, act, Y, ldy);
+    auto meta = [&](int j) -> ColVal { ColVal m; m.col = col_idx[j]; m.val = values[j]; return m; };
+    for (int base = blockIdx.x * kSlots; base < num_rows; base += gridDim.x * kSlots) {
+        const int v = base + wave * R + rw;
+        int rs = 0, re = 0;
+        if (v < num_rows && lane_on) { rs = row_ptr[v]; re = row_ptr[v + 1]; }
+        V acc = row_sum_split<VEC, G>(meta, rs, re, gq, foff, LPR * R, zrow);
+        if (v < num_rows && lane_on && gq == 0) epilogue_store<VEC>(acc, v, foff, Y0, ldy0, bias, act, Y, ldy);
     }
 }
 
@@ -161,49 +221,107 @@ static int env_int(const char* name, int dflt) {
     return atoi(e);
 }
 
-template <int VEC, int LPR>
+template <int VEC, int LPR, int G, int BLOCK>
+static int launch_spmm_lds(const DgcnCsr* S, const int32_t* graph_ptr, int B, int tiles, int rows_per_tile,
+                           const float* Z, int ldz, int C, int zs, int csr_cap, size_t lds, const float* Y0, int ldy0,
+                           const float* bias, int act, float* Y, int ldy, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<VEC, LPR, G, BLOCK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_spmm_lds: cannot reserve %zu bytes of LDS", lds);
+    }
+    TimedLaunch t("spmm", s);
+    hipLaunchKernelGGL((k_spmm_lds<VEC, LPR, G, BLOCK>), dim3((unsigned)tiles * (unsigned)B), dim3(BLOCK), lds, s,
+                       S->row_ptr, S->col_idx, S->values, graph_ptr, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, Y0,
+                       ldy0, bias, act, Y, ldy);
+    return check_launch("k_spmm_lds");
+}
+
+template <int VEC, int LPR, int G>
 static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
                        const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s) {
-    constexpr size_t kLdsBudget = 64 * 1024;  // per workgroup: keeps >= 2 workgroups per CU
-    const int zs = (C == 1) ? 1 : C + VEC;    // pad one vector: staggers rows across LDS banks
+    constexpr size_t kLdsMax = 150 * 1024;    // one workgroup may own (almost) the whole 160 KB LDS
+    const int pad = env_int("DGCN_SPMM_PAD", VEC);  // default: pad one vector, staggers rows across LDS banks
+    const int zs = (C == 1) ? 1 : C + (pad / VEC) * VEC;
     const size_t zbytes = (size_t)((max_nodes * zs + 3) & ~3) * sizeof(float);
-    static const int force_global = env_int("DGCN_SPMM_GLOBAL", 0);
-    if (graph_ptr && B > 0 && max_nodes > 0 && zbytes + 2048 <= kLdsBudget && !force_global) {
-        static const int rows_env = env_int("DGCN_SPMM_ROWS", 0);
+    const int force_global = env_int("DGCN_SPMM_GLOBAL", 0);
+    if (graph_ptr && B > 0 && max_nodes > 0 && zbytes + 4096 <= kLdsMax && !force_global) {
+        // Tile = the whole graph unless the batch is too small to fill the chip; threads per
+        // workgroup chosen so that every row group has about two rows.
+        const int rows_env = env_int("DGCN_SPMM_ROWS", 0);
         int rows_per_tile = rows_env > 0 ? rows_env : max_nodes;
-        if (rows_env <= 0) {
-            // enough workgroups to fill 256 CUs a few times over, but never below 64 rows a tile
-            while ((long)B * ceil_div(max_nodes, rows_per_tile) < 1024 && rows_per_tile > 64)
+        if (rows_env <= 0)
+            while ((long)B * ceil_div(max_nodes, rows_per_tile) < 256 && rows_per_tile > 64)
                 rows_per_tile = (rows_per_tile + 1) / 2;
+        int block = env_int("DGCN_SPMM_BLOCK", 0);
+        if (block != 256 && block != 512 && block != 1024) {
+            const int want_slots = (rows_per_tile + 1) / 2;  // about two passes per row slot
+            block = want_slots * LPR * G <= 256 ? 256 : (want_slots * LPR * G <= 512 ? 512 : 1024);
         }
+        // the kernel keeps at most 4 rows per row group in registers: shrink the tile to fit
+        if (rows_per_tile > 4 * (block / (LPR * G))) rows_per_tile = 4 * (block / (LPR * G));
         const int tiles = ceil_div(max_nodes, rows_per_tile);
-        int csr_cap = (int)((kLdsBudget - zbytes) / 8);
-        static const int cap_env = env_int("DGCN_SPMM_CSRCAP", -1);
-        if (cap_env >= 0) csr_cap = min(csr_cap, cap_env);
-        csr_cap &= ~3;
+        // (col,val) slots: the exact per-graph maximum when known, else 1.15x the tile's average share of the nonzeros; a denser tile falls back to
+        // reading its CSR range from global memory inside the kernel (still correct).
+        const double avg_row = (double)S->nnz / (double)max(S->num_rows, 1);
+        long cap = (long)(avg_row * rows_per_tile * 1.15) + 128;
+        if (S->max_graph_nnz > 0 && tiles == 1) cap = S->max_graph_nnz;  // exact bound known
+        const int cap_env = env_int("DGCN_SPMM_CSRCAP", -1);
+        if (cap_env >= 0) cap = cap_env;
+        // prefer two workgroups per CU (<= 78 KB each) when the average tile still fits
+        const long two_per_cu = ((long)78 * 1024 - (long)zbytes) / 8;
+        if (cap > two_per_cu && two_per_cu >= (long)(avg_row * rows_per_tile * 1.15) + 128) cap = two_per_cu;
+        cap = min(cap, (long)((kLdsMax - zbytes) / 8));
+        const int csr_cap = (int)(cap & ~3L);
         const size_t lds = zbytes + (size_t)csr_cap * 8;
-        TimedLaunch t("spmm", s);
-        hipLaunchKernelGGL((k_spmm_lds<VEC, LPR>), dim3((unsigned)tiles * (unsigned)B), dim3(256), lds, s, S->row_ptr,
-                           S->col_idx, S->values, graph_ptr, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, Y0, ldy0,
-                           bias, act, Y, ldy);
-        return check_launch("k_spmm_lds");
+#define DGCN_SPMM_LDS(BL)                                                                                          \
+    return launch_spmm_lds<VEC, LPR, G, BL>(S, graph_ptr, B, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, lds, Y0, ldy0, \
+                                         bias, act, Y, ldy, s)
+        if (block == 256) DGCN_SPMM_LDS(256);
+        if (block == 512) DGCN_SPMM_LDS(512);
+        DGCN_SPMM_LDS(1024);
+#undef DGCN_SPMM_LDS
     }
-    constexpr int kGroups = 256 / LPR;
-    int blocks = ceil_div(S->num_rows, kGroups);
+    constexpr int kSlots = 256 / (LPR * G);
+    int blocks = ceil_div(S->num_rows, kSlots);
     blocks = min(blocks, 256 * 16);
     TimedLaunch t("spmm", s);
-    hipLaunchKernelGGL((k_spmm_global<VEC, LPR>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values,
+    hipLaunchKernelGGL((k_spmm_global<VEC, LPR, G>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values,
                        S->num_rows, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy);
     return check_launch("k_spmm_global");
 }
 
+// The split factor G is part of the arithmetic (it fixes the summation order), so it depends on
+// the feature width only - never on the data.  DGCN_SPMM_SPLIT overrides it for tuning.
+int spmm_split_for(int C) {
+    const int env = env_int("DGCN_SPMM_SPLIT", 0);
+    int g = env > 0 ? env : 1;  // measured on MI355X (C=32, ER and BA batches): the plain chain is fastest
+    const bool vec = (C % 4 == 0);
+    int lpr = 1;
+    while (lpr * (vec ? 4 : 1) < C) lpr *= 2;
+    while (g > 1 && lpr * g > 64) g /= 2;
+    if (g != 1 && g != 2 && g != 4 && g != 8) g = 1;
+    return g;
+}
+
 int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
                   const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s) {
-    const bool vec_ok = (C % 4 == 0) && (ldz % 4 == 0) && (ldy % 4 == 0) && (!Y0 || ldy0 % 4 == 0) &&
-                        ((uintptr_t)Z % 16 == 0) && ((uintptr_t)Y % 16 == 0) && (!Y0 || (uintptr_t)Y0 % 16 == 0) &&
-                        (!bias || (uintptr_t)bias % 16 == 0);
-#define DGCN_SPMM_CASE(V, L) return launch_spmm<V, L>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s)
-    if (vec_ok) {
+    const bool aligned = (ldz % 4 == 0) && (ldy % 4 == 0) && (!Y0 || ldy0 % 4 == 0) && ((uintptr_t)Z % 16 == 0) &&
+                         ((uintptr_t)Y % 16 == 0) && (!Y0 || (uintptr_t)Y0 % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+    const bool vec = (C % 4 == 0) && aligned;
+    const int G = spmm_split_for(C);
+#define DGCN_SPMM_CASE(V, L)                                                                                          \
+    do {                                                                                                              \
+        if (G == 1) return launch_spmm<V, L, 1>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s); \
+        if constexpr (L * 2 <= 64)                                                                                    \
+            if (G == 2) return launch_spmm<V, L, 2>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s); \
+        if constexpr (L * 4 <= 64)                                                                                    \
+            if (G == 4) return launch_spmm<V, L, 4>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s); \
+        if constexpr (L * 8 <= 64)                                                                                    \
+            if (G == 8) return launch_spmm<V, L, 8>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s); \
+        return fail(DGCN_ERR_ARG, "dgcn_spmm_batch: split %d does not fit width %d", G, C);                         \
+    } while (0)
+    if (vec) {
         if (C <= 4) DGCN_SPMM_CASE(4, 1);
         if (C <= 8) DGCN_SPMM_CASE(4, 2);
         if (C <= 16) DGCN_SPMM_CASE(4, 4);
@@ -227,6 +345,8 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
 }  // namespace dgcn
 
 using namespace dgcn;
+
+extern "C" int dgcn_spmm_split(int32_t C) { return C > 0 ? spmm_split_for(C) : 1; }
 
 extern "C" int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
                                const float* Z, int32_t ldz, int32_t C, const float* Y0, int32_t ldy0,

@@ -1,0 +1,229 @@
+"""Device engine: thin Python over the C ABI (include/dgcn.h).
+
+PyTorch is used for device memory and streams only; every computation on the path runs in
+libdgcn.so.  All methods enqueue on the current torch stream and do not synchronise unless they
+return host data.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .batch import DeviceBatch, HostBatch
+
+ACT_CODES = {"linear": _lib.ACT_LINEAR, "identity": _lib.ACT_LINEAR, None: _lib.ACT_LINEAR,
+             "leaky_relu": _lib.ACT_LEAKY_RELU, "relu": _lib.ACT_RELU}
+
+MODE_LAYERED, MODE_FUSED = 0, 1
+
+
+def dinv_table(max_degree: int) -> np.ndarray:
+    """float64 d^-1/2 for d = 0..max_degree with inf -> 0, computed with the very NumPy call the
+    reference uses (gcn/utils.py:124-125) so the bits agree."""
+    d = np.arange(max_degree + 1, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        t = np.power(d, -0.5)
+    t[np.isinf(t)] = 0.0
+    return t
+
+
+class DeviceModel:
+    """Layer stack on the device.  ``layers`` is a list of dicts
+    {"weights": [W_0, W_1] (each [in, out] float32), "bias": None | [out], "act": str}."""
+
+    def __init__(self, layers: List[dict], device="cuda"):
+        import torch
+        if not layers:
+            raise ValueError("model has no layers")
+        self.device = torch.device(device)
+        self.layers = layers
+        self.num_supports = len(layers[0]["weights"])
+        self._keep = []
+        arr = (_lib.DgcnLayer * len(layers))()
+        for i, lyr in enumerate(layers):
+            ws = [np.asarray(w, dtype=np.float32) for w in lyr["weights"]]
+            if len(ws) != self.num_supports:
+                raise ValueError("layer %d has %d weight matrices, expected %d" % (i, len(ws), self.num_supports))
+            cat = np.ascontiguousarray(np.concatenate(ws, axis=1))  # [in, K*out]
+            wt = torch.from_numpy(cat).to(self.device)
+            bt = None
+            if lyr.get("bias") is not None:
+                bt = torch.from_numpy(np.ascontiguousarray(lyr["bias"], dtype=np.float32).ravel()).to(self.device)
+            self._keep += [wt, bt]
+            arr[i] = _lib.DgcnLayer(ws[0].shape[0], ws[0].shape[1], wt.data_ptr(),
+                                    bt.data_ptr() if bt is not None else None, ACT_CODES[lyr.get("act")])
+        self._layer_arr = arr
+        self.c = _lib.DgcnModel(len(layers), self.num_supports, arr)
+        self.in_dim = int(arr[0].in_dim)
+        self.out_dim = int(arr[len(layers) - 1].out_dim)
+
+
+class Engine:
+    def __init__(self, device="cuda"):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.DgcnError("no GPU visible: distgcn_amd runs on MI355X only (there is no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self._table = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dinv(self, max_degree: int):
+        if self._table is None or self._table.numel() <= max_degree:
+            n = max(1024, 2 * (max_degree + 1))
+            self._table = self.torch.from_numpy(dinv_table(n - 1)).to(self.device)
+        return self._table
+
+    def _workspace(self, nbytes: int):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = self.torch.empty(max(nbytes, 256), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def upload(self, host: HostBatch) -> DeviceBatch:
+        with self.torch.cuda.device(self.device):
+            return DeviceBatch(host, self.device)
+
+    def check_status(self, status) -> None:
+        bits = int(status.item())
+        if bits:
+            raise _lib.DgcnError("device-side validation failed: " + _lib.fault_text(bits))
+
+    # ------------------------------------------------------------------ A1/A2
+    def supports(self, b: DeviceBatch, status=None):
+        """L = I - D^-1/2 A D^-1/2 for the batch (gcn/utils.py:258-274, k=1).  Cached on the batch."""
+        t = self.torch
+        if b.lap is not None:
+            return b.lap
+        n, e = b.host.num_nodes, b.host.num_edges
+        row_ptr = t.empty(n + 1, dtype=t.int32, device=self.device)
+        col = t.empty(max(n + e, 1), dtype=t.int32, device=self.device)
+        val = t.empty(max(n + e, 1), dtype=t.float32, device=self.device)
+        own = status is None
+        if own:
+            status = t.zeros(1, dtype=t.int32, device=self.device)
+        tab = self._dinv(b.host.max_degree)
+        if n == 0:
+            row_ptr.zero_()
+        _lib.check(self.lib.dgcn_supports_batch(C.byref(b.c), tab.data_ptr(), int(tab.numel()), row_ptr.data_ptr(),
+                                                col.data_ptr(), val.data_ptr(), status.data_ptr(), self._stream()),
+                   "dgcn_supports_batch")
+        if own:
+            self.check_status(status)
+        csr = _lib.DgcnCsr(n, n + e, b.host.max_graph_edges + b.host.max_nodes, row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
+        b.lap = {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
+        return b.lap
+
+    # ------------------------------------------------------------------ K4
+    def spmm(self, csr: dict, Z, C_feat: int, ldz: Optional[int] = None, graph_ptr=None, num_graphs=0, max_nodes=0,
+             Y0=None, ldy0=0, bias=None, act="linear", out=None):
+        t = self.torch
+        n = int(csr["c"].num_rows)
+        ldz = ldz or int(Z.shape[-1])
+        if out is None:
+            out = t.empty((n, C_feat), dtype=t.float32, device=self.device)
+        _lib.check(self.lib.dgcn_spmm_batch(
+            C.byref(csr["c"]), graph_ptr.data_ptr() if graph_ptr is not None else None, num_graphs, max_nodes,
+            Z.data_ptr(), ldz, C_feat, Y0.data_ptr() if Y0 is not None else None, ldy0,
+            bias.data_ptr() if bias is not None else None, ACT_CODES[act], out.data_ptr(), int(out.shape[-1]),
+            self._stream()), "dgcn_spmm_batch")
+        return out
+
+    # ------------------------------------------------------------------ K2/K3
+    def transform(self, H, W, rows: Optional[int] = None, h_const: float = 1.0):
+        t = self.torch
+        cin, ctot = int(W.shape[0]), int(W.shape[1])
+        if H is not None:
+            rows = int(H.shape[0])
+        out = t.empty((rows, ctot), dtype=t.float32, device=self.device)
+        _lib.check(self.lib.dgcn_transform_batch(H.data_ptr() if H is not None else None,
+                                                 int(H.shape[1]) if H is not None else cin, h_const, rows, cin,
+                                                 W.data_ptr(), ctot, out.data_ptr(), ctot, self._stream()),
+                   "dgcn_transform_batch")
+        return out
+
+    # ------------------------------------------------------------------ A4-A6
+    def forward(self, b: DeviceBatch, model: DeviceModel, X=None, x_const: Optional[float] = None,
+                mode: int = MODE_LAYERED, out=None):
+        """scores[num_nodes, out_dim] (float32) = model.outputs for every node of the batch."""
+        t = self.torch
+        lap = self.supports(b)
+        if x_const is None:
+            x_const = float(np.float32(1.0 / model.in_dim))  # row-normalised all-ones features
+        if out is None:
+            out = t.empty((b.host.num_nodes, model.out_dim), dtype=t.float32, device=self.device)
+        need = int(self.lib.dgcn_gcn_forward_workspace(C.byref(b.c), C.byref(model.c), mode))
+        if need == 0:
+            _lib.check(-1, "dgcn_gcn_forward_workspace")
+        ws = self._workspace(need)
+        _lib.check(self.lib.dgcn_gcn_forward_batch(C.byref(b.c), C.byref(lap["c"]), C.byref(model.c),
+                                                   X.data_ptr() if X is not None else None, x_const, out.data_ptr(),
+                                                   ws.data_ptr(), int(ws.numel()), mode, self._stream()),
+                   "dgcn_gcn_forward_batch")
+        return out
+
+    def argmax(self, b: DeviceBatch, scores):
+        t = self.torch
+        out = t.empty(b.host.num_graphs, dtype=t.int32, device=self.device)
+        _lib.check(self.lib.dgcn_argmax_batch(scores.data_ptr(), int(scores.shape[-1]) if scores.dim() > 1 else 1,
+                                              b.graph_ptr.data_ptr(), b.host.num_graphs, out.data_ptr(),
+                                              self._stream()), "dgcn_argmax_batch")
+        return out
+
+    # ------------------------------------------------------------------ A7-A9
+    def lgs(self, b: DeviceBatch, prio=None, scores=None, weights=None, max_rounds: int = 0, want_stats=False,
+            want_overhead=False, sum_weights=None, want_totals=True, status=None):
+        """Local greedy search over the batch.  Returns a dict of device tensors."""
+        t = self.torch
+        n, B = b.host.num_nodes, b.host.num_graphs
+        state = t.empty(max(n, 1), dtype=t.uint8, device=self.device)
+        rounds = t.empty(max(B, 1), dtype=t.int32, device=self.device)
+        stats = t.empty((max(B, 1), 2), dtype=t.int64, device=self.device) if want_stats or want_overhead else None
+        overhead = t.empty(max(n, 1), dtype=t.int32, device=self.device) if want_overhead else None
+        totals = t.empty(max(B, 1), dtype=t.float64, device=self.device) if want_totals else None
+        own = status is None
+        if own:
+            status = t.zeros(1, dtype=t.int32, device=self.device)
+        p = lambda x: x.data_ptr() if x is not None else None
+        _lib.check(self.lib.dgcn_lgs_batch(C.byref(b.c), p(prio), p(scores), p(weights), int(max_rounds), p(state),
+                                           p(rounds), p(stats), p(overhead), p(sum_weights), p(totals), p(status),
+                                           self._stream()), "dgcn_lgs_batch")
+        return {"state": state[:n], "rounds": rounds[:B], "stats": stats, "overhead": overhead,
+                "totals": totals, "status": status}
+
+    # ------------------------------------------------------------------ A10 (batched)
+    def solve(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", mode: int = MODE_LAYERED, X=None,
+              x_const=None):
+        """GCN forward -> priority -> local greedy for every graph of the batch
+        (mwis_gdpg_call.py:200-235, batched).  ``b.weights`` must be set."""
+        if b.weights is None:
+            raise ValueError("batch has no vertex weights")
+        if model.out_dim != 1:
+            raise _lib.DgcnError("solve() needs a model with one output per node (diver_num=1)")
+        status = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+        self.supports(b, status=status)  # no host sync on the path: faults surface through res["status"]
+        scores = self.forward(b, model, X=X, x_const=x_const, mode=mode)
+        res = self.lgs(b, scores=scores, weights=b.weights if predict == "mwis" else None, sum_weights=b.weights,
+                       status=status)
+        res["scores"] = scores
+        return res
+
+    # ------------------------------------------------------------------ timing hooks (bench.py)
+    def timing(self, on: bool):
+        """on=True clears earlier records and starts recording; on=False stops (records stay readable)."""
+        if on:
+            self.lib.dgcn_timing_reset()
+        self.lib.dgcn_timing_enable(1 if on else 0)
+
+    def timing_read(self, family: str):
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        _lib.check(self.lib.dgcn_timing_read(family.encode(), C.byref(ms), C.byref(n)), "dgcn_timing_read")
+        return ms.value, n.value

@@ -63,6 +63,7 @@ typedef struct DgcnBatch {
 typedef struct DgcnCsr {
     int32_t num_rows;
     int32_t nnz;
+    int32_t max_graph_nnz;  /* largest per-graph nnz (sizes the LDS copy of one graph's entries); 0 = unknown */
     const int32_t* row_ptr; /* [num_rows+1] */
     const int32_t* col_idx; /* [nnz] global ids */
     const float* values;    /* [nnz] */
@@ -101,10 +102,14 @@ int dgcn_supports_batch(const DgcnBatch* batch, const double* dinv_table, int32_
 
 /* ---- K4 (+K5-K7): gcn/layers.py:206 sparse_tensor_dense_matmul, :208 add_n, :211 bias, :216 act
  * Y[v, 0:C] = act( Y0[v, 0:C] + sum_j S.values[j] * Z[S.col_idx[j], 0:C] + bias[0:C] )
- * for every row v of the block-diagonal S; the row sum is a float32 fmaf chain in CSR order
- * starting from 0, then "+ Y0", then "+ bias".  Y0 and bias may be NULL (plain SpMM: K4 alone).
+ * for every row v of the block-diagonal S.  Summation order (part of the contract, mirrored by
+ * oracle/dgcn_oracle.c): with G = dgcn_spmm_split(C), entry number i of the row goes to partial sum
+ * i % G; each partial sum is a float32 fmaf chain in CSR order starting from 0; the partials are
+ * combined by the butterfly "for off = G/2..1: p[g] += p[g ^ off]"; then "Y0 + sum", then "+ bias".
+ * G depends on C only.  Y0 and bias may be NULL (plain SpMM: K4 alone).
  * ldz / ldy / ldy0 are row strides in floats.  graph_ptr/num_graphs/max_nodes let a workgroup
  * keep its graph's slice of Z in LDS; pass graph_ptr = NULL to force the global-gather path. */
+int dgcn_spmm_split(int32_t C);
 int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
                     const float* Z, int32_t ldz, int32_t C,
                     const float* Y0, int32_t ldy0, const float* bias, int32_t act,

@@ -1,0 +1,301 @@
+"""Parity of the HIP kernels (through the C ABI) against the oracle.  Run on the GPU box: -m gpu.
+
+Bars: integer / index / byte outputs bit-exact; float32 scores bit-exact against the CPU twin
+(oracle/dgcn_oracle.c, same operation order) and within 1e-5 of the float64 restatement
+(oracle/ref_numpy.py) - loosened to twice the float32 restatement's own distance from float64 on the
+few ill-conditioned fixture graphs where plain float32 arithmetic itself exceeds 1e-5.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _dev(engine, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(engine.device)
+
+
+def test_supports_bit_exact(engine, golden):
+    from oracle import ctwin
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    lap = engine.supports(db)
+    lrp, lc, lv, fault = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)
+    assert fault == 0
+    assert np.array_equal(lap["row_ptr"].cpu().numpy(), lrp)
+    assert np.array_equal(lap["col_idx"].cpu().numpy()[:lc.size], lc)
+    got = lap["values"].cpu().numpy()[:lv.size]
+    assert np.array_equal(got.view(np.uint32), lv.view(np.uint32))
+    # and against the imported reference's simple_polynomials output (float64 -> float32 feed cast)
+    import scipy.sparse as sp
+    for i, (n0, n1) in enumerate(hb.graph_slices()):
+        e0, e1 = lrp[n0], lrp[n1]
+        m = sp.csr_matrix((got[e0:e1], lc[e0:e1] - n0, lrp[n0:n1 + 1] - e0), shape=(n1 - n0, n1 - n0))
+        m.sort_indices()
+        assert np.array_equal(m.indices, golden.supports["g%02d_lap_indices" % i])
+        assert np.array_equal(m.data, golden.supports["g%02d_lap_data" % i].astype(np.float32))
+
+
+def test_supports_faults(engine):
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd._lib import DgcnError
+    # self loop on vertex 1
+    hb = HostBatch(np.array([0, 3]), np.array([0, 1, 3, 4]), np.array([1, 0, 1, 1]))
+    db = engine.upload(hb)
+    with pytest.raises(DgcnError, match="self-loop"):
+        engine.supports(db)
+    # column pointing into another graph
+    hb = HostBatch(np.array([0, 2, 4]), np.array([0, 1, 2, 3, 4]), np.array([1, 0, 1, 2]))
+    db = engine.upload(hb)
+    with pytest.raises(DgcnError, match="column index"):
+        engine.supports(db)
+
+
+def test_spmm_split_rule_matches_twin(engine):
+    """The split factor fixes the summation order: library and twin must agree for every width."""
+    from oracle import ctwin
+    for C in range(1, 257):
+        assert engine.lib.dgcn_spmm_split(C) == ctwin.spmm_split(C), C
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 8, 16, 19, 32, 64])
+@pytest.mark.parametrize("path", ["lds", "global"])
+def test_spmm_bit_exact(engine, golden, C, path):
+    from oracle import ctwin
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    lap = engine.supports(db)
+    lrp, lc, lv, _ = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)
+    rng = np.random.default_rng(C)
+    Z = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
+    Y0 = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    kw = dict(graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs, max_nodes=hb.max_nodes) if path == "lds" else {}
+    # plain SpMM (K4 alone)
+    got = engine.spmm(lap, _dev(engine, Z), C, **kw).cpu().numpy()
+    want = ctwin.spmm(lrp, lc, lv, Z, C)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # with the GraphConvolution epilogue (add_n, bias, leaky_relu)
+    got = engine.spmm(lap, _dev(engine, Z), C, Y0=_dev(engine, Y0), ldy0=C, bias=_dev(engine, bias),
+                      act="leaky_relu", **kw).cpu().numpy()
+    want = ctwin.spmm(lrp, lc, lv, Z, C, Y0=Y0, bias=bias, act=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # independent check of the twin itself against SciPy float64
+    import scipy.sparse as sp
+    S = sp.csr_matrix((lv.astype(np.float64), lc, lrp), shape=(hb.num_nodes, hb.num_nodes))
+    ref = S @ Z.astype(np.float64)
+    assert np.abs(ctwin.spmm(lrp, lc, lv, Z, C) - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("cin,ctot", [(32, 64), (16, 32), (64, 128), (32, 32), (1, 64), (32, 2), (19, 38), (5, 2)])
+def test_transform_bit_exact(engine, cin, ctot):
+    from oracle import ctwin
+    rng = np.random.default_rng(cin * 1000 + ctot)
+    for rows in (1, 31, 200, 4099):
+        H = rng.standard_normal((rows, cin)).astype(np.float32)
+        W = rng.standard_normal((cin, ctot)).astype(np.float32)
+        got = engine.transform(_dev(engine, H), _dev(engine, W)).cpu().numpy()
+        want = ctwin.transform(H, W)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rows, cin, ctot)
+    # constant-feature form (H = NULL)
+    W = rng.standard_normal((cin, ctot)).astype(np.float32)
+    got = engine.transform(None, _dev(engine, W), rows=77, h_const=0.25).cpu().numpy()
+    want = ctwin.transform(None, W, rows=77, h_const=0.25)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _modes():
+    from distgcn_amd.engine import MODE_LAYERED, MODE_FUSED
+    return [MODE_LAYERED, MODE_FUSED]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_forward_golden_models(engine, golden, mode):
+    """Every shipped-checkpoint fixture model on every fixture graph."""
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    for mname in golden.model_names:
+        layers = golden.layers(mname)
+        got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
+        twin = ctwin.forward(lap, layers, hb.num_nodes)
+        assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), mname
+        for i, (n0, n1) in enumerate(hb.graph_slices()):
+            f64 = golden.scores["g%02d|%s|f64" % (i, mname)]
+            f32 = golden.scores["g%02d|%s|f32" % (i, mname)]
+            bar = max(TOL, 2.0 * np.abs(f32 - f64).max())
+            assert np.abs(got[n0:n1, 0] - f64).max() <= bar, (mname, golden.names[i])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_forward_closed_form_l1(engine, golden, mode):
+    """l=1, F=1: score_v = w0 + w1 * (1 - sum_u 1/sqrt(d_v d_u)); SURVEY anchors for ER_n200_p0.1_b0."""
+    from distgcn_amd.engine import DeviceModel
+    m = "result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn"
+    hb = golden.host_batch([0])
+    db = engine.upload(hb)
+    got = engine.forward(db, DeviceModel(golden.layers(m), engine.device), mode=mode).cpu().numpy()[:, 0]
+    assert np.allclose(got[:5], [0.6762156, 0.81670225, 0.65740633, 0.5908851, 0.7500816], atol=2e-7)
+    p = golden.params(m)
+    w0 = float(p["gcn_dqn/graphconvolution_1_vars/weights_0"][0, 0])
+    w1 = float(p["gcn_dqn/graphconvolution_1_vars/weights_1"][0, 0])
+    a = golden.scipy(0)
+    d = np.asarray(a.sum(1)).ravel()
+    dinv = np.where(d > 0, d ** -0.5, 0.0)
+    closed = w0 + w1 * (1.0 - dinv * (a @ dinv))
+    assert np.abs(got - closed).max() < TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_forward_bias_relu_and_features(engine, golden, mode):
+    """GCN2_DQN shape: bias on every layer, activation on the last layer too, explicit feature matrix."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = golden.host_batch([1, 2, 8])
+    db = engine.upload(hb)
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    layers = datagen.random_model(4, 32, feature_size=1, bias=True, last_act="leaky_relu", seed=3)
+    rng = np.random.default_rng(5)
+    X = (rng.random((hb.num_nodes, 1)) > 0.2).astype(np.float32)  # zero-weight rows -> 0 features
+    got = engine.forward(db, DeviceModel(layers, engine.device), X=_dev(engine, X), mode=mode).cpu().numpy()
+    want = ctwin.forward(lap, layers, hb.num_nodes, X=X)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _lgs_check(res, hb, golden, variant, ids):
+    state = res["state"].cpu().numpy()
+    rounds = res["rounds"].cpu().numpy()
+    for j, i in enumerate(ids):
+        n0, n1 = hb.graph_slices()[j]
+        k = "g%02d_%s" % (i, variant)
+        assert np.array_equal(np.flatnonzero(state[n0:n1] == 1), golden.lgs[k + "_set"]), k
+        assert rounds[j] == golden.lgs[k + "_rounds"], k
+
+
+@pytest.mark.parametrize("variant", ["raw", "ties1", "ties0", "signed", "int3"])
+@pytest.mark.parametrize("lpv", [0, 1, 2, 4, 8])
+def test_lgs_reference_goldens(engine, golden, variant, lpv, monkeypatch):
+    """Sets / rounds / p2p / bst / overhead / totals equal to the imported reference's outputs."""
+    ids = list(range(golden.num_graphs))
+    hb = golden.host_batch(ids)
+    db = engine.upload(hb)
+    prio = np.concatenate([golden.lgs["g%02d_%s_prio" % (i, variant)] for i in ids])
+    if lpv:
+        monkeypatch.setenv("DGCN_LGS_LPV", str(lpv))  # lanes per vertex: 0 = library default
+    res = engine.lgs(db, prio=_dev(engine, prio), want_stats=True, want_overhead=True)
+    engine.check_status(res["status"])
+    _lgs_check(res, hb, golden, variant, ids)
+    stats = res["stats"].cpu().numpy()
+    oh = res["overhead"].cpu().numpy()
+    tot = res["totals"].cpu().numpy()
+    for j, i in enumerate(ids):
+        n0, n1 = hb.graph_slices()[j]
+        k = "g%02d_%s" % (i, variant)
+        assert stats[j, 0] == golden.lgs[k + "_p2p"] and stats[j, 1] == golden.lgs[k + "_bst"], k
+        assert np.array_equal(oh[n0:n1], golden.lgs[k + "_overhead"].astype(np.int32)), k
+        assert tot[j] == pytest.approx(float(golden.lgs[k + "_total"]), rel=1e-12, abs=1e-12)
+    # plain variant (no stats) must take the same decisions
+    res2 = engine.lgs(db, prio=_dev(engine, prio))
+    assert np.array_equal(res2["state"].cpu().numpy(), res["state"].cpu().numpy())
+    assert np.array_equal(res2["rounds"].cpu().numpy(), res["rounds"].cpu().numpy())
+
+
+@pytest.mark.parametrize("nstep", [1, 2])
+def test_lgs_nstep(engine, golden, nstep):
+    ids = list(range(golden.num_graphs))
+    hb = golden.host_batch(ids)
+    db = engine.upload(hb)
+    for variant in ("raw", "ties1", "signed"):
+        prio = np.concatenate([golden.lgs["g%02d_%s_prio" % (i, variant)] for i in ids])
+        res = engine.lgs(db, prio=_dev(engine, prio), max_rounds=nstep)
+        state = res["state"].cpu().numpy()
+        for j, i in enumerate(ids):
+            n0, n1 = hb.graph_slices()[j]
+            k = "g%02d_%s_n%d" % (i, variant, nstep)
+            assert np.array_equal(np.flatnonzero(state[n0:n1] == 1), golden.lgs[k + "_set"])
+            assert np.array_equal(np.flatnonzero(state[n0:n1] == 2), golden.lgs[k + "_nb"])
+
+
+def test_lgs_greedy_utility_pin(engine, golden):
+    """greedy_utility stored by the reference in every .mat (Data_Generation.py:149-153, 218) pins the
+    selection on raw weights: sequential greedy == local greedy for distinct weights."""
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    res = engine.lgs(db, prio=db.weights, sum_weights=db.weights)
+    tot = res["totals"].cpu().numpy()
+    for i in range(golden.num_graphs):
+        assert tot[i] == pytest.approx(float(golden.graphs["g%02d_greedy_utility" % i]), rel=1e-9)
+        assert tot[i] == pytest.approx(float(golden.lgs["g%02d_raw_greedy_total" % i]), rel=1e-12)
+
+
+def test_lgs_nan_fault_and_edge_cases(engine):
+    import torch
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd._lib import DgcnError
+    # graphs: empty graph, single vertex, two isolated vertices, a triangle
+    hb = HostBatch(np.array([0, 0, 1, 3, 6]), np.array([0, 0, 0, 0, 2, 4, 6]), np.array([4, 5, 3, 5, 3, 4]))
+    db = engine.upload(hb)
+    prio = np.array([1.0, -1.0, float("-inf"), 0.5, 0.5, 0.5])
+    res = engine.lgs(db, prio=_dev(engine, prio), want_stats=True)
+    engine.check_status(res["status"])
+    assert res["state"].cpu().numpy().tolist() == [1, 1, 1, 1, 2, 2]
+    assert res["rounds"].cpu().numpy().tolist() == [0, 1, 1, 1]
+    prio[4] = float("nan")
+    res = engine.lgs(db, prio=_dev(engine, prio))
+    with pytest.raises(DgcnError, match="NaN"):
+        engine.check_status(res["status"])
+    assert res["rounds"].cpu().numpy().tolist() == [0, 1, 1, -1]
+
+
+def _independent_and_maximal(hb, state):
+    rows = np.repeat(np.arange(hb.num_nodes), np.diff(hb.row_ptr))
+    sel = state == 1
+    assert not (sel[rows] & sel[hb.col_idx]).any(), "two adjacent vertices selected"
+    has_sel_nb = np.zeros(hb.num_nodes, bool)
+    has_sel_nb[rows[sel[hb.col_idx]]] = True
+    assert (sel | has_sel_nb).all(), "set is not maximal"
+    assert ((state == 2) == (~sel & has_sel_nb)).all()
+
+
+@pytest.mark.parametrize("config", ["C2", "C3", "BA"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_solve_full_size_vs_twin(engine, config, mode):
+    """BASELINE.json full sizes: 500 ER graphs (C2: N=100 l=1; C3: N=200 l=20 c32) and a 500-graph BA
+    test2 mix.  Scores bit-exact vs the CPU twin, hence selected sets bit-identical; plus the
+    size-independent properties (independence, maximality)."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    if config == "C2":
+        hb, layers = datagen.er_batch(500, 100, 0.1), datagen.random_model(1, 32)
+    elif config == "C3":
+        hb, layers = datagen.er_batch(500, 200, 0.1), datagen.random_model(20, 32)
+    else:
+        hb, layers = datagen.ba_test2_batch(500), datagen.random_model(20, 32, seed=11)
+    db = engine.upload(hb)
+    res = engine.solve(db, DeviceModel(layers, engine.device), mode=mode)
+    engine.check_status(res["status"])
+    ref = ctwin.solve(hb, layers)
+    got = res["scores"].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref["scores"].view(np.uint32))
+    state = res["state"].cpu().numpy()
+    assert np.array_equal(state, ref["state"])
+    assert np.array_equal(res["rounds"].cpu().numpy(), ref["rounds"])
+    assert np.allclose(res["totals"].cpu().numpy(), ref["totals"], rtol=1e-12, atol=0)
+    _independent_and_maximal(hb, state)
+
+
+def test_argmax(engine, golden):
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 5, size=(hb.num_nodes, 1)).astype(np.float32)  # many ties: first maximum wins
+    got = engine.argmax(db, _dev(engine, s)).cpu().numpy()
+    for g, (n0, n1) in enumerate(hb.graph_slices()):
+        assert got[g] == int(np.argmax(s[n0:n1, 0]))
