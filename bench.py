@@ -116,7 +116,7 @@ def main():
     model = DeviceModel(layers, dev)
     mode_name = args.mode
     if mode_name == "auto":
-        mode_name = os.environ.get("DGCN_BENCH_MODE", "layered")
+        mode_name = os.environ.get("DGCN_BENCH_MODE", "fused")
     mode = MODE_FUSED if mode_name == "fused" else MODE_LAYERED
 
     gather_buf = None

@@ -1,14 +1,468 @@
-// Fused per-graph persistent forward (mode 1).  Placeholder until the kernel lands: the entry
-// points exist so the dispatcher links, and report "unsupported" loudly.
+// Fused per-graph path: one workgroup owns one graph from the first layer to the selected set.
+//
+//   dgcn_gcn_forward_batch(mode = 1)  : all GraphConvolution layers (gcn/models.py:536-573), scores out
+//   dgcn_solve_batch                  : support construction (gcn/utils.py:120-127, 258-274) + all layers +
+//                                       priority product (mwis_dqn_call.py:232) + local greedy search
+//                                       (heuristics.py:77-116) in ONE launch: adjacency in, set out
+//
+// Why: at N ~ 200 one graph's working set fits the 160 KB LDS of a CU.  The layer-by-layer path moves
+// ~1.66 MB per graph through HBM/L2 over 20 layers and pays ~40 kernel boundaries; here HBM sees the
+// adjacency once (nnz*4 + N*12 bytes in) and the membership once (N bytes out).
+//
+// LDS image of a graph (N <= 512 vertices, hidden width 32):
+//   bufA[N][32] f32   H, then Z0 = H.W0 in place, then H' in place        (16-byte chunks XOR-swizzled by row)
+//   bufB[N][32] f32   Z1 = H.W1, the operand every neighbour gather reads  (same swizzle)
+//   vals[nnzL] f32, words[nnzL] u16, roff[N+1] i32   the support L = I - D^-1/2 A D^-1/2, diagonal first;
+//                     word = (u << 7) | ((u & 7) << 4), so a lane's gather address is word ^ (chunk << 4)
+// N = 200, nnzL ~ 4.2k -> ~77 KB: two workgroups per CU, so one graph's MFMA phase overlaps the
+// other's LDS-bound gather phase.
+//
+// Arithmetic is the library-wide contract (include/dgcn.h): transform = k-ordered fmaf chain (fp32 MFMA
+// 16x16x4 is exactly that), aggregate = fmaf chain in entry order from 0, then Z0 + sum, + bias,
+// activation.  Scores are therefore bit-identical to mode 0 and to oracle/dgcn_oracle.c.
+//
+// Shapes handled here: first layer any width -> 32 (VALU), hidden layers 32 -> 32 (MFMA), last layer
+// -> 1; or a single layer F -> 1.  Anything else returns DGCN_ERR_UNSUPPORTED and the caller uses mode 0.
 #include "common.h"
 
 namespace dgcn {
 
-size_t fused_workspace(const DgcnBatch*, const DgcnModel*) { return 256; }
+constexpr int kMaxFusedLayers = 64;
+constexpr int kFusedBlock = 512;
+constexpr int kHid = 32;  // hidden width of the LDS image
 
-int fused_forward(const DgcnBatch*, const DgcnCsr*, const DgcnModel*, const float*, float, float*, void*, size_t,
-                  hipStream_t) {
-    return fail(DGCN_ERR_UNSUPPORTED, "dgcn_gcn_forward_batch: fused mode is not built in this version");
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct FusedLayer {
+    const float* W;     // [cin][2*cout]
+    const float* bias;  // [cout] or null
+    int32_t cin, cout, act, pad;
+};
+
+struct FusedArgs {
+    const int32_t* graph_ptr;
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const float* vals;         // values of the given support CSR; unused when from_adj
+    const double* dinv_table;  // from_adj: float64 d^-1/2 table
+    int32_t table_len;
+    int32_t from_adj;          // CSR is the adjacency: build L (diagonal first) on the fly
+    const float* X;            // [num_nodes][cin0] or null
+    float x_const;
+    float* scores;             // [num_nodes] or null
+    const double* weights;     // vertex weights (priority product and totals) or null
+    int32_t predict_mwis;
+    int32_t do_lgs;
+    uint8_t* state;
+    int32_t* rounds;
+    double* totals;
+    int32_t* status;
+    int32_t num_layers;
+    int32_t max_nodes;
+    int32_t meta_cap;
+    FusedLayer layers[kMaxFusedLayers];
+};
+
+__device__ __forceinline__ int swz(int row, int col) {  // float index of H[row][col] in a swizzled buffer
+    return row * kHid + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));
+}
+
+__device__ __forceinline__ unsigned short enc_word(int u) { return (unsigned short)((u << 7) | ((u & 7) << 4)); }
+
+// ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
+__device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const FusedLayer& L, int n0, int ng,
+                                                      float* bufA, float* bufB) {
+    const int cin = L.cin, ctot = 2 * L.cout;  // cout == kHid here
+    for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+        for (int c0 = 0; c0 < ctot; c0 += 16) {
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int k = 0; k < cin; ++k) {
+                const float x = a.X ? a.X[(size_t)(n0 + v) * cin + k] : a.x_const;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = fmaf(x, L.W[k * ctot + c0 + i], acc[i]);
+            }
+            float* dst = c0 < kHid ? bufA : bufB;
+            const int cb = c0 < kHid ? c0 : c0 - kHid;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4)
+                *reinterpret_cast<float4*>(dst + swz(v, cb + i)) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+        }
+    }
+}
+
+// ---- hidden layer 32 -> (32 | 32): fp32 MFMA 16x16x4, one 16-row tile per wave at a time.
+// A: lane (r = l & 15, kq = l >> 4) holds H[row0 + r][4s + kq]; B: W[4s + kq][ct*16 + r];
+// C/D: col = l & 15, row = 4 * (l >> 4) + reg.  Z0 overwrites the tile's own rows of bufA.
+__device__ __forceinline__ void hidden_transform(const FusedLayer& L, int ng, float* bufA, float* bufB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    constexpr int kWaves = kFusedBlock / 64;
+    float b[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b[s][ct] = L.W[(4 * s + kq) * 64 + ct * 16 + r];
+    const int tiles = (ng + 15) >> 4;
+    for (int t = wave; t < tiles; t += kWaves) {
+        const int row = t * 16 + r;
+        float av[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b[s][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float* dst = ct < 2 ? bufA : bufB;
+            const int n = (ct & 1) * 16 + r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int orow = t * 16 + kq * 4 + reg;
+                if (orow < ng) dst[swz(orow, n)] = acc[ct][reg];
+            }
+        }
+    }
+}
+
+// ---- aggregation at width 32: 8 lanes x float4 per row, sequential fmaf chain over the row's entries
+__device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
+                                                 const int* roff, const float* vals, const unsigned short* words) {
+    const int grp = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const unsigned qx = (unsigned)q << 4;
+    const char* zb = reinterpret_cast<const char*>(bufB);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L.bias) bias = *reinterpret_cast<const float4*>(L.bias + 4 * q);
+    for (int v = grp; v < ng; v += kFusedBlock / 8) {
+        const int rs = roff[v], re = roff[v + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int j = rs;
+        for (; j + 4 <= re; j += 4) {
+            const unsigned w0 = words[j], w1 = words[j + 1], w2 = words[j + 2], w3 = words[j + 3];
+            const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
+            const float4 z0 = *reinterpret_cast<const float4*>(zb + (w0 ^ qx));
+            const float4 z1 = *reinterpret_cast<const float4*>(zb + (w1 ^ qx));
+            const float4 z2 = *reinterpret_cast<const float4*>(zb + (w2 ^ qx));
+            const float4 z3 = *reinterpret_cast<const float4*>(zb + (w3 ^ qx));
+            acc.x = fmaf(a0, z0.x, acc.x); acc.y = fmaf(a0, z0.y, acc.y); acc.z = fmaf(a0, z0.z, acc.z); acc.w = fmaf(a0, z0.w, acc.w);
+            acc.x = fmaf(a1, z1.x, acc.x); acc.y = fmaf(a1, z1.y, acc.y); acc.z = fmaf(a1, z1.z, acc.z); acc.w = fmaf(a1, z1.w, acc.w);
+            acc.x = fmaf(a2, z2.x, acc.x); acc.y = fmaf(a2, z2.y, acc.y); acc.z = fmaf(a2, z2.z, acc.z); acc.w = fmaf(a2, z2.w, acc.w);
+            acc.x = fmaf(a3, z3.x, acc.x); acc.y = fmaf(a3, z3.y, acc.y); acc.z = fmaf(a3, z3.z, acc.z); acc.w = fmaf(a3, z3.w, acc.w);
+        }
+        for (; j < re; ++j) {
+            const float a0 = vals[j];
+            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((unsigned)words[j] ^ qx));
+            acc.x = fmaf(a0, z0.x, acc.x); acc.y = fmaf(a0, z0.y, acc.y); acc.z = fmaf(a0, z0.z, acc.z); acc.w = fmaf(a0, z0.w, acc.w);
+        }
+        float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
+        const float4 z = *own;
+        float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
+        if (L.bias) { o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w; }
+        o.x = apply_act(o.x, L.act); o.y = apply_act(o.y, L.act); o.z = apply_act(o.z, L.act); o.w = apply_act(o.w, L.act);
+        *own = o;
+    }
+}
+
+__global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int g = blockIdx.x;
+    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
+    const int ng = n1 - n0;
+    float* bufA = reinterpret_cast<float*>(lds_raw);
+    float* bufB = bufA + (size_t)a.max_nodes * kHid;
+    int* roff = reinterpret_cast<int*>(bufB + (size_t)a.max_nodes * kHid);
+    float* vals = reinterpret_cast<float*>(roff + ((a.max_nodes + 1 + 3) & ~3));
+    unsigned short* words = reinterpret_cast<unsigned short*>(vals + a.meta_cap);
+    if (ng <= 0) {
+        if (threadIdx.x == 0 && a.do_lgs) {
+            if (a.rounds) a.rounds[g] = 0;
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        return;
+    }
+    const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
+    int fault = 0;
+
+    // ------------------------------------------------------------ P0: the support matrix into LDS
+    double* dinv = reinterpret_cast<double*>(bufB);  // scratch until the first transform
+    for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+        const int rs = a.row_ptr[n0 + v];
+        roff[v] = rs - e0 + (a.from_adj ? v : 0);
+        if (a.from_adj) {
+            const int deg = a.row_ptr[n0 + v + 1] - rs;
+            double d = 0.0;
+            if (deg < a.table_len) d = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+            dinv[v] = d;
+        }
+    }
+    if (threadIdx.x == 0) roff[ng] = e1 - e0 + (a.from_adj ? ng : 0);
+    __syncthreads();
+    if (a.from_adj) {
+        const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+        for (int v = grp; v < ng; v += kFusedBlock / 8) {
+            const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+            const int base = rs - e0 + v;
+            const double dv = dinv[v];
+            if (sub == 0) { words[base] = enc_word(v); vals[base] = 1.0f; }
+            for (int j = rs + sub; j < re; j += 8) {
+                const int u = a.col_idx[j] - n0;
+                float val = 0.f;
+                int uu = 0;
+                if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
+                else {
+                    if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                    val = (float)(-(dinv[u] * dv));
+                    uu = u;
+                }
+                words[j - e0 + v + 1] = enc_word(uu);
+                vals[j - e0 + v + 1] = val;
+            }
+        }
+    } else {
+        for (int j = threadIdx.x; j < e1 - e0; j += kFusedBlock) {
+            int u = a.col_idx[e0 + j] - n0;
+            if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; }
+            words[j] = enc_word(u);
+            vals[j] = a.vals[e0 + j];
+        }
+    }
+    __syncthreads();  // dinv scratch (bufB) is dead from here on
+
+    // ------------------------------------------------------------ layers
+    float score = 0.f;  // final output of vertex threadIdx.x (+ k * block), only ng <= block supported
+    for (int l = 0; l < a.num_layers; ++l) {
+        const FusedLayer& L = a.layers[l];
+        if (L.cout == kHid) {
+            if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB);
+            else hidden_transform(L, ng, bufA, bufB);
+            __syncthreads();
+            hidden_aggregate(L, ng, bufA, bufB, roff, vals, words);
+            __syncthreads();
+        } else {
+            // last layer: width 1.  z0 stays in a register, z1 goes to bufB[v] (bufB is free: the
+            // previous aggregation finished at the barrier above).
+            const int v = threadIdx.x;
+            float z0 = 0.f, z1 = 0.f;
+            if (v < ng) {
+                for (int k = 0; k < L.cin; ++k) {
+                    float h;
+                    if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : a.x_const;
+                    else h = bufA[swz(v, k)];
+                    z0 = fmaf(h, L.W[k * 2 + 0], z0);
+                    z1 = fmaf(h, L.W[k * 2 + 1], z1);
+                }
+                bufB[v] = z1;
+            }
+            __syncthreads();
+            if (v < ng) {
+                float acc = 0.f;
+                for (int j = roff[v]; j < roff[v + 1]; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
+                float o = z0 + acc;
+                if (L.bias) o += L.bias[0];
+                score = apply_act(o, L.act);
+                if (a.scores) a.scores[n0 + v] = score;
+            }
+            __syncthreads();
+        }
+    }
+    if (!a.do_lgs) {
+        if (fault && a.status) atomicOr(a.status, fault);
+        return;
+    }
+
+    // ------------------------------------------------------------ priority + local greedy search
+    double* pr = reinterpret_cast<double*>(bufB);
+    double* red = pr + a.max_nodes;  // [kFusedBlock] slots; bufB has 128 B per row and max_nodes >= 64 rows
+    uint8_t* st = reinterpret_cast<uint8_t*>(bufA);
+    uint8_t* nw = st + a.max_nodes;
+    const int v = threadIdx.x;
+    int bad = 0;
+    if (v < ng) {
+        double p = (double)score;
+        if (a.predict_mwis && a.weights) p *= a.weights[n0 + v];
+        bad = (p != p);
+        pr[v] = p;
+        st[v] = 0;
+        nw[v] = 0;
+    }
+    if (__syncthreads_or(bad)) {
+        if (threadIdx.x == 0) {
+            atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+            if (a.rounds) a.rounds[g] = -1;
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        if (v < ng) a.state[n0 + v] = 0;
+        return;
+    }
+    int rounds = 0;
+    int remaining = 1;
+    const int rs = v < ng ? roff[v] : 0, re = v < ng ? roff[v + 1] : 0;
+    const double pv = v < ng ? pr[v] : 0.0;
+    while (remaining) {
+        bool live = v < ng && st[v] == 0;
+        bool lost = false;
+        if (live) {
+            for (int j = rs; j < re; ++j) {
+                const int u = words[j] >> 7;
+                if (u != v && st[u] == 0) {
+                    const double pu = pr[u];
+                    lost |= (pu > pv) || (pu == pv && u < v);
+                }
+            }
+            nw[v] = lost ? 0 : 1;
+        }
+        __syncthreads();
+        if (live && !lost) {
+            for (int j = rs; j < re; ++j) {
+                const int u = words[j] >> 7;
+                if (u != v && st[u] == 0) st[u] = 2;
+            }
+        }
+        __syncthreads();
+        int mine = 0;
+        if (v < ng && st[v] == 0) {
+            if (nw[v]) st[v] = 1; else mine = 1;
+        }
+        remaining = __syncthreads_or(mine);
+        ++rounds;
+    }
+    if (v < ng) a.state[n0 + v] = st[v];
+    if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+    if (a.totals) {
+        double part = 0.0;
+        if (v < ng && st[v] == 1) part = a.weights ? a.weights[n0 + v] : pv;
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (int off = kFusedBlock / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.totals[g] = red[0];
+    }
+    if (fault) atomicOr(a.status, fault);
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t fused_lds_bytes(int max_nodes, int meta_cap) {
+    const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
+    const size_t roff = (size_t)((max_nodes + 1 + 3) & ~3) * sizeof(int);
+    return bufs + roff + (size_t)meta_cap * 6 + 16;
+}
+
+static int fused_shape_ok(const DgcnModel* m) {
+    if (m->num_layers > kMaxFusedLayers) return 0;
+    const int Lc = m->num_layers;
+    for (int l = 0; l < Lc; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        const bool last = l == Lc - 1;
+        if (last) { if (L.out_dim != 1) return 0; }
+        else if (L.out_dim != kHid) return 0;
+        if (l > 0 && L.in_dim != kHid) return 0;
+        if (l == 0 && L.in_dim > 64) return 0;
+    }
+    return 1;
+}
+
+// Fills the launch arguments shared by both entry points; returns 0 or an error code.
+static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who) {
+    if (!fused_shape_ok(m))
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->32->...->32->1 layer stacks only", who);
+    if (b->max_nodes > kFusedBlock)
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: graphs of %d vertices exceed the fused kernel's %d", who, b->max_nodes,
+                    kFusedBlock);
+    a->graph_ptr = b->graph_ptr;
+    a->max_nodes = max(b->max_nodes, 64);  // >= 64 rows: the greedy phase re-uses bufB for priorities + reduction
+    a->num_layers = m->num_layers;
+    for (int l = 0; l < m->num_layers; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        a->layers[l].W = L.weights;
+        a->layers[l].bias = L.bias;
+        a->layers[l].cin = L.in_dim;
+        a->layers[l].cout = L.out_dim;
+        a->layers[l].act = L.act;
+        a->layers[l].pad = 0;
+    }
+    *lds = fused_lds_bytes(a->max_nodes, a->meta_cap);
+    if (*lds > 160 * 1024)
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who, *lds);
+    return DGCN_OK;
+}
+
+static int fused_launch(const FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+    }
+    TimedLaunch t(family, s);
+    hipLaunchKernelGGL(k_fused, dim3(B), dim3(kFusedBlock), lds, s, a);
+    return check_launch("k_fused");
+}
+
+size_t fused_workspace(const DgcnBatch*, const DgcnModel*) { return 256; }  // everything lives in LDS
+
+int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
+                  float* scores, void*, size_t, hipStream_t s) {
+    FusedArgs args = {};
+    args.row_ptr = lap->row_ptr;
+    args.col_idx = lap->col_idx;
+    args.vals = lap->values;
+    args.from_adj = 0;
+    args.meta_cap = lap->max_graph_nnz > 0 ? lap->max_graph_nnz : b->max_graph_edges + b->max_nodes;
+    args.X = X;
+    args.x_const = x_const;
+    args.scores = scores;
+    args.do_lgs = 0;
+    size_t lds = 0;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)");
+    if (rc) return rc;
+    return fused_launch(args, b->num_graphs, lds, "fused_forward", s);
 }
 
 }  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
+    if (!b || !m || !m->layers_host || m->num_supports != 2) return 0;
+    if (!fused_shape_ok(m) || b->max_nodes > kFusedBlock) return 0;
+    const int cap = b->max_graph_edges + b->max_nodes;
+    return fused_lds_bytes(max(b->max_nodes, 64), cap) <= 160 * 1024;
+}
+
+extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len,
+                                const float* X, float x_const, const double* weights, int32_t predict_mwis,
+                                float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status,
+                                void* stream) {
+    if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
+        return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
+    if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
+    if (b->num_graphs <= 0) return DGCN_OK;
+    FusedArgs args = {};
+    args.row_ptr = b->row_ptr;
+    args.col_idx = b->col_idx;
+    args.vals = nullptr;
+    args.dinv_table = dinv_table;
+    args.table_len = table_len;
+    args.from_adj = 1;
+    args.meta_cap = b->max_graph_edges + b->max_nodes;
+    args.X = X;
+    args.x_const = x_const;
+    args.scores = scores;
+    args.weights = weights;
+    args.predict_mwis = predict_mwis;
+    args.do_lgs = 1;
+    args.state = state;
+    args.rounds = rounds;
+    args.totals = totals;
+    args.status = status;
+    size_t lds = 0;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch");
+    if (rc) return rc;
+    return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream);
+}

@@ -207,6 +207,8 @@ class Engine:
             raise ValueError("batch has no vertex weights")
         if model.out_dim != 1:
             raise _lib.DgcnError("solve() needs a model with one output per node (diver_num=1)")
+        if mode == MODE_FUSED:
+            return self.solve_fused(b, model, predict=predict, X=X, x_const=x_const)
         status = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
         self.supports(b, status=status)  # no host sync on the path: faults surface through res["status"]
         scores = self.forward(b, model, X=X, x_const=x_const, mode=mode)
@@ -214,6 +216,30 @@ class Engine:
                        status=status)
         res["scores"] = scores
         return res
+
+    def solve_supported(self, b: DeviceBatch, model: DeviceModel) -> bool:
+        return bool(self.lib.dgcn_solve_supported(C.byref(b.c), C.byref(model.c)))
+
+    def solve_fused(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", X=None, x_const=None,
+                    want_scores: bool = True):
+        """The whole path in one launch (dgcn_solve_batch): adjacency + weights in, membership out."""
+        t = self.torch
+        n, B = b.host.num_nodes, b.host.num_graphs
+        if x_const is None:
+            x_const = float(np.float32(1.0 / model.in_dim))
+        tab = self._dinv(b.host.max_degree)
+        scores = t.empty((max(n, 1), 1), dtype=t.float32, device=self.device) if want_scores else None
+        state = t.empty(max(n, 1), dtype=t.uint8, device=self.device)
+        rounds = t.empty(max(B, 1), dtype=t.int32, device=self.device)
+        totals = t.empty(max(B, 1), dtype=t.float64, device=self.device)
+        status = t.zeros(1, dtype=t.int32, device=self.device)
+        p = lambda x: x.data_ptr() if x is not None else None
+        _lib.check(self.lib.dgcn_solve_batch(C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X),
+                                             x_const, p(b.weights), 1 if predict == "mwis" else 0, p(scores),
+                                             p(state), p(rounds), p(totals), p(status), self._stream()),
+                   "dgcn_solve_batch")
+        return {"state": state[:n], "rounds": rounds[:B], "totals": totals[:B], "status": status,
+                "scores": None if scores is None else scores[:n], "stats": None, "overhead": None}
 
     # ------------------------------------------------------------------ timing hooks (bench.py)
     def timing(self, on: bool):

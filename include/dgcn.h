@@ -153,6 +153,20 @@ int dgcn_lgs_batch(const DgcnBatch* batch, const double* prio, const float* scor
                    int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
                    const double* sum_weights, double* totals, int32_t* status, void* stream);
 
+/* ---- A1-A10 in one launch: mwis_gdpg_call.py:200-235 solve_mwis for a whole batch ---------------
+ * adjacency + vertex weights in, membership out; one workgroup keeps one graph in LDS from support
+ * construction (gcn/utils.py:120-127) through every layer (gcn/models.py:536-573) to the greedy
+ * rounds (heuristics.py:77-116).  Same arithmetic contract as the separate entry points, so scores
+ * and sets are bit-identical to supports -> forward(mode 0) -> lgs.
+ * Handles F->32->..->32->1 layer stacks on graphs of <= 512 vertices whose image fits the LDS;
+ * dgcn_solve_supported() tells (1/0) so the caller can route other shapes through the separate calls.
+ * scores (float[num_nodes]), rounds, totals may be NULL.  weights NULL or predict_mwis = 0: the
+ * priority is the score itself (mwis_dqn_call.py:234). */
+int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
+int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table, int32_t table_len,
+                     const float* X, float x_const, const double* weights, int32_t predict_mwis,
+                     float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* stream);
+
 /* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
  * enable(1) makes every launch of the named kernel families record an event pair;
  * read() synchronises those events and returns the summed milliseconds and launch count. */

