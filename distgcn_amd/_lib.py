@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgcn.so")
+# DGCN_LIB selects another build of the same library (e.g. the -DDGCN_DIAG profiling build)
+LIB_PATH = os.environ.get("DGCN_LIB") or os.path.join(_HERE, "libdgcn.so")
 
 OK = 0
 ACT_LINEAR, ACT_LEAKY_RELU, ACT_RELU = 0, 1, 2

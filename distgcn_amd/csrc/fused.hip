@@ -11,9 +11,15 @@
 //
 // LDS image of a graph (N <= 512 vertices, hidden width 32):
 //   bufA[N][32] f32   H, then Z0 = H.W0 in place, then H' in place        (16-byte chunks XOR-swizzled by row)
-//   bufB[N][32] f32   Z1 = H.W1, the operand every neighbour gather reads  (same swizzle)
-//   vals[nnzL] f32, words[nnzL] u16, roff[N+1] i32   the support L = I - D^-1/2 A D^-1/2, diagonal first;
-//                     word = (u << 7) | ((u & 7) << 4), so a lane's gather address is word ^ (chunk << 4)
+//   bufB[N][32] f32   Z1 = H.W1, the operand every neighbour gather reads  (chunks swizzled inside each
+//                     64-byte half by row & 3: keeps the half-row bank windows the random gather
+//                     conflicts least on, and lets the MFMA epilogue store 16-byte chunks 2-way instead of 8-way)
+//   vals[] f32, words[] u16, rinfo[N] u32, perm[N] u16   the support L = I - D^-1/2 A D^-1/2, diagonal
+//                     first; word = (u << 7) | ((u & 3) << 4), a lane's gather address is word ^ (chunk << 4);
+//                     every row's entry list starts
+//                     at an even slot so two words / two values come with one 4- / 8-byte LDS read;
+//                     rinfo = start | count << 16; perm = rows by descending entry count, dealt to the
+//                     waves in snake order so the 8 rows a wave walks in lockstep have equal length
 // N = 200, nnzL ~ 4.2k -> ~77 KB: two workgroups per CU, so one graph's MFMA phase overlaps the
 // other's LDS-bound gather phase.
 //
@@ -60,14 +66,24 @@ struct FusedArgs {
     int32_t num_layers;
     int32_t max_nodes;
     int32_t meta_cap;
+    int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     FusedLayer layers[kMaxFusedLayers];
 };
+
+#ifdef DGCN_DIAG
+#define DIAG_ON(a, bit) (((a).diag >> (bit)) & 1)
+#else
+#define DIAG_ON(a, bit) 0
+#endif
 
 __device__ __forceinline__ int swz(int row, int col) {  // float index of H[row][col] in a swizzled buffer
     return row * kHid + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));
 }
 
-__device__ __forceinline__ unsigned short enc_word(int u) { return (unsigned short)((u << 7) | ((u & 7) << 4)); }
+__device__ __forceinline__ unsigned short enc_word(int u) { return (unsigned short)((u << 7) | ((u & 3) << 4)); }
+__device__ __forceinline__ int swzB(int row, int col) {  // bufB: chunk index ^ (row & 3), i.e. inside its half
+    return row * kHid + ((((col >> 2) ^ (row & 3)) << 2) | (col & 3));
+}
 
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
 __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const FusedLayer& L, int n0, int ng,
@@ -83,11 +99,11 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = fmaf(x, L.W[k * ctot + c0 + i], acc[i]);
             }
-            float* dst = c0 < kHid ? bufA : bufB;
-            const int cb = c0 < kHid ? c0 : c0 - kHid;
 #pragma unroll
-            for (int i = 0; i < 16; i += 4)
-                *reinterpret_cast<float4*>(dst + swz(v, cb + i)) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+            for (int i = 0; i < 16; i += 4) {
+                float* dst = c0 < kHid ? bufA + swz(v, c0 + i) : bufB + swzB(v, c0 - kHid + i);
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+            }
         }
     }
 }
@@ -95,15 +111,21 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
 // ---- hidden layer 32 -> (32 | 32): fp32 MFMA 16x16x4, one 16-row tile per wave at a time.
 // A: lane (r = l & 15, kq = l >> 4) holds H[row0 + r][4s + kq]; B: W[4s + kq][ct*16 + r];
 // C/D: col = l & 15, row = 4 * (l >> 4) + reg.  Z0 overwrites the tile's own rows of bufA.
-__device__ __forceinline__ void hidden_transform(const FusedLayer& L, int ng, float* bufA, float* bufB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The B fragments of a layer are fetched one layer ahead (load_bfrag) so that their global-memory
+// latency hides under the previous layer's gather phase.
+__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4]) {
+    const int lane = threadIdx.x & 63;
     const int r = lane & 15, kq = lane >> 4;
-    constexpr int kWaves = kFusedBlock / 64;
-    float b[8][4];
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) b[s][ct] = L.W[(4 * s + kq) * 64 + ct * 16 + r];
+        for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
+}
+
+__device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    constexpr int kWaves = kFusedBlock / 64;
     const int tiles = (ng + 15) >> 4;
     for (int t = wave; t < tiles; t += kWaves) {
         const int row = t * 16 + r;
@@ -113,52 +135,78 @@ __device__ __forceinline__ void hidden_transform(const FusedLayer& L, int ng, fl
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Operands swapped (D^T = W^T . H^T): the accumulator then holds, per lane, 4 CONSECUTIVE
+        // features (4*kq + reg of column tile ct) of ONE vertex (row0 + r) = one 16-byte chunk,
+        // stored with a single ds_write_b128.  Each element is still the k-ordered fmaf chain.
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b[s][ct], acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc[ct], 0, 0, 0);
+        if (row < ng) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float* dst = ct < 2 ? bufA : bufB;
-            const int n = (ct & 1) * 16 + r;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int orow = t * 16 + kq * 4 + reg;
-                if (orow < ng) dst[swz(orow, n)] = acc[ct][reg];
+            for (int ct = 0; ct < 4; ++ct) {
+                const int chunk = (ct & 1) * 4 + kq;
+                const float4 o = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+                if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
+                else *reinterpret_cast<float4*>(bufB + row * kHid + ((chunk ^ (row & 3)) << 2)) = o;
             }
         }
     }
 }
 
-// ---- aggregation at width 32: 8 lanes x float4 per row, sequential fmaf chain over the row's entries
+// ---- aggregation at width 32: 8 lanes x float4 per row, sequential fmaf chain over the row's entries.
+// Rows are taken in `perm` order (descending entry count), blocks of 8 dealt to the 8 waves in snake
+// order: only the processing order changes, never the arithmetic.
+__device__ __forceinline__ float4 fma4(float a, float4 z, float4 acc) {
+    acc.x = fmaf(a, z.x, acc.x); acc.y = fmaf(a, z.y, acc.y); acc.z = fmaf(a, z.z, acc.z); acc.w = fmaf(a, z.w, acc.w);
+    return acc;
+}
+
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
-                                                 const int* roff, const float* vals, const unsigned short* words) {
-    const int grp = threadIdx.x >> 3, q = threadIdx.x & 7;
-    const unsigned qx = (unsigned)q << 4;
+                                                 const unsigned* rinfo, const unsigned short* perm,
+                                                 const float* vals, const unsigned short* words) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = lane >> 3, q = lane & 7;
+    constexpr int kWaves = kFusedBlock / 64;
     const char* zb = reinterpret_cast<const char*>(bufB);
+    const unsigned qx = (unsigned)q << 4;  // gather address = word ^ qx (the word carries the row's swizzle key)
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.bias) bias = *reinterpret_cast<const float4*>(L.bias + 4 * q);
-    for (int v = grp; v < ng; v += kFusedBlock / 8) {
-        const int rs = roff[v], re = roff[v + 1];
+    const int blocks = (ng + 7) >> 3;
+    for (int k = 0; k * kWaves < blocks; ++k) {
+        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
+        const int slot = blk * 8 + gw;
+        if (blk >= blocks || slot >= ng) continue;
+        const int v = perm[slot];
+        const unsigned ri = rinfo[v];
+        const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = rs;
+        int j = rs;  // even by construction
         for (; j + 4 <= re; j += 4) {
-            const unsigned w0 = words[j], w1 = words[j + 1], w2 = words[j + 2], w3 = words[j + 3];
-            const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
-            const float4 z0 = *reinterpret_cast<const float4*>(zb + (w0 ^ qx));
-            const float4 z1 = *reinterpret_cast<const float4*>(zb + (w1 ^ qx));
-            const float4 z2 = *reinterpret_cast<const float4*>(zb + (w2 ^ qx));
-            const float4 z3 = *reinterpret_cast<const float4*>(zb + (w3 ^ qx));
-            acc.x = fmaf(a0, z0.x, acc.x); acc.y = fmaf(a0, z0.y, acc.y); acc.z = fmaf(a0, z0.z, acc.z); acc.w = fmaf(a0, z0.w, acc.w);
-            acc.x = fmaf(a1, z1.x, acc.x); acc.y = fmaf(a1, z1.y, acc.y); acc.z = fmaf(a1, z1.z, acc.z); acc.w = fmaf(a1, z1.w, acc.w);
-            acc.x = fmaf(a2, z2.x, acc.x); acc.y = fmaf(a2, z2.y, acc.y); acc.z = fmaf(a2, z2.z, acc.z); acc.w = fmaf(a2, z2.w, acc.w);
-            acc.x = fmaf(a3, z3.x, acc.x); acc.y = fmaf(a3, z3.y, acc.y); acc.z = fmaf(a3, z3.z, acc.z); acc.w = fmaf(a3, z3.w, acc.w);
+            uint2 w;  // entry lists start at even slots: 4-byte aligned word pairs, 8-byte aligned value pairs
+            w.x = *reinterpret_cast<const unsigned*>(words + j);
+            w.y = *reinterpret_cast<const unsigned*>(words + j + 2);
+            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
+            const float2 a23 = *reinterpret_cast<const float2*>(vals + j + 2);
+            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((w.x & 0xffffu) ^ qx));
+            const float4 z1 = *reinterpret_cast<const float4*>(zb + ((w.x >> 16) ^ qx));
+            const float4 z2 = *reinterpret_cast<const float4*>(zb + ((w.y & 0xffffu) ^ qx));
+            const float4 z3 = *reinterpret_cast<const float4*>(zb + ((w.y >> 16) ^ qx));
+            acc = fma4(a01.x, z0, acc);
+            acc = fma4(a01.y, z1, acc);
+            acc = fma4(a23.x, z2, acc);
+            acc = fma4(a23.y, z3, acc);
         }
-        for (; j < re; ++j) {
-            const float a0 = vals[j];
-            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((unsigned)words[j] ^ qx));
-            acc.x = fmaf(a0, z0.x, acc.x); acc.y = fmaf(a0, z0.y, acc.y); acc.z = fmaf(a0, z0.z, acc.z); acc.w = fmaf(a0, z0.w, acc.w);
+        if (j + 2 <= re) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(words + j);
+            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
+            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((w & 0xffffu) ^ qx));
+            const float4 z1 = *reinterpret_cast<const float4*>(zb + ((w >> 16) ^ qx));
+            acc = fma4(a01.x, z0, acc);
+            acc = fma4(a01.y, z1, acc);
+            j += 2;
         }
+        if (j < re) acc = fma4(vals[j], *reinterpret_cast<const float4*>(zb + ((unsigned)words[j] ^ qx)), acc);
         float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
         const float4 z = *own;
         float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
@@ -175,9 +223,10 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     const int ng = n1 - n0;
     float* bufA = reinterpret_cast<float*>(lds_raw);
     float* bufB = bufA + (size_t)a.max_nodes * kHid;
-    int* roff = reinterpret_cast<int*>(bufB + (size_t)a.max_nodes * kHid);
-    float* vals = reinterpret_cast<float*>(roff + ((a.max_nodes + 1 + 3) & ~3));
+    unsigned* rinfo = reinterpret_cast<unsigned*>(bufB + (size_t)a.max_nodes * kHid);
+    float* vals = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     unsigned short* words = reinterpret_cast<unsigned short*>(vals + a.meta_cap);
+    unsigned short* perm = words + a.meta_cap;
     if (ng <= 0) {
         if (threadIdx.x == 0 && a.do_lgs) {
             if (a.rounds) a.rounds[g] = 0;
@@ -189,59 +238,69 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     int fault = 0;
 
     // ------------------------------------------------------------ P0: the support matrix into LDS
+    // Row v of L (diagonal first, then the adjacency row) occupies entry slots [S_v, S_v + c_v) with
+    // S_v = (U_v + v + 1) & ~1 where U_v is the unpadded start: even, and never overlapping.
     double* dinv = reinterpret_cast<double*>(bufB);  // scratch until the first transform
+    const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
     for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
-        const int rs = a.row_ptr[n0 + v];
-        roff[v] = rs - e0 + (a.from_adj ? v : 0);
+        const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+        const int start = ((rs - e0) + v * extra + v + 1) & ~1;
+        rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
         if (a.from_adj) {
-            const int deg = a.row_ptr[n0 + v + 1] - rs;
+            const int deg = re - rs;
             double d = 0.0;
             if (deg < a.table_len) d = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
             dinv[v] = d;
         }
     }
-    if (threadIdx.x == 0) roff[ng] = e1 - e0 + (a.from_adj ? ng : 0);
     __syncthreads();
-    if (a.from_adj) {
+    {
         const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
         for (int v = grp; v < ng; v += kFusedBlock / 8) {
             const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
-            const int base = rs - e0 + v;
-            const double dv = dinv[v];
-            if (sub == 0) { words[base] = enc_word(v); vals[base] = 1.0f; }
+            const int base = (int)(rinfo[v] & 0xffff) + extra;
+            const double dv = a.from_adj ? dinv[v] : 0.0;
+            if (a.from_adj && sub == 0) { words[base - 1] = enc_word(v); vals[base - 1] = 1.0f; }
             for (int j = rs + sub; j < re; j += 8) {
-                const int u = a.col_idx[j] - n0;
+                int u = a.col_idx[j] - n0;
                 float val = 0.f;
-                int uu = 0;
-                if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
-                else {
+                if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; }
+                else if (a.from_adj) {
                     if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
                     val = (float)(-(dinv[u] * dv));
-                    uu = u;
+                } else {
+                    val = a.vals[j];
                 }
-                words[j - e0 + v + 1] = enc_word(uu);
-                vals[j - e0 + v + 1] = val;
+                words[base + (j - rs)] = enc_word(u);
+                vals[base + (j - rs)] = val;
             }
         }
-    } else {
-        for (int j = threadIdx.x; j < e1 - e0; j += kFusedBlock) {
-            int u = a.col_idx[e0 + j] - n0;
-            if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; }
-            words[j] = enc_word(u);
-            vals[j] = a.vals[e0 + j];
+        // processing order: rank of v by (entry count desc, index asc) -> perm[rank] = v
+        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+            const unsigned cv = rinfo[v] >> 16;
+            int rank = 0;
+            for (int w = 0; w < ng; ++w) {
+                const unsigned cw = rinfo[w] >> 16;
+                rank += (cw > cv) || (cw == cv && w < v);
+            }
+            perm[rank] = (unsigned short)v;
         }
     }
     __syncthreads();  // dinv scratch (bufB) is dead from here on
 
     // ------------------------------------------------------------ layers
-    float score = 0.f;  // final output of vertex threadIdx.x (+ k * block), only ng <= block supported
+    float score = 0.f;  // final output of vertex threadIdx.x (ng <= block, checked by the host)
+    float bfrag[8][4];
+    if (a.num_layers > 2) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
     for (int l = 0; l < a.num_layers; ++l) {
         const FusedLayer& L = a.layers[l];
         if (L.cout == kHid) {
             if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB);
-            else hidden_transform(L, ng, bufA, bufB);
+            else if (!DIAG_ON(a, 1)) hidden_transform(bfrag, ng, bufA, bufB);
+            // fetch the next hidden layer's weights now; they land while this layer gathers
+            if (l >= 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
-            hidden_aggregate(L, ng, bufA, bufB, roff, vals, words);
+            if (!DIAG_ON(a, 0)) hidden_aggregate(L, ng, bufA, bufB, rinfo, perm, vals, words);
             __syncthreads();
         } else {
             // last layer: width 1.  z0 stays in a register, z1 goes to bufB[v] (bufB is free: the
@@ -260,8 +319,10 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             }
             __syncthreads();
             if (v < ng) {
+                const unsigned ri = rinfo[v];
+                const int rs = ri & 0xffff, re = rs + (ri >> 16);
                 float acc = 0.f;
-                for (int j = roff[v]; j < roff[v + 1]; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
+                for (int j = rs; j < re; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
                 float o = z0 + acc;
                 if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
@@ -301,8 +362,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     }
     int rounds = 0;
     int remaining = 1;
-    const int rs = v < ng ? roff[v] : 0, re = v < ng ? roff[v + 1] : 0;
+    const int rs = v < ng ? (int)(rinfo[v] & 0xffff) : 0, re = v < ng ? rs + (int)(rinfo[v] >> 16) : 0;
     const double pv = v < ng ? pr[v] : 0.0;
+    if (DIAG_ON(a, 2)) remaining = 0;
     while (remaining) {
         bool live = v < ng && st[v] == 0;
         bool lost = false;
@@ -348,10 +410,13 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// entry slots: the entries themselves plus at most one padding slot per row (even row starts)
+static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 3) & ~3; }
+
 static size_t fused_lds_bytes(int max_nodes, int meta_cap) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
-    const size_t roff = (size_t)((max_nodes + 1 + 3) & ~3) * sizeof(int);
-    return bufs + roff + (size_t)meta_cap * 6 + 16;
+    const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
+    return bufs + rinfo + (size_t)meta_cap * 6 + (size_t)max_nodes * 2 + 16;
 }
 
 static int fused_shape_ok(const DgcnModel* m) {
@@ -393,7 +458,10 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     return DGCN_OK;
 }
 
-static int fused_launch(const FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+#ifdef DGCN_DIAG
+    a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -413,7 +481,7 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     args.col_idx = lap->col_idx;
     args.vals = lap->values;
     args.from_adj = 0;
-    args.meta_cap = lap->max_graph_nnz > 0 ? lap->max_graph_nnz : b->max_graph_edges + b->max_nodes;
+    args.meta_cap = fused_meta_cap((lap->max_graph_nnz > 0 ? lap->max_graph_nnz : b->max_graph_edges + b->max_nodes), b->max_nodes);
     args.X = X;
     args.x_const = x_const;
     args.scores = scores;
@@ -431,7 +499,7 @@ using namespace dgcn;
 extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m || !m->layers_host || m->num_supports != 2) return 0;
     if (!fused_shape_ok(m) || b->max_nodes > kFusedBlock) return 0;
-    const int cap = b->max_graph_edges + b->max_nodes;
+    const int cap = fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes);
     return fused_lds_bytes(max(b->max_nodes, 64), cap) <= 160 * 1024;
 }
 
@@ -450,7 +518,7 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     args.dinv_table = dinv_table;
     args.table_len = table_len;
     args.from_adj = 1;
-    args.meta_cap = b->max_graph_edges + b->max_nodes;
+    args.meta_cap = fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes);
     args.X = X;
     args.x_const = x_const;
     args.scores = scores;
