@@ -67,13 +67,22 @@ struct FusedArgs {
     int32_t max_nodes;
     int32_t meta_cap;
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
+    unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
     FusedLayer layers[kMaxFusedLayers];
 };
 
 #ifdef DGCN_DIAG
 #define DIAG_ON(a, bit) (((a).diag >> (bit)) & 1)
+// phase clock of workgroup g, slot i: accumulated (not overwritten) so per-layer phases sum up
+#define STAMP(a, g, i, t0)                                                                    \
+    do {                                                                                      \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
+        if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(g) * 16 + (i)] += _t - (t0); \
+        (t0) = _t;                                                                            \
+    } while (0)
 #else
 #define DIAG_ON(a, bit) 0
+#define STAMP(a, g, i, t0) do { } while (0)
 #endif
 
 __device__ __forceinline__ int swz(int row, int col) {  // float index of H[row][col] in a swizzled buffer
@@ -234,47 +243,88 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
         return;
     }
+    unsigned long long tclk = 0;
+#ifdef DGCN_DIAG
+    tclk = __builtin_amdgcn_s_memtime();
+#endif
+    (void)tclk;
+#ifdef DGCN_DIAG
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[(size_t)g * 16 + 12] = hw;
+        a.stamps[(size_t)g * 16 + 13] = xcc;
+        a.stamps[(size_t)g * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
     int fault = 0;
 
     // ------------------------------------------------------------ P0: the support matrix into LDS
     // Row v of L (diagonal first, then the adjacency row) occupies entry slots [S_v, S_v + c_v) with
     // S_v = (U_v + v + 1) & ~1 where U_v is the unpadded start: even, and never overlapping.
+    // Two dependent global round trips only: (row_ptr, d^-1/2 table) then (col_idx [, values]), the
+    // second one entry-parallel and coalesced with 4 loads in flight per thread; the owning row of
+    // an entry is found by bisection over the row starts kept in LDS.
     double* dinv = reinterpret_cast<double*>(bufB);  // scratch until the first transform
+    int* rowstart = reinterpret_cast<int*>(bufA);    // [ng + 1], scratch until the first transform
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
     for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
         const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
         const int start = ((rs - e0) + v * extra + v + 1) & ~1;
         rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
+        rowstart[v] = rs - e0;
         if (a.from_adj) {
             const int deg = re - rs;
             double d = 0.0;
             if (deg < a.table_len) d = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
             dinv[v] = d;
+            words[start] = enc_word(v);
+            vals[start] = 1.0f;
         }
     }
+    if (threadIdx.x == 0) rowstart[ng] = e1 - e0;
     __syncthreads();
+    STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
-        const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        for (int v = grp; v < ng; v += kFusedBlock / 8) {
-            const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
-            const int base = (int)(rinfo[v] & 0xffff) + extra;
-            const double dv = a.from_adj ? dinv[v] : 0.0;
-            if (a.from_adj && sub == 0) { words[base - 1] = enc_word(v); vals[base - 1] = 1.0f; }
-            for (int j = rs + sub; j < re; j += 8) {
-                int u = a.col_idx[j] - n0;
-                float val = 0.f;
-                if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; }
+        const int total = e1 - e0;
+        for (int base = threadIdx.x; base < total; base += kFusedBlock * 4) {
+            int c[4];
+            float gv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = base + i * kFusedBlock;
+                c[i] = 0;
+                gv[i] = 0.f;
+                if (j < total) {
+                    c[i] = a.col_idx[e0 + j];
+                    if (!a.from_adj) gv[i] = a.vals[e0 + j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = base + i * kFusedBlock;
+                if (j >= total) continue;
+                int lo = 0, hi = ng;  // last row whose start is <= j
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rowstart[mid] <= j) lo = mid; else hi = mid;
+                }
+                const int v = lo;
+                int u = c[i] - n0;
+                float val = gv[i];
+                if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; val = 0.f; }
                 else if (a.from_adj) {
                     if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
-                    val = (float)(-(dinv[u] * dv));
-                } else {
-                    val = a.vals[j];
+                    val = (float)(-(dinv[u] * dinv[v]));
                 }
-                words[base + (j - rs)] = enc_word(u);
-                vals[base + (j - rs)] = val;
+                const int slot = (int)(rinfo[v] & 0xffff) + extra + (j - rowstart[v]);
+                words[slot] = enc_word(u);
+                vals[slot] = val;
             }
         }
+        STAMP(a, g, 1, tclk);  // P0b: entries
         // processing order: rank of v by (entry count desc, index asc) -> perm[rank] = v
         for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
             const unsigned cv = rinfo[v] >> 16;
@@ -286,7 +336,8 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             perm[rank] = (unsigned short)v;
         }
     }
-    __syncthreads();  // dinv scratch (bufB) is dead from here on
+    __syncthreads();  // scratch (bufA, bufB) is dead from here on
+    STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
     float score = 0.f;  // final output of vertex threadIdx.x (ng <= block, checked by the host)
@@ -297,11 +348,15 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         if (L.cout == kHid) {
             if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB);
             else if (!DIAG_ON(a, 1)) hidden_transform(bfrag, ng, bufA, bufB);
+            STAMP(a, g, l == 0 ? 3 : 5, tclk);  // transform body (wave 0)
             // fetch the next hidden layer's weights now; they land while this layer gathers
             if (l >= 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
+            STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
             if (!DIAG_ON(a, 0)) hidden_aggregate(L, ng, bufA, bufB, rinfo, perm, vals, words);
+            STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
             __syncthreads();
+            STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
         } else {
             // last layer: width 1.  z0 stays in a register, z1 goes to bufB[v] (bufB is free: the
             // previous aggregation finished at the barrier above).
@@ -329,6 +384,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
                 if (a.scores) a.scores[n0 + v] = score;
             }
             __syncthreads();
+            STAMP(a, g, 9, tclk);  // last layer
         }
     }
     if (!a.do_lgs) {
@@ -337,19 +393,21 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     }
 
     // ------------------------------------------------------------ priority + local greedy search
+    // heuristics.py:77-116.  Priorities are turned into unique integer ranks under the order
+    // (priority desc, index asc) once; a removed vertex gets rank 0xFFFF.  A round is then: every
+    // live vertex takes the minimum rank over its adjacency (one LDS read per neighbour), wins iff
+    // its own rank is smaller; winners join and kill their neighbours.  lpv lanes share a vertex.
     double* pr = reinterpret_cast<double*>(bufB);
     double* red = pr + a.max_nodes;  // [kFusedBlock] slots; bufB has 128 B per row and max_nodes >= 64 rows
-    uint8_t* st = reinterpret_cast<uint8_t*>(bufA);
-    uint8_t* nw = st + a.max_nodes;
-    const int v = threadIdx.x;
+    unsigned short* key = reinterpret_cast<unsigned short*>(bufA);
+    uint8_t* st = reinterpret_cast<uint8_t*>(key + a.max_nodes);
+    constexpr unsigned kDead = 0xFFFFu;
     int bad = 0;
-    if (v < ng) {
+    if ((int)threadIdx.x < ng) {
         double p = (double)score;
-        if (a.predict_mwis && a.weights) p *= a.weights[n0 + v];
+        if (a.predict_mwis && a.weights) p *= a.weights[n0 + threadIdx.x];
         bad = (p != p);
-        pr[v] = p;
-        st[v] = 0;
-        nw[v] = 0;
+        pr[threadIdx.x] = p;
     }
     if (__syncthreads_or(bad)) {
         if (threadIdx.x == 0) {
@@ -357,47 +415,59 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             if (a.rounds) a.rounds[g] = -1;
             if (a.totals) a.totals[g] = 0.0;
         }
-        if (v < ng) a.state[n0 + v] = 0;
+        if ((int)threadIdx.x < ng) a.state[n0 + threadIdx.x] = 0;
         return;
     }
-    int rounds = 0;
-    int remaining = 1;
-    const int rs = v < ng ? (int)(rinfo[v] & 0xffff) : 0, re = v < ng ? rs + (int)(rinfo[v] >> 16) : 0;
-    const double pv = v < ng ? pr[v] : 0.0;
-    if (DIAG_ON(a, 2)) remaining = 0;
-    while (remaining) {
-        bool live = v < ng && st[v] == 0;
-        bool lost = false;
-        if (live) {
-            for (int j = rs; j < re; ++j) {
-                const int u = words[j] >> 7;
-                if (u != v && st[u] == 0) {
-                    const double pu = pr[u];
-                    lost |= (pu > pv) || (pu == pv && u < v);
-                }
-            }
-            nw[v] = lost ? 0 : 1;
-        }
-        __syncthreads();
-        if (live && !lost) {
-            for (int j = rs; j < re; ++j) {
-                const int u = words[j] >> 7;
-                if (u != v && st[u] == 0) st[u] = 2;
+    int lsh = 0;  // lanes per vertex = 1 << lsh, as many as the block affords (<= 8)
+    while (lsh < 3 && (ng << (lsh + 1)) <= kFusedBlock) ++lsh;
+    const int lpv = 1 << lsh;
+    const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
+    const bool mine = vv < ng;
+    {
+        int cnt = 0;
+        if (mine) {
+            const double pvv = pr[vv];
+            for (int w = sub; w < ng; w += lpv) {
+                const double pw = pr[w];
+                cnt += (pw > pvv) || (pw == pvv && w < vv);
             }
         }
-        __syncthreads();
-        int mine = 0;
-        if (v < ng && st[v] == 0) {
-            if (nw[v]) st[v] = 1; else mine = 1;
-        }
-        remaining = __syncthreads_or(mine);
-        ++rounds;
+        for (int off = 1; off < lpv; off <<= 1) cnt += __shfl_xor(cnt, off);
+        if (mine && sub == 0) { key[vv] = (unsigned short)cnt; st[vv] = 0; }
     }
-    if (v < ng) a.state[n0 + v] = st[v];
+    __syncthreads();
+    int rounds = 0;
+    const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
+    while (!DIAG_ON(a, 2)) {
+        const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
+        const bool live = mykey != kDead;
+        unsigned m = kDead;
+        if (live)
+            for (int j = rs + sub; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                const unsigned k = key[u];
+                if (u != vv) m = min(m, k);
+            }
+        for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
+        const bool won = live && mykey < m;
+        if (!__syncthreads_or(live)) break;  // also orders every rank read before the kills below
+        ++rounds;
+        if (won) {
+            for (int j = rs + sub; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                if (u != vv && key[u] != kDead) { key[u] = (unsigned short)kDead; st[u] = 2; }
+            }
+            if (sub == 0) { key[vv] = (unsigned short)kDead; st[vv] = 1; }
+        }
+        __syncthreads();
+    }
+    STAMP(a, g, 10, tclk);  // priorities, ranks, greedy rounds
+    const int tv = threadIdx.x;
+    if (tv < ng) a.state[n0 + tv] = st[tv];
     if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
     if (a.totals) {
         double part = 0.0;
-        if (v < ng && st[v] == 1) part = a.weights ? a.weights[n0 + v] : pv;
+        if (tv < ng && st[tv] == 1) part = a.weights ? a.weights[n0 + tv] : pr[tv];
         red[threadIdx.x] = part;
         __syncthreads();
         for (int off = kFusedBlock / 2; off > 0; off >>= 1) {
@@ -407,6 +477,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         if (threadIdx.x == 0) a.totals[g] = red[0];
     }
     if (fault) atomicOr(a.status, fault);
+    STAMP(a, g, 11, tclk);  // totals, output
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -460,7 +531,11 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
 #ifdef DGCN_DIAG
+    if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
+#endif
+#ifdef DGCN_DIAG
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
+    a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused),
