@@ -1,0 +1,85 @@
+"""Glue shared by the drop-in modules (heuristics, gcn.*, mwis_*_call): the process-wide engine and
+conversions between the reference's host objects (SciPy matrices, COO tuples) and device batches."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from .batch import HostBatch
+
+_engine = None
+
+
+def get_engine(device=None):
+    """The process-wide Engine (created on first use; raises DgcnError without a GPU - the product
+    has no CPU fallback)."""
+    global _engine
+    if _engine is None or (device is not None and str(_engine.device) != str(device)):
+        from .engine import Engine
+        _engine = Engine(device or "cuda")
+    return _engine
+
+
+def as_csr(adj):
+    a = sp.csr_matrix(adj)
+    if a.shape[0] != a.shape[1]:
+        raise ValueError("adjacency must be square, got %s" % (a.shape,))
+    a.sum_duplicates()
+    a.sort_indices()
+    return a
+
+
+def single_batch(adj, weights=None) -> HostBatch:
+    a = as_csr(adj)
+    w = None if weights is None else [np.asarray(weights, dtype=np.float64).ravel()]
+    return HostBatch.from_csr_lists([a.indptr.astype(np.int64)], [a.indices.astype(np.int64)], w)
+
+
+def tuple_to_dense(tup, dtype=np.float32):
+    coords, values, shape = tup
+    out = np.zeros(shape, dtype=dtype)
+    coords = np.asarray(coords)
+    if coords.size:
+        out[coords[:, 0], coords[:, 1]] = np.asarray(values).astype(dtype)
+    return out
+
+
+def state_to_device(engine, state, input_dim):
+    """Turn the reference's ``state`` dict into (DeviceBatch with its support attached, X or None).
+
+    A state made by this package's ``makestate`` carries the adjacency (key ``"adj"``): the support
+    is then built on the device.  A foreign state (supports computed elsewhere as COO tuples,
+    ``gcn/utils.py:258-274``) is honoured as given: ``support[1]`` is uploaded as the CSR of L.
+    """
+    import torch
+    feats = state["features"]
+    n = int(feats[2][0])
+    X = tuple_to_dense(feats, np.float32)
+    if X.shape[1] != input_dim:
+        raise ValueError("state features have %d columns, model expects %d" % (X.shape[1], input_dim))
+    const = X[0, 0] if X.size else 0.0
+    Xd = None if (X.size and np.all(X == const)) else torch.from_numpy(X).to(engine.device)
+    x_const = float(const)
+    adj = state.get("adj") if isinstance(state, dict) else None
+    if adj is not None:
+        db = engine.upload(single_batch(adj))
+        return db, Xd, x_const
+    sup = dict.__getitem__(state, "support") if isinstance(state, dict) else state["support"]
+    if len(sup) != 2:
+        raise _lib.DgcnError("only [I, L] supports (max_degree=1) are implemented; state has %d" % len(sup))
+    coords, values, shape = sup[1]
+    lap = sp.csr_matrix((np.asarray(values, dtype=np.float64), (coords[:, 0], coords[:, 1])), shape=shape)
+    lap.sort_indices()
+    off = lap.copy().tolil()
+    off.setdiag(0)
+    off = sp.csr_matrix(off)
+    off.eliminate_zeros()
+    db = engine.upload(HostBatch.from_csr_lists([off.indptr.astype(np.int64)], [off.indices.astype(np.int64)]))
+    t = torch
+    row_ptr = t.from_numpy(lap.indptr.astype(np.int32)).to(engine.device)
+    col = t.from_numpy(lap.indices.astype(np.int32)).to(engine.device)
+    val = t.from_numpy(lap.data.astype(np.float32)).to(engine.device)  # TF's float64 -> float32 feed cast
+    csr = _lib.DgcnCsr(n, int(lap.nnz), int(lap.nnz), row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
+    db.lap = {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
+    return db, Xd, x_const

@@ -26,14 +26,16 @@ class HostBatch:
         self.num_graphs = int(self.graph_ptr.size - 1)
         self.num_nodes = int(self.graph_ptr[-1]) if self.graph_ptr.size else 0
         self.num_edges = int(self.row_ptr[-1]) if self.row_ptr.size else 0
+        if self.row_ptr.size != self.num_nodes + 1:
+            raise ValueError("row_ptr has %d entries, expected %d" % (self.row_ptr.size, self.num_nodes + 1))
+        if self.col_idx.size != self.num_edges:
+            raise ValueError("col_idx has %d entries, row_ptr says %d" % (self.col_idx.size, self.num_edges))
         sizes = np.diff(self.graph_ptr)
         self.max_nodes = int(sizes.max()) if sizes.size else 0
         gedges = self.row_ptr[self.graph_ptr[1:]] - self.row_ptr[self.graph_ptr[:-1]] if self.num_graphs else np.zeros(0)
         self.max_graph_edges = int(gedges.max()) if self.num_graphs else 0
         deg = np.diff(self.row_ptr)
         self.max_degree = int(deg.max()) if deg.size else 0
-        if self.row_ptr.size != self.num_nodes + 1:
-            raise ValueError("row_ptr has %d entries, expected %d" % (self.row_ptr.size, self.num_nodes + 1))
         if self.weights is not None and self.weights.size != self.num_nodes:
             raise ValueError("weights has %d entries, expected %d" % (self.weights.size, self.num_nodes))
 

@@ -133,20 +133,25 @@ class _GCNBase:
             self._device_model = DeviceModel(self.layers, engine.device)
         return self._device_model
 
-    def forward_batch(self, engine, device_batch, X=None, mode: int = 0):
+    def forward_batch(self, engine, device_batch, X=None, x_const=None, mode: int = 0):
         """scores[num_nodes, out] for a whole batch, on the device (no host round trip)."""
-        out = engine.forward(device_batch, self.device_model(engine), X=X, mode=mode)
         if self.is_dual:
             raise NotImplementedError("GCN2_DQN(is_dual=True) (models.py:651-653) is not implemented")
-        return out
+        return engine.forward(device_batch, self.device_model(engine), X=X, x_const=x_const, mode=mode)
 
     def predict(self, state, engine=None):
         """``sess.run([outputs_softmax, pred])`` for ONE graph given the reference's ``state`` dict
         ({"features": COO tuple, "support": [COO tuples]}) -> (act_values [N, out] f32, action [out] i64)."""
         from ..api_common import get_engine, state_to_device
         engine = engine or get_engine()
-        db, X = state_to_device(engine, state, self.input_dim)
-        scores = self.forward_batch(engine, db, X=X).cpu().numpy()
+        db, X, x_const = state_to_device(engine, state, self.input_dim)
+        dm = self.device_model(engine)
+        mode = 1 if (engine.solve_supported(db, dm) and not self.is_dual) else 0
+        scores_d = self.forward_batch(engine, db, X=X, x_const=x_const, mode=mode)
+        if scores_d.shape[1] == 1:
+            action = engine.argmax(db, scores_d).cpu().numpy().astype(np.int64)  # models.py:526 pred
+            return scores_d.cpu().numpy(), action
+        scores = scores_d.cpu().numpy()
         return scores, np.argmax(scores, axis=0)
 
 

@@ -1,0 +1,147 @@
+"""Drop-in for the inference API of the reference's ``mwis_dqn_call.py`` (``DQNAgent``).
+
+``makestate / predict / solve_mwis / load / save`` keep the reference's signatures and return types
+(``mwis_dqn_call.py:104-261``).  ``solve_mwis_batch`` is the MI355X-native entry: many graphs in one
+launch.  Training (``replay``, ``memorize``, epsilon-greedy exploration) is out of scope; calling it
+raises.  Unlike the reference nothing happens at import time (the reference builds a TF session and a
+module-level singleton on import, ``mwis_dqn_call.py:326-344``); ``dqn_agent`` is created lazily by
+``get_agent()``.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from .api_common import as_csr, get_engine
+from .batch import HostBatch
+from .gcn.models import GCN_DQN
+from .gcn import utils as gutils
+from .runtime_config import FLAGS, flags  # noqa: F401
+
+flags.DEFINE_string("test_datapath", "./data/ER_Graph_Uniform_NP20_test", "test dataset")
+
+
+class _State(dict):
+    """The reference's state dict.  ``support`` is materialised on first access (host SciPy, as in the
+    reference) - the device path works from ``adj`` and never needs it."""
+
+    def __missing__(self, key):
+        if key == "support":
+            sup = gutils.simple_polynomials(self["adj"], self["max_degree"])
+            self["support"] = sup
+            return sup
+        raise KeyError(key)
+
+    def copy(self):
+        return _State(self)
+
+
+class DQNAgent:
+    model_class = GCN_DQN
+
+    def __init__(self, feature_size=32, memory_size=5000, flags=None, seed=0):
+        self.flags = flags or FLAGS
+        self.feature_size = int(feature_size)
+        self.smallconst = 0.000001
+        self.gamma = 0.95
+        self.epsilon = self.flags.epsilon
+        self.epsilon_min = self.flags.epsilon_min
+        self.epsilon_decay = 0.985
+        self.learning_rate = self.flags.learning_rate
+        self.model = self._build_model(seed)
+
+    def _build_model(self, seed=0):
+        return GCN_DQN(None, input_dim=self.feature_size, flags=self.flags, seed=seed)
+
+    # ---- reference API ------------------------------------------------------------------------
+    def makestate(self, adj, wts_nn):
+        """``mwis_dqn_call.py:129-138``: features = ones * w/||w||, row-normalised (=> 1/F per
+        non-zero-weight row); support = [I, L]."""
+        wts_nn = np.asarray(wts_nn, dtype=np.float64).reshape(-1, 1)
+        n = wts_nn.shape[0]
+        norm = np.linalg.norm(wts_nn)
+        feats = np.multiply(np.ones([n, self.feature_size]), wts_nn / norm)
+        features = gutils.preprocess_features(sp.lil_matrix(feats))
+        return _State(features=features, adj=as_csr(adj), max_degree=int(self.flags.max_degree))
+
+    def predict(self, state):
+        """``sess.run([outputs_softmax, pred])`` (``:140-143``) -> (act_values [N,1] f32, action [1] i64)."""
+        return self.model.predict(state, get_engine())
+
+    def act(self, state):
+        _, action = self.predict(state)
+        return action
+
+    def load(self, name):
+        self.model.load(name)
+        print("loaded " + name)
+
+    def save(self, name):
+        self.model.save(name)
+
+    def memorize(self, *a, **k):
+        raise NotImplementedError("training (replay memory) is outside the inference drop-in")
+
+    replay = memorize
+
+    def solve_mwis(self, adj_0, wts_0, train=False):
+        """``mwis_dqn_call.py:198-261`` (inference branch) -> (set of original vertex ids, total_wt, 1.0).
+        Zero-weight vertices are dropped first and ids mapped back (``:202-207, 241``)."""
+        if train:
+            raise NotImplementedError("train=True (exploration + replay memory) is outside the inference drop-in")
+        return self.solve_mwis_batch([adj_0], [wts_0])[0]
+
+    # ---- batched entry --------------------------------------------------------------------------
+    def _prune(self, adj, wts):
+        a = as_csr(adj)
+        w = np.asarray(wts, dtype=np.float64).ravel()
+        keep = np.where(w > 0)[0]
+        if keep.size != w.size:
+            a = as_csr(a[keep][:, keep])
+        return a, w[keep], keep
+
+    def solve_mwis_batch(self, adjs: Sequence, wts_list: Sequence, mode: str = "auto") -> List[tuple]:
+        """Solve many graphs in one launch.  Returns a list of ``(set, total_wt, 1.0)`` in input order."""
+        eng = get_engine()
+        pruned = [self._prune(a, w) for a, w in zip(adjs, wts_list)]
+        hb = HostBatch.from_csr_lists([p[0].indptr.astype(np.int64) for p in pruned],
+                                      [p[0].indices.astype(np.int64) for p in pruned], [p[1] for p in pruned])
+        res = solve_host_batch(eng, self.model, hb, self.flags.predict, mode)
+        out = []
+        for g, (n0, n1) in enumerate(hb.graph_slices()):
+            keep = pruned[g][2]
+            sel = np.flatnonzero(res["state"][n0:n1] == 1)
+            out.append((set(int(i) for i in keep[sel]), np.float64(res["totals"][g]), 1.0))
+        return out
+
+
+def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str = "auto", X=None):
+    """Upload, run the whole path, fetch.  ``mode``: "fused" (one launch), "layered", or "auto"."""
+    db = eng.upload(hb)
+    dm = model.device_model(eng)
+    if model.is_dual:
+        raise NotImplementedError("is_dual models are not implemented")
+    fused_ok = eng.solve_supported(db, dm)
+    if mode == "fused" and not fused_ok:
+        raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")
+    use_fused = fused_ok if mode == "auto" else (mode == "fused")
+    from .engine import MODE_FUSED, MODE_LAYERED
+    res = eng.solve(db, dm, predict=predict, mode=MODE_FUSED if use_fused else MODE_LAYERED, X=X)
+    eng.check_status(res["status"])
+    return {"state": res["state"].cpu().numpy(), "totals": res["totals"].cpu().numpy(),
+            "rounds": res["rounds"].cpu().numpy(),
+            "scores": None if res["scores"] is None else res["scores"].cpu().numpy()}
+
+
+_agent = None
+
+
+def get_agent():
+    """The lazily-built counterpart of the reference's module-level ``dqn_agent`` (``:344``)."""
+    global _agent
+    if _agent is None:
+        _agent = DQNAgent(FLAGS.feature_size, 5000)
+    return _agent

@@ -1,0 +1,158 @@
+"""GPU: the drop-in modules (same names, arguments and return types as the reference) against the
+oracle and the reference-derived goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M1 = "result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn"
+M20 = "result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn"
+M16 = "result_IS4SAT_deep_ld1_c16_l4_cheb1_diver1_mwis_dqn"
+
+
+def _flags(**kw):
+    from distgcn_amd.runtime_config import FLAGS
+    base = dict(feature_size=1, hidden1=32, num_layer=20, diver_num=1, max_degree=1, predict="mwis")
+    base.update(kw)
+    return FLAGS.copy(**base)
+
+
+@pytest.mark.parametrize("variant", ["raw", "ties1", "signed"])
+def test_heuristics_dropin(engine, golden, variant):
+    from distgcn_amd import heuristics as h
+    for i in (0, 1, 8, 12):
+        adj = golden.scipy(i).tocoo()  # what a modern loadmat hands out
+        k = "g%02d_%s" % (i, variant)
+        prio = golden.lgs[k + "_prio"]
+        s, tot = h.local_greedy_search(adj, prio)
+        assert isinstance(s, set) and all(isinstance(x, int) for x in s) and isinstance(tot, np.float64)
+        assert sorted(s) == golden.lgs[k + "_set"].tolist()
+        assert tot == pytest.approx(float(golden.lgs[k + "_total"]), rel=1e-12, abs=1e-12)
+        s2, _, step = h.local_greedy_search_count(adj, prio.reshape(-1, 1))  # column vectors are flattened
+        assert s2 == s and step == int(golden.lgs[k + "_rounds"])
+        _, _, step, p2p, bst = h.local_greedy_search_stats(adj, prio)
+        assert (step, p2p, bst) == (int(golden.lgs[k + "_rounds"]), int(golden.lgs[k + "_p2p"]), int(golden.lgs[k + "_bst"]))
+        *_, oh = h.local_greedy_search_overhead(adj, prio)
+        assert oh.dtype == np.float64 and np.array_equal(oh, golden.lgs[k + "_overhead"])
+        sn, _, nb = h.local_greedy_search_nstep(adj, prio, nstep=1)
+        assert sorted(sn) == golden.lgs[k + "_n1_set"].tolist() and sorted(nb) == golden.lgs[k + "_n1_nb"].tolist()
+    adj = golden.scipy(3)
+    g, gtot = h.greedy_search(adj, golden.csr(3)[2])
+    assert sorted(g) == golden.lgs["g03_raw_greedy_set"].tolist()
+    assert gtot == pytest.approx(float(golden.graphs["g03_greedy_utility"]), rel=1e-9)
+
+
+def test_heuristics_preconditions(engine):
+    import scipy.sparse as sp
+    from distgcn_amd import heuristics as h
+    from distgcn_amd._lib import DgcnError
+    a = sp.csr_matrix(np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=float))
+    with pytest.raises(DgcnError, match="NaN"):
+        h.local_greedy_search(a, [1.0, float("nan"), 2.0])
+    loop = sp.csr_matrix(np.array([[1, 1], [1, 0]], dtype=float))
+    with pytest.raises(DgcnError, match="self-loop"):
+        h.local_greedy_search(loop, [1.0, 2.0])
+    assert h.local_greedy_search(sp.csr_matrix((0, 0)), [])[0] == set()
+    assert h.local_greedy_search_nstep(a, [3.0, 2.0, 1.0], nstep=0) == (set(), np.float64(0.0), set())
+
+
+@pytest.mark.parametrize("mname", [M1, M20, M16])
+def test_dqn_agent_solve_mwis(engine, golden, mname):
+    """mwis_dqn_call.DQNAgent.solve_mwis(adj, wts) -> (set, total, 1.0), incl. zero-weight pruning."""
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ref_numpy as orc
+    hid = 16 if "_c16_" in mname else 32
+    import re
+    nl = int(re.search(r"_l(\d+)_cheb", mname).group(1))
+    agent = DQNAgent(1, flags=_flags(hidden1=hid, num_layer=nl))
+    agent.model.set_params(golden.params(mname))
+    layers = golden.layers(mname)
+    rng = np.random.default_rng(1)
+    for i in (0, 2, 9):
+        adj = golden.scipy(i)
+        w = golden.csr(i)[2].copy()
+        w[rng.random(w.size) < 0.1] = 0.0  # the pruning branch (mwis_dqn_call.py:202-207)
+        got, tot, reward = agent.solve_mwis(adj, w)
+        want, wtot, _ = orc.solve_mwis_dqn(layers, adj, w)
+        assert got == set(int(x) for x in want) and reward == 1.0
+        assert tot == pytest.approx(float(wtot), rel=1e-12)
+    res = agent.solve_mwis_batch([golden.scipy(i) for i in (3, 4, 5)], [golden.csr(i)[2] for i in (3, 4, 5)])
+    for (got, tot, _), i in zip(res, (3, 4, 5)):
+        assert got == agent.solve_mwis(golden.scipy(i), golden.csr(i)[2])[0]
+    with pytest.raises(NotImplementedError):
+        agent.solve_mwis(golden.scipy(0), golden.csr(0)[2], train=True)
+
+
+def test_predict_state_api(engine, golden):
+    """makestate/predict: act_values float32 [N,1], action int64 [1]; a foreign state (supports built
+    by the oracle's SciPy code, as the reference would) gives the same scores within 1e-5."""
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(1, flags=_flags())
+    agent.model.set_params(golden.params(M20))
+    adj, w = golden.scipy(0), golden.csr(0)[2]
+    state = agent.makestate(adj, w.reshape(-1, 1))
+    act_values, action = agent.predict(state)
+    assert act_values.dtype == np.float32 and act_values.shape == (200, 1)
+    assert action.dtype == np.int64 and action.shape == (1,) and action[0] == int(np.argmax(act_values[:, 0]))
+    assert np.abs(act_values[:, 0] - golden.scores["g00|%s|f64" % M20]).max() <= 1e-5
+    assert len(state["support"]) == 2 and state["support"][1][1].dtype == np.float64  # lazily built host copy
+    foreign = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "dqn_call")
+    fv, fa = agent.predict(foreign)
+    assert np.abs(fv - act_values).max() <= 1e-5 and fa[0] == action[0]
+
+
+def test_gdpg_agent(engine, golden):
+    """mwis_gdpg_call.DQNAgent: GCN2_DQN with bias on every layer and leaky_relu on the last."""
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    fl = _flags(num_layer=3)
+    agent = DQNAgent(fl, seed=5)
+    rng = np.random.default_rng(2)
+    for k in agent.model.vars:
+        if k.endswith("/bias"):
+            agent.model.vars[k] = rng.uniform(-0.2, 0.2, agent.model.vars[k].shape).astype(np.float32)
+    agent.model._device_model = None
+    layers = agent.model.layers
+    assert layers[-1]["act"] == "leaky_relu"
+    for i in (1, 10):
+        adj, w = golden.scipy(i), golden.csr(i)[2]
+        got, tot = agent.solve_mwis(adj, w)
+        want, wtot = orc.solve_mwis_gdpg(layers, adj, w)
+        assert got == set(int(x) for x in want) and tot == pytest.approx(float(wtot), rel=1e-12)
+    # predict != 'mwis': features w/(max w + 1e-9), priority = raw score
+    agent2 = DQNAgent(_flags(num_layer=3, predict="mis"), seed=5)
+    adj, w = golden.scipy(2), golden.csr(2)[2]
+    got, tot = agent2.solve_mwis(adj, w)
+    want, wtot = orc.solve_mwis_gdpg(agent2.model.layers, adj, w, predict="mis")
+    assert got == set(int(x) for x in want)
+
+
+def test_graph_convolution_layer(engine, golden):
+    from distgcn_amd.gcn.layers import GraphConvolution
+    from oracle import ctwin
+    hb = golden.host_batch([2, 3])
+    db = engine.upload(hb)
+    layer = GraphConvolution(1, 32, act="leaky_relu", bias=True, seed=4)
+    out = layer(engine, db).cpu().numpy()
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    want = ctwin.forward(lap, [layer.layer_dict()], hb.num_nodes)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_sharded_solve_single_rank(engine, golden):
+    """parallel.solve_sharded wrapping the HIP engine (world 1 here; world 2 runs on gloo in test_dist_gloo)."""
+    from distgcn_amd import datagen, parallel
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = datagen.ba_test2_batch(30)
+    layers = datagen.random_model(20, 32)
+    dm = DeviceModel(layers, engine.device)
+
+    def local(sub):
+        res = engine.solve_fused(engine.upload(sub), dm)
+        return {k: res[k].cpu().numpy() for k in ("state", "totals", "rounds")}
+
+    res = parallel.solve_sharded(hb, local)
+    ref = ctwin.solve(hb, layers)
+    assert np.array_equal(res["state"], ref["state"]) and np.array_equal(res["rounds"], ref["rounds"])

@@ -1,0 +1,79 @@
+"""CPU: batch packing, synthetic generators, sharding, flags, host mirrors of gcn.utils."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from distgcn_amd import datagen, directory, parallel
+from distgcn_amd.batch import HostBatch
+from distgcn_amd.gcn import utils as gutils
+from distgcn_amd.runtime_config import FLAGS, parse_argv
+
+
+def test_batch_packing(golden):
+    hb = golden.host_batch()
+    assert hb.num_graphs == golden.num_graphs
+    for g, (n0, n1) in enumerate(hb.graph_slices()):
+        a = hb.scipy_graph(g)
+        assert (a != golden.scipy(g)).nnz == 0
+        cols = hb.col_idx[hb.row_ptr[n0]:hb.row_ptr[n1]]
+        assert cols.min(initial=n0) >= n0 and cols.max(initial=n0) < n1
+    hb2 = HostBatch.from_scipy([sp.coo_matrix(golden.scipy(i)) for i in range(3)], [golden.csr(i)[2] for i in range(3)])
+    assert np.array_equal(hb2.col_idx, golden.host_batch(range(3)).col_idx)
+    sub = hb.subset(2, 5)
+    assert sub.num_graphs == 3 and (sub.scipy_graph(0) != golden.scipy(2)).nnz == 0
+    empty = HostBatch(np.array([0, 0, 2]), np.array([0, 0, 0]), np.zeros(0))
+    assert empty.num_graphs == 2 and empty.max_nodes == 2 and empty.num_edges == 0
+    with pytest.raises(ValueError):
+        HostBatch(np.array([0, 2]), np.array([0, 1]), np.array([1]))
+
+
+def test_generators_deterministic_and_well_formed():
+    a = datagen.er_batch(6, 50, 0.1)
+    b = datagen.er_batch(6, 50, 0.1)
+    assert np.array_equal(a.col_idx, b.col_idx) and np.array_equal(a.weights, b.weights)
+    c = datagen.er_batch(3, 50, 0.1, first_index=3)
+    assert np.array_equal(c.weights, a.weights[150:])
+    for hb in (a, datagen.ba_test2_batch(10)):
+        for g in range(hb.num_graphs):
+            m = hb.scipy_graph(g)
+            assert (m != m.T).nnz == 0 and m.diagonal().sum() == 0
+            assert np.all(np.diff(m.indptr) >= 0)
+    ba = datagen.ba_test2_batch(25)
+    sizes = np.diff(ba.graph_ptr)
+    assert sorted(set(sizes.tolist())) == [100, 150, 200, 250, 300]
+    m = ba.scipy_graph(4)  # N=100, m=20: (N - m - 1) * m + m edges
+    assert m.nnz // 2 == (100 - 21) * 20 + 20
+
+
+def test_shard_ranges_cover_and_balance():
+    hb = datagen.ba_test2_batch(50)
+    for world in (1, 2, 3, 8):
+        r = parallel.shard_ranges(hb, world)
+        assert r[0][0] == 0 and r[-1][1] == hb.num_graphs
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+    r = parallel.shard_ranges(hb, 4)
+    cost = [int(hb.graph_ptr[b] - hb.graph_ptr[a] + hb.row_ptr[hb.graph_ptr[b]] - hb.row_ptr[hb.graph_ptr[a]]) for a, b in r]
+    assert max(cost) < 1.6 * (sum(cost) / 4)
+
+
+def test_flags_and_directory():
+    assert FLAGS.num_layer == 20 and FLAGS.predict == "mwis" and FLAGS.max_degree == 1
+    fl = FLAGS.copy(training_set="IS4SAT", feature_size=1, hidden1=32, num_layer=20, max_degree=1, diver_num=1)
+    assert directory.find_model_folder(fl, "dqn") == "./model/result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn"
+    saved = FLAGS.hidden1
+    rest = parse_argv(["--hidden1=16", "--unknown=3", "pos"])
+    assert FLAGS.hidden1 == 16 and rest == ["--unknown=3", "pos"]
+    FLAGS.hidden1 = saved
+
+
+def test_host_utils_match_goldens(golden):
+    adj = golden.scipy(3)
+    sup = gutils.simple_polynomials(adj, 1)
+    lap = sp.csr_matrix((sup[1][1], (sup[1][0][:, 0], sup[1][0][:, 1])), shape=sup[1][2])
+    lap.sort_indices()
+    assert np.array_equal(lap.data, golden.supports["g03_lap_data"])
+    w = golden.csr(3)[2]
+    f = gutils.preprocess_features(sp.lil_matrix(np.ones([w.size, 1]) * w[:, None]))
+    dense = np.zeros(w.size)
+    dense[f[0][:, 0]] = f[1]
+    assert np.array_equal(dense, golden.supports["g03_feat_rownorm"])

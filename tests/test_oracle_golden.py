@@ -1,0 +1,172 @@
+"""CPU: the oracle (oracle/ref_numpy.py and the C twin) against the golden vectors that
+oracle/make_golden.py captured from the imported reference.  No GPU, no /root/reference needed."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ctwin, ref_numpy as orc
+
+VARIANTS = ["raw", "ties1", "ties0", "signed", "int3"]
+
+
+def test_supports_match_reference(golden):
+    """A1/A2: oracle simple_polynomials == imported gcn.utils.simple_polynomials (float64 bits)."""
+    for i in range(golden.num_graphs):
+        adj = golden.scipy(i)
+        sup = orc.simple_polynomials(adj, 1)
+        assert np.array_equal(sup[0][1], np.ones(adj.shape[0]))
+        lap = sp.csr_matrix((sup[1][1], (sup[1][0][:, 0], sup[1][0][:, 1])), shape=sup[1][2])
+        lap.sort_indices()
+        k = "g%02d" % i
+        assert np.array_equal(lap.indptr, golden.supports[k + "_lap_indptr"])
+        assert np.array_equal(lap.indices, golden.supports[k + "_lap_indices"])
+        assert np.array_equal(lap.data, golden.supports[k + "_lap_data"])
+        if k + "_lap2_data" in golden.supports.files:
+            sup2 = orc.simple_polynomials(adj, 2)
+            lap2 = sp.csr_matrix((sup2[2][1], (sup2[2][0][:, 0], sup2[2][0][:, 1])), shape=sup2[2][2])
+            lap2.sort_indices()
+            assert np.array_equal(lap2.indices, golden.supports[k + "_lap2_indices"])
+            assert np.allclose(lap2.data, golden.supports[k + "_lap2_data"], rtol=0, atol=1e-15)
+
+
+def test_preprocess_features_match_reference(golden):
+    for i in range(golden.num_graphs):
+        w = golden.csr(i)[2]
+        feats = orc.preprocess_features(sp.lil_matrix(np.ones([w.size, 1]) * w[:, None]))
+        dense = np.zeros(w.size)
+        dense[feats[0][:, 0]] = feats[1]
+        assert np.array_equal(dense, golden.supports["g%02d_feat_rownorm" % i])
+
+
+def test_twin_supports_bits(golden):
+    """The C twin's float32 support values == float32 cast of the reference's float64 values."""
+    hb = golden.host_batch()
+    lrp, lc, lv, fault = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)
+    assert fault == 0
+    for i, (n0, n1) in enumerate(hb.graph_slices()):
+        e0, e1 = lrp[n0], lrp[n1]
+        m = sp.csr_matrix((lv[e0:e1], lc[e0:e1] - n0, lrp[n0:n1 + 1] - e0), shape=(n1 - n0, n1 - n0))
+        m.sort_indices()
+        assert np.array_equal(m.indices, golden.supports["g%02d_lap_indices" % i])
+        assert np.array_equal(m.data, golden.supports["g%02d_lap_data" % i].astype(np.float32))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_lgs_python_oracle_matches_reference(golden, variant):
+    """A8/A8': the Python-set restatement on a subset (it is as slow as the reference)."""
+    for i in (1, 2, 7):
+        adj = golden.scipy(i)
+        k = "g%02d_%s" % (i, variant)
+        prio = golden.lgs[k + "_prio"]
+        s, tot, rounds, p2p, bst, oh = orc.local_greedy_search_overhead(adj, prio)
+        assert sorted(s) == golden.lgs[k + "_set"].tolist()
+        assert rounds == golden.lgs[k + "_rounds"] and p2p == golden.lgs[k + "_p2p"] and bst == golden.lgs[k + "_bst"]
+        assert np.array_equal(oh, golden.lgs[k + "_overhead"])
+        assert tot == pytest.approx(float(golden.lgs[k + "_total"]), rel=1e-12, abs=1e-12)
+        for ns in (1, 2):
+            sn, _, nb = orc.local_greedy_search_nstep(adj, prio, nstep=ns)
+            assert sorted(sn) == golden.lgs["%s_n%d_set" % (k, ns)].tolist()
+            assert sorted(nb) == golden.lgs["%s_n%d_nb" % (k, ns)].tolist()
+        assert orc.local_greedy_search(adj, prio)[0] == s
+        assert orc.local_greedy_search_count(adj, prio)[2] == rounds
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_lgs_twin_and_vectorised_match_reference(golden, variant):
+    """All fixture graphs: C twin and the vectorised form reproduce the reference's sets, rounds,
+    message counts, overhead vectors and the _nstep partial results."""
+    ids = list(range(golden.num_graphs))
+    hb = golden.host_batch(ids)
+    prio = np.concatenate([golden.lgs["g%02d_%s_prio" % (i, variant)] for i in ids])
+    r = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, prio)
+    assert r["fault"] == 0
+    for i, (n0, n1) in enumerate(hb.graph_slices()):
+        k = "g%02d_%s" % (i, variant)
+        assert np.array_equal(np.flatnonzero(r["state"][n0:n1] == 1), golden.lgs[k + "_set"])
+        assert r["rounds"][i] == golden.lgs[k + "_rounds"]
+        assert r["stats"][i, 0] == golden.lgs[k + "_p2p"] and r["stats"][i, 1] == golden.lgs[k + "_bst"]
+        assert np.array_equal(r["overhead"][n0:n1], golden.lgs[k + "_overhead"].astype(np.int32))
+        assert r["totals"][i] == pytest.approx(float(golden.lgs[k + "_total"]), rel=1e-12, abs=1e-12)
+        p, c, _ = golden.csr(i)
+        st, rounds = orc.lgs_vectorised(p, c, prio[n0:n1])
+        assert np.array_equal(st, r["state"][n0:n1]) and rounds == r["rounds"][i]
+    for ns in (1, 2):
+        r = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, prio, max_rounds=ns)
+        for i, (n0, n1) in enumerate(hb.graph_slices()):
+            k = "g%02d_%s_n%d" % (i, variant, ns)
+            assert np.array_equal(np.flatnonzero(r["state"][n0:n1] == 1), golden.lgs[k + "_set"])
+            assert np.array_equal(np.flatnonzero(r["state"][n0:n1] == 2), golden.lgs[k + "_nb"])
+
+
+def test_greedy_utility_pins(golden):
+    """A9: greedy_utility stored by the reference in every .mat == oracle greedy == oracle local greedy."""
+    for i in range(golden.num_graphs):
+        p, c, w = golden.csr(i)
+        st, _ = orc.lgs_vectorised(p, c, w)
+        tot = w[st == 1].sum()
+        assert tot == pytest.approx(float(golden.graphs["g%02d_greedy_utility" % i]), rel=1e-9)
+        assert np.array_equal(np.flatnonzero(st == 1), golden.lgs["g%02d_raw_greedy_set" % i])
+    adj = golden.scipy(2)
+    s, tot = orc.greedy_search(adj, golden.csr(2)[2])
+    assert sorted(s) == golden.lgs["g02_raw_greedy_set"].tolist()
+
+
+def test_forward_anchors_and_closed_form(golden):
+    """SURVEY anchors (ER_n200_p0.1_b0, IS4SAT l=1 and l=20) and the l=1 closed form."""
+    adj = golden.scipy(0)
+    w = golden.csr(0)[2]
+    state = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "gdpg")
+    l1 = golden.layers("result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn")
+    l20 = golden.layers("result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn")
+    s1, a1 = orc.gcn_forward(l1, state)
+    s20, _ = orc.gcn_forward(l20, state)
+    assert np.allclose(s1[:5, 0], [0.6762156, 0.81670225, 0.65740633, 0.5908851, 0.7500816], atol=1e-7)
+    assert np.allclose(s20[:5, 0], [0.7366634, 0.8553817, 0.6315565, 0.61124575, 0.7963782], atol=2e-6)
+    assert a1.shape == (1,) and a1[0] == int(np.argmax(s1[:, 0]))
+    w0, w1 = float(l1[0]["weights"][0][0, 0]), float(l1[0]["weights"][1][0, 0])
+    d = np.asarray(adj.sum(1)).ravel()
+    dinv = np.where(d > 0, d ** -0.5, 0.0)
+    assert np.abs(s1[:, 0] - (w0 + w1 * (1.0 - dinv * (adj @ dinv)))).max() < 1e-6
+    mw, tot = orc.solve_mwis_gdpg(l20, adj, w)
+    assert len(mw) == 29 and tot == pytest.approx(22.786594696283, rel=1e-12)
+    assert sorted(mw)[:12] == [1, 5, 20, 21, 30, 40, 49, 51, 59, 69, 80, 81]
+
+
+def test_twin_forward_close_to_restatement(golden):
+    """The C twin (HIP operation order) stays within 1e-5 of the float64 restatement, except on the
+    fixture graphs where plain float32 arithmetic itself does not (then: twice its own distance)."""
+    hb = golden.host_batch()
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    for m in golden.model_names:
+        sc = ctwin.forward(lap, golden.layers(m), hb.num_nodes)[:, 0]
+        for i, (n0, n1) in enumerate(hb.graph_slices()):
+            f64 = golden.scores["g%02d|%s|f64" % (i, m)]
+            f32 = golden.scores["g%02d|%s|f32" % (i, m)]
+            assert np.abs(sc[n0:n1] - f64).max() <= max(1e-5, 2 * np.abs(f32 - f64).max()), (m, i)
+
+
+def test_twin_solve_equals_restatement_sets(golden):
+    """End to end on fixtures: sets chosen from twin scores == sets stored from restatement scores
+    wherever the decisive priority margins exceed the float32 noise (all fixture cases do)."""
+    hb = golden.host_batch()
+    for m in ("result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn", "result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn"):
+        res = ctwin.solve(hb, golden.layers(m))
+        same = 0
+        for i, (n0, n1) in enumerate(hb.graph_slices()):
+            same += np.array_equal(np.flatnonzero(res["state"][n0:n1] == 1), golden.scores["g%02d|%s|set" % (i, m)])
+        assert same >= golden.num_graphs - 1
+
+
+def test_reference_import_agrees_when_available(golden):
+    """In the build container only: call the reference's own functions again and compare."""
+    import os
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle.make_golden import import_reference
+    ref_h, ref_u = import_reference()
+    adj = golden.scipy(2)
+    w = golden.csr(2)[2]
+    assert ref_h.local_greedy_search(adj, w)[0] == orc.local_greedy_search(adj, w)[0]
+    a = ref_u.simple_polynomials(adj, 1)[1]
+    b = orc.simple_polynomials(adj, 1)[1]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
