@@ -6,8 +6,8 @@
 One "step" = one pass of the whole hot path over one batch already resident in HBM:
 support construction (L = I - D^-1/2 A D^-1/2) -> 20-layer c32 GCN forward -> priority product ->
 local greedy search.  Workload at every N: BASELINE.json configs[2] (C3), 500 ER graphs
-G(200, 0.1) per GPU (weak scaling: each rank owns its own 500 graphs; no data-path collective, the
-only collective is the final gather of memberships, outside nothing - it is inside the timed step).
+G(200, 0.1) per GPU (weak scaling: each rank owns its own 500 graphs; no data-path collective; the
+one collective, the end-of-step all_gather of the membership bytes, is inside the timed step).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--mode", choices=["layered", "fused", "auto"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step membership gather at N>1")
+    ap.add_argument("--no-spmm-probe", action="store_true", help="skip the stand-alone SpMM kernel measurement")
     return ap.parse_args()
 
 
@@ -58,15 +59,15 @@ def load_layers(args):
     return datagen.random_model(args.layers, args.hidden), "random-init weights"
 
 
-def spmm_algorithmic_bytes(hb, layers):
-    """SURVEY 8d formula per SpMM launch, summed over the layers of one forward:
-    sum_g[nnz_g*(4+4) + (N_g+1)*4] + 2*4*C*sum N_g, plus 4*C*sum N_g for the fused '+ Z0' read."""
+def spmm_algorithmic_bytes(hb, layers, with_y0):
+    """SURVEY 8d formula per SpMM launch, one entry per layer of the forward:
+    sum_g[nnz_g*(4+4) + (N_g+1)*4] + 2*4*C*sum N_g  (+ 4*C*sum N_g for the fused '+ Z0' read)."""
     n, nnz_l = hb.num_nodes, hb.num_edges + hb.num_nodes
     csr = nnz_l * 8 + (n + hb.num_graphs) * 4
     per_launch = []
     for lyr in layers:
         c = lyr["weights"][0].shape[1]
-        per_launch.append(csr + 3 * 4 * c * n)
+        per_launch.append(csr + (3 if with_y0 else 2) * 4 * c * n)
     return per_launch
 
 
@@ -153,38 +154,81 @@ def main():
         dt = float(tt.item())
 
     # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the
-    # timed region (on the launch stream), against algorithmic bytes
+    # timed region (on the launch stream), against SURVEY 8d's algorithmic bytes
     fam_ms = {}
     for fam in ("supports", "transform", "spmm", "lgs", "fused_forward", "fused_solve"):
         ms, n = eng.timing_read(fam)
         if n:
             fam_ms[fam] = (ms, n)
     roofline = None
+    per_layer_bytes = spmm_algorithmic_bytes(hb, layers, with_y0=False)  # SURVEY 8d, layer by layer
+    traffic_db = {}
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.isfile(tpath):
+        traffic_db = json.load(open(tpath))
     if fam_ms:
         dom = max(fam_ms, key=lambda k: fam_ms[k][0])
         ms, n = fam_ms[dom]
         avg_s = ms / n * 1e-3
+        tkey = "%s|%dx%d|l%d" % (dom, args.graphs, args.nodes, args.layers)
+        traffic = traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")
         if dom == "spmm":
-            per = spmm_algorithmic_bytes(hb, layers)
+            per = spmm_algorithmic_bytes(hb, layers, with_y0=True)
             avg_bytes = sum(per) / len(per)
             ach = avg_bytes / avg_s / 1e9
-            roofline = {"kernel": "k_spmm_lds (all %d launches per step)" % len(per), "bound": "hbm",
+            roofline = {"kernel": "k_spmm_lds (all %d launches of a step)" % len(per), "bound": "hbm",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": None, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": avg_bytes}
+                        "traffic": traffic, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": avg_bytes,
+                        "formula": "SURVEY 8d B_spmm + 4*C*N for the fused '+Z0' read, averaged over the layers"}
         elif dom in ("fused_forward", "fused_solve"):
+            # one launch = every layer of every graph: SURVEY 8d counts the forward layer by layer
+            # (1.658 MB per ER N=200 l=20 graph); the kernel keeps the graph in LDS, so its real HBM
+            # traffic ('traffic', from PMC counters) is far BELOW this figure, not above it.
+            algo = float(sum(per_layer_bytes))
+            ach = algo / avg_s / 1e9
             flops = 0.0
             n_nodes, nnz_l = hb.num_nodes, hb.num_edges + hb.num_nodes
             for lyr in layers:
                 cin, cout = lyr["weights"][0].shape
                 flops += 2.0 * n_nodes * cin * 2 * cout + 2.0 * nnz_l * cout
-            ach = flops / avg_s / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_TF, "traffic": None,
-                        "avg_launch_us": avg_s * 1e6, "algorithmic_flops_per_launch": flops}
+            roofline = {"kernel": "k_fused (%s: whole path, one launch per step)" % dom, "bound": "hbm",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": traffic, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo,
+                        "formula": "SURVEY 8d: sum over layers of B_spmm (CSR + Z read + Y write), %d graphs" % hb.num_graphs,
+                        "fp32_matrix_view": {"flops_per_launch": flops, "achieved_tflops": flops / avg_s / 1e12,
+                                             "peak_tflops": F32_MATRIX_PEAK_TF,
+                                             "frac": flops / avg_s / 1e12 / F32_MATRIX_PEAK_TF}}
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": None, "traffic": None, "avg_launch_us": avg_s * 1e6}
+                        "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
     kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
+
+    # ---- the stand-alone batched SpMM kernel of the north star (not part of the fused step): one
+    # hidden-layer aggregation over the same batch, timed with the same event hooks, outside the timed region
+    spmm_line = None
+    if rank == 0 and not args.no_spmm_probe:
+        lap = eng.supports(db)
+        C = args.hidden
+        Zt = torch.randn(hb.num_nodes, 2 * C, device=dev)
+        Yt = torch.empty(hb.num_nodes, C, device=dev)
+        def one():
+            eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs,
+                     max_nodes=hb.max_nodes, Y0=Zt, ldy0=2 * C, act="leaky_relu", out=Yt)
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize()
+        eng.timing(True)
+        for _ in range(50):
+            one()
+        torch.cuda.synchronize()
+        eng.timing(False)
+        ms, n = eng.timing_read("spmm")
+        nb = (hb.num_edges + hb.num_nodes) * 8 + (hb.num_nodes + hb.num_graphs) * 4 + 3 * 4 * C * hb.num_nodes
+        ach = nb / (ms / n * 1e-3) / 1e9
+        spmm_line = {"kernel": "k_spmm_lds C=%d with the GraphConvolution epilogue" % C, "bound": "hbm", "achieved": ach,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": ms / n * 1e3,
+                     "algorithmic_bytes_per_launch": nb,
+                     "traffic": traffic_db.get("spmm|%dx%d|C%d" % (args.graphs, args.nodes, C), {}).get("hbm_bytes_per_launch")}
 
     if rank == 0:
         out = {
@@ -204,6 +248,7 @@ def main():
                                    "supports rebuilt every step" % (args.graphs, args.nodes, args.p, args.layers, args.hidden),
                        "forward_mode": mode_name, "graphs_per_gpu": args.graphs, "parallelism": "graph-sharded x%d" % world},
             "roofline": roofline,
+            "spmm_kernel_roofline": spmm_line,
             "kernels": kernel_us,
         }
         if world == 1 and args.cpu_seconds > 0:
