@@ -86,6 +86,35 @@ class HostBatch:
         w = None if self.weights is None else self.weights[n0:n1]
         return HostBatch(self.graph_ptr[lo:hi + 1] - n0, self.row_ptr[n0:n1 + 1] - e0, self.col_idx[e0:e1] - n0, w)
 
+    def select(self, ids) -> "HostBatch":
+        """The graphs ``ids`` (any order) as a new batch."""
+        ids = np.asarray(ids, dtype=np.int64)
+        ps, cs, ws = [], [], []
+        for g in ids:
+            n0, n1 = int(self.graph_ptr[g]), int(self.graph_ptr[g + 1])
+            e0, e1 = int(self.row_ptr[n0]), int(self.row_ptr[n1])
+            ps.append(self.row_ptr[n0:n1 + 1].astype(np.int64) - e0)
+            cs.append(self.col_idx[e0:e1].astype(np.int64) - n0)
+            if self.weights is not None:
+                ws.append(self.weights[n0:n1])
+        return HostBatch.from_csr_lists(ps, cs, ws if self.weights is not None else None)
+
+    def size_buckets(self, lds_budget: int = 80 * 1024, hidden: int = 32):
+        """Group graphs by the LDS image the fused kernel needs (``csrc/fused.hip``): graphs that fit
+        two-per-CU in one bucket, the rest in another.  A launch sizes LDS for its largest graph, so a
+        few big graphs would otherwise halve the residency of all the small ones.  Returns a list of
+        index arrays (a single one when the batch is homogeneous)."""
+        if self.num_graphs == 0:
+            return [np.zeros(0, np.int64)]
+        sizes = np.diff(self.graph_ptr).astype(np.int64)
+        nnz = (self.row_ptr[self.graph_ptr[1:]] - self.row_ptr[self.graph_ptr[:-1]]).astype(np.int64)
+        need = np.maximum(sizes, 64) * hidden * 4 * 2 + (nnz + 2 * sizes + 6) * 6 + sizes * 6 + 64
+        small = np.flatnonzero(need <= lds_budget)
+        big = np.flatnonzero(need > lds_budget)
+        if small.size == 0 or big.size == 0 or min(small.size, big.size) < 32:
+            return [np.arange(self.num_graphs)]
+        return [small, big]
+
     def scipy_graph(self, g: int):
         n0, n1 = int(self.graph_ptr[g]), int(self.graph_ptr[g + 1])
         e0, e1 = int(self.row_ptr[n0]), int(self.row_ptr[n1])

@@ -1,0 +1,73 @@
+"""The "500 graphs" evaluation loop of the reference (``mwis_dqn_test.py:304-348``) as a batched call.
+
+The reference walks a folder of ``.mat`` files (``adj``, ``weights``, ``greedy_utility`` ...,
+``Data_Generation.py:218-219``), solves each graph, and records the approximation ratio
+``p = total_wt / greedy_utility`` (``mwis_dqn_test.py:321``) in a CSV.  Here the folder becomes one
+block-diagonal batch and one launch; the denominators come from the stored ``greedy_utility`` or are
+recomputed on the device (``greedy_search`` on raw weights, ``mwis_dqn_test.py:311``).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .api_common import as_csr, get_engine
+from .batch import HostBatch
+
+
+def load_mat_folder(path: str, limit: Optional[int] = None) -> Dict[str, list]:
+    """Read the reference's dataset folders.  ``loadmat`` hands out COO/CSC depending on the SciPy
+    version (the reference relied on CSC row slicing); everything is normalised to sorted CSR."""
+    import scipy.io as sio
+    names = sorted(f for f in os.listdir(path) if f.endswith(".mat"))
+    if limit is not None:
+        names = names[:limit]
+    out = {"names": names, "adjs": [], "weights": [], "greedy_utility": [], "mwis_utility": []}
+    for f in names:
+        m = sio.loadmat(os.path.join(path, f))
+        out["adjs"].append(as_csr(m["adj"]))
+        out["weights"].append(np.asarray(m["weights"], dtype=np.float64).ravel())
+        out["greedy_utility"].append(float(np.asarray(m["greedy_utility"]).ravel()[0]) if "greedy_utility" in m else None)
+        out["mwis_utility"].append(float(np.asarray(m["mwis_utility"]).ravel()[0]) if "mwis_utility" in m else None)
+    return out
+
+
+def greedy_utilities(adjs: Sequence, wts_list: Sequence) -> np.ndarray:
+    """``greedy_search(adj, wts)`` totals for a batch (the denominators of ``mwis_dqn_test.py:311``)."""
+    import torch
+    eng = get_engine()
+    csrs = [as_csr(a) for a in adjs]
+    hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs], [c.indices.astype(np.int64) for c in csrs],
+                                  [np.asarray(w, dtype=np.float64).ravel() for w in wts_list])
+    db = eng.upload(hb)
+    res = eng.lgs(db, prio=db.weights, sum_weights=db.weights)
+    eng.check_status(res["status"])
+    return res["totals"].cpu().numpy()
+
+
+def evaluate(agent, adjs: Sequence, wts_list: Sequence, greedy_utility: Optional[Sequence[float]] = None,
+             names: Optional[Sequence[str]] = None) -> List[dict]:
+    """Solve every graph with ``agent.solve_mwis_batch`` and return one record per graph:
+    ``{"data", "p", "total", "size"}`` - ``p`` is the reference's ratio column."""
+    res = agent.solve_mwis_batch(adjs, wts_list)
+    if greedy_utility is None or any(g is None for g in greedy_utility):
+        greedy_utility = greedy_utilities(adjs, wts_list)
+    rows = []
+    for i, r in enumerate(res):
+        total = float(r[1])
+        rows.append({"data": names[i] if names else i, "p": total / float(greedy_utility[i]), "total": total,
+                     "size": len(r[0])})
+    return rows
+
+
+def write_csv(rows: List[dict], path: str) -> None:
+    """``results.to_csv('./output/<model>.csv')`` (``mwis_dqn_test.py:348``): columns data, p."""
+    import csv
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["", "data", "p"])
+        for i, r in enumerate(rows):
+            w.writerow([i, r["data"], r["p"]])

@@ -119,7 +119,24 @@ class DQNAgent:
 
 
 def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str = "auto", X=None):
-    """Upload, run the whole path, fetch.  ``mode``: "fused" (one launch), "layered", or "auto"."""
+    """Upload, run the whole path, fetch.  ``mode``: "fused" (one launch), "layered", or "auto".
+    Mixed-size batches are solved as two launches (small / large LDS images, ``HostBatch.size_buckets``)."""
+    buckets = hb.size_buckets() if (mode != "layered" and X is None) else [None]
+    if len(buckets) > 1:
+        out = {"state": np.empty(hb.num_nodes, np.uint8), "totals": np.empty(hb.num_graphs),
+               "rounds": np.empty(hb.num_graphs, np.int32), "scores": np.empty((hb.num_nodes, 1), np.float32)}
+        for ids in buckets:
+            sub = hb.select(ids)
+            r = solve_host_batch(eng, model, sub, predict, mode)
+            out["totals"][ids] = r["totals"]
+            out["rounds"][ids] = r["rounds"]
+            for k, g in enumerate(ids):
+                n0, n1 = int(hb.graph_ptr[g]), int(hb.graph_ptr[g + 1])
+                s0 = int(sub.graph_ptr[k])
+                out["state"][n0:n1] = r["state"][s0:s0 + n1 - n0]
+                if r["scores"] is not None:
+                    out["scores"][n0:n1] = r["scores"][s0:s0 + n1 - n0]
+        return out
     db = eng.upload(hb)
     dm = model.device_model(eng)
     if model.is_dual:

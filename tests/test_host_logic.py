@@ -77,3 +77,27 @@ def test_host_utils_match_goldens(golden):
     dense = np.zeros(w.size)
     dense[f[0][:, 0]] = f[1]
     assert np.array_equal(dense, golden.supports["g03_feat_rownorm"])
+
+
+def test_size_buckets_and_select():
+    hb = datagen.ba_test2_batch(100)
+    buckets = hb.size_buckets()
+    assert len(buckets) == 2 and sorted(np.concatenate(buckets).tolist()) == list(range(100))
+    sub = hb.select(buckets[1])
+    assert sub.num_graphs == buckets[1].size
+    g = int(buckets[1][3])
+    assert (sub.scipy_graph(3) != hb.scipy_graph(g)).nnz == 0
+    n0, n1 = hb.graph_slices()[g]
+    assert np.array_equal(sub.weights[sub.graph_ptr[3]:sub.graph_ptr[4]], hb.weights[n0:n1])
+    assert len(datagen.er_batch(40, 100, 0.1).size_buckets()) == 1
+
+
+def test_mat_loader_when_reference_available():
+    import os
+    from distgcn_amd import harness
+    path = "/root/reference/data/ER_Graph_Uniform_GEN21_test2"
+    if not os.path.isdir(path):
+        pytest.skip("reference data not present (GPU box)")
+    d = harness.load_mat_folder(path, limit=3)
+    assert len(d["adjs"]) == 3 and d["adjs"][0].shape[0] == d["weights"][0].size
+    assert d["greedy_utility"][0] > 0 and d["adjs"][0].format == "csr"
