@@ -37,6 +37,12 @@ struct LgsArgs {
     int32_t* status;
     int max_nodes;   // LDS carve-up
     int cols_cap;    // 16-bit column slots in LDS (0 = read col_idx from global memory)
+    // masked / multi-instance form (dgcn_lgs_masked_batch): instance k works on its own
+    // [num_nodes] slice of state/init_state/overhead (and prio when prio_stride != 0) and its own
+    // [num_graphs] slice of rounds/totals/stats, all over the SAME block-diagonal adjacency.
+    const uint8_t* init_state;  // non-zero = vertex does not take part (kept as given in the output)
+    int num_graphs, num_nodes;
+    long prio_stride;
 };
 
 template <bool COLS_LDS>
@@ -57,6 +63,16 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
     unsigned long long p2p = 0, bst = 0;
     int rounds = 0;
     int remaining = ng;
+    if (a.init_state) {  // masked start: count the vertices that actually take part
+        if (threadIdx.x == 0) acc64[2] = 0;
+        __syncthreads();
+        int c = 0;
+        for (int v = threadIdx.x; v < ng; v += 256) c += st[v] == 0;
+        if (c) atomicAdd(&acc64[2], (unsigned long long)c);
+        __syncthreads();
+        remaining = (int)acc64[2];
+        __syncthreads();
+    }
     while (remaining > 0 && (a.max_rounds <= 0 || rounds < a.max_rounds)) {
         if (STATS && threadIdx.x == 0) bst += (unsigned long long)remaining;
         // ---------------- phase A: who wins this round
@@ -145,7 +161,18 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
 template <int LPV, bool STATS>
 __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int g = blockIdx.x;
+    const int inst = blockIdx.x / a.num_graphs;
+    const int g = blockIdx.x - inst * a.num_graphs;
+    if (inst) {
+        const size_t no = (size_t)inst * a.num_nodes, go = (size_t)inst * a.num_graphs;
+        a.state += no;
+        if (a.init_state) a.init_state += no;
+        if (a.overhead) a.overhead += no;
+        if (a.rounds) a.rounds += go;
+        if (a.totals) a.totals += go;
+        if (a.stats) a.stats += 2 * go;
+        if (a.prio) a.prio += (size_t)inst * a.prio_stride;
+    }
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
     // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | u8 st | u8 nw | u16 cols]
@@ -169,9 +196,10 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
         if (a.prio) p = a.prio[n0 + v];
         else if (a.weights) p = (double)a.scores[n0 + v] * a.weights[n0 + v];
         else p = (double)a.scores[n0 + v];
-        bad |= (p != p);
+        const uint8_t s0 = a.init_state ? a.init_state[n0 + v] : (uint8_t)0;
+        bad |= (p != p) && s0 == 0;  // a masked-out vertex may carry any priority
         pr[v] = p;
-        st[v] = 0;
+        st[v] = s0;
         nw[v] = 0;
         if (STATS && a.overhead) a.overhead[n0 + v] = 0;
     }
@@ -231,9 +259,32 @@ static int launch_lgs(const LgsArgs& a, int B, size_t lds, hipStream_t s) {
 
 using namespace dgcn;
 
+static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
+                             const double* weights, const uint8_t* init_state, int32_t num_instances,
+                             int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                             const double* sum_weights, double* totals, int32_t* status, void* stream);
+
 extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const float* scores, const double* weights,
                               int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
                               const double* sum_weights, double* totals, int32_t* status, void* stream) {
+    return lgs_launch_common(b, prio, 0, scores, weights, nullptr, 1, max_rounds, state, rounds, stats, overhead,
+                             sum_weights, totals, status, stream);
+}
+
+extern "C" int dgcn_lgs_masked_batch(const DgcnBatch* b, const double* prio, int64_t prio_stride,
+                                     const uint8_t* init_state, int32_t num_instances, int32_t max_rounds,
+                                     uint8_t* state, int32_t* rounds, const double* sum_weights, double* totals,
+                                     int32_t* status, void* stream) {
+    if (!prio || !init_state || num_instances <= 0)
+        return fail(DGCN_ERR_ARG, "dgcn_lgs_masked_batch: prio, init_state and num_instances > 0 are required");
+    return lgs_launch_common(b, prio, (long)prio_stride, nullptr, nullptr, init_state, num_instances, max_rounds, state,
+                             rounds, nullptr, nullptr, sum_weights, totals, status, stream);
+}
+
+static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
+                             const double* weights, const uint8_t* init_state, int32_t num_instances,
+                             int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                             const double* sum_weights, double* totals, int32_t* status, void* stream) {
     if (!b || !state || !status) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: null argument");
     if (!prio && !scores) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: need prio or scores");
     if (b->num_graphs <= 0) return DGCN_OK;
@@ -248,6 +299,10 @@ extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const floa
     a.state = state; a.rounds = rounds; a.stats = stats; a.overhead = overhead;
     a.sum_weights = sum_weights; a.totals = totals; a.status = status;
     a.max_nodes = b->max_nodes;
+    a.init_state = init_state;
+    a.num_graphs = b->num_graphs;
+    a.num_nodes = b->num_nodes;
+    a.prio_stride = prio_stride;
     // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
     // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
     int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;
@@ -260,8 +315,8 @@ extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const floa
     const int lpv_env = lpv_s ? atoi(lpv_s) : 0;
     int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 64 ? 4 : (b->max_nodes <= 128 ? 2 : 1));
 #define DGCN_LGS_CASE(L)                                                      \
-    if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs, lds, s) \
-                                    : launch_lgs<L, false>(a, b->num_graphs, lds, s)
+    if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs * num_instances, lds, s) \
+                                    : launch_lgs<L, false>(a, b->num_graphs * num_instances, lds, s)
     DGCN_LGS_CASE(1);
     DGCN_LGS_CASE(2);
     DGCN_LGS_CASE(4);

@@ -198,6 +198,23 @@ class Engine:
         return {"state": state[:n], "rounds": rounds[:B], "stats": stats, "overhead": overhead,
                 "totals": totals, "status": status}
 
+    def lgs_masked(self, b: DeviceBatch, prio, init_state, num_instances: int, sum_weights=None, max_rounds: int = 0,
+                   prio_stride: int = 0):
+        """Greedy search on ``num_instances`` residuals of the same batch (``dgcn_lgs_masked_batch``).
+        ``init_state`` is uint8 ``[num_instances, num_nodes]`` (non-zero = vertex taken out)."""
+        t = self.torch
+        n, B = b.host.num_nodes, b.host.num_graphs
+        state = t.empty((num_instances, max(n, 1)), dtype=t.uint8, device=self.device)
+        rounds = t.empty((num_instances, max(B, 1)), dtype=t.int32, device=self.device)
+        totals = t.empty((num_instances, max(B, 1)), dtype=t.float64, device=self.device)
+        status = t.zeros(1, dtype=t.int32, device=self.device)
+        _lib.check(self.lib.dgcn_lgs_masked_batch(C.byref(b.c), prio.data_ptr(), int(prio_stride), init_state.data_ptr(),
+                                                  int(num_instances), int(max_rounds), state.data_ptr(), rounds.data_ptr(),
+                                                  sum_weights.data_ptr() if sum_weights is not None else None,
+                                                  totals.data_ptr(), status.data_ptr(), self._stream()),
+                   "dgcn_lgs_masked_batch")
+        return {"state": state[:, :n], "rounds": rounds[:, :B], "totals": totals[:, :B], "status": status}
+
     # ------------------------------------------------------------------ A10 (batched)
     def solve(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", mode: int = MODE_LAYERED, X=None,
               x_const=None):

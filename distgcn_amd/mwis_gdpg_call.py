@@ -92,6 +92,131 @@ class MWISSolver(object):
         return out
 
 
+    # ---- iterative solvers on the same kernels ------------------------------
+    # Residual graphs are re-sliced on the host exactly as the reference does (SciPy); every
+    # forward pass, greedy round and rollout completion runs on the device.
+    def _residual_scores(self, adj_nn, wts_nn):
+        """(DeviceBatch, device scores [n,1]) of one residual graph: ``makestate`` + ``act``."""
+        eng = get_engine()
+        hb = HostBatch.from_csr_lists([adj_nn.indptr.astype(np.int64)], [adj_nn.indices.astype(np.int64)],
+                                      [np.asarray(wts_nn, dtype=np.float64)[:, 0]])
+        db = eng.upload(hb)
+        dm = self.model.device_model(eng)
+        mode = 1 if eng.solve_supported(db, dm) else 0
+        scores = self.model.forward_batch(eng, db, X=self._features(hb), mode=mode)
+        return eng, db, scores
+
+    @staticmethod
+    def _start(adj_0, wts_0, feature_size):
+        adj_0 = as_csr(adj_0)
+        wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], feature_size))
+        return adj_0, wts, -np.ones(adj_0.shape[0])
+
+    @staticmethod
+    def _slice(adj_0, wts, nIS_vec):
+        remain = nIS_vec == -1
+        rmap = np.argwhere(remain)[:, 0]
+        return as_csr(adj_0[remain, :][:, remain]), wts[remain, :], rmap
+
+    def _gcn_wts(self, scores, wts_nn):
+        act_vals = scores.cpu().numpy().flatten()
+        return act_vals * wts_nn.flatten() if self.flags.predict == "mwis" else act_vals.astype(np.float64)
+
+    def solve_mwis_dit(self, adj_0, wts_0, train=False, grd=1.0):
+        """GCN embedded into the greedy iteration (``mwis_gdpg_call.py:278-318``): scores are
+        recomputed on the residual graph before every round.  -> (mwis, best_IS_util)"""
+        adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
+        best = np.array([0.0])
+        while np.sum(nIS_vec == -1) > 0:
+            adj_nn, wts_nn, rmap = self._slice(adj_0, wts, nIS_vec)
+            if np.sum(wts_nn) <= 0:
+                break
+            eng, db, scores = self._residual_scores(adj_nn, wts_nn)
+            res = eng.lgs(db, scores=scores, weights=db.weights if self.flags.predict == "mwis" else None,
+                          max_rounds=1, want_totals=False)
+            eng.check_status(res["status"])
+            st = res["state"].cpu().numpy()
+            nIS_vec[rmap[st == 1]] = 1
+            nIS_vec[rmap[st == 2]] = 0
+            best = np.dot(nIS_vec, wts)
+        return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+    def solve_mwis_cit(self, adj_0, wts_0, train=False, grd=1.0):
+        """GCN + centralised argmax, one vertex per step (``mwis_gdpg_call.py:343-384``)."""
+        adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
+        best = np.array([0.0])
+        while np.sum(nIS_vec == -1) > 0:
+            adj_nn, wts_nn, rmap = self._slice(adj_0, wts, nIS_vec)
+            if np.sum(wts_nn) <= 0:
+                break
+            _, _, scores = self._residual_scores(adj_nn, wts_nn)
+            pick = int(np.argmax(self._gcn_wts(scores, wts_nn)))
+            nb_v = adj_nn.indices[adj_nn.indptr[pick]:adj_nn.indptr[pick + 1]]
+            nIS_vec[rmap[pick]] = 1
+            nIS_vec[rmap[nb_v]] = 0
+            best = np.dot(nIS_vec, wts)
+        return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+    def solve_mwis_rollout(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        """Top-``b`` GCN candidates, each scored by its weight plus a greedy completion of what is left
+        (``mwis_gdpg_call.py:596-659``).  The ``b`` completions are ONE launch of the masked greedy
+        kernel over the residual graph.  The reference breaks score ties with ``np.random.choice``
+        (unseeded) and ranks with an unstable sort: here ties go to the first candidate / lower index
+        unless ``rng`` (a ``numpy.random.Generator``) is given."""
+        import torch
+        adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
+        best = np.array([0.0])
+        while np.sum(nIS_vec == -1) > 0:
+            adj_nn, wts_nn, rmap = self._slice(adj_0, wts, nIS_vec)
+            n = wts_nn.shape[0]
+            if np.sum(wts_nn) <= 0:
+                break
+            eng, db, scores = self._residual_scores(adj_nn, wts_nn)
+            children = np.argsort(-self._gcn_wts(scores, wts_nn), kind="stable")[0:b]
+            cand = wts_nn[children].copy()
+            if len(cand) > 1:
+                init = np.zeros((len(children), n), dtype=np.uint8)
+                for i, child in enumerate(children):
+                    init[i, child] = 3
+                    init[i, adj_nn.indices[adj_nn.indptr[child]:adj_nn.indptr[child + 1]]] = 3
+                ro = eng.lgs_masked(db, db.weights, torch.from_numpy(init).to(eng.device), len(children),
+                                    sum_weights=db.weights)
+                eng.check_status(ro["status"])
+                cand[:, 0] += ro["totals"].cpu().numpy()[:, 0]
+            # candidates that complete to the same set tie mathematically but not bit for bit (the sums run
+            # in different orders): totals within 1e-12 relative count as tied
+            ties = np.flatnonzero(np.isclose(cand, cand.max(), rtol=1e-12, atol=0.0))
+            i_best = int(rng.choice(ties)) if rng is not None else int(ties[0])
+            pick = int(children[i_best])
+            nb_v = adj_nn.indices[adj_nn.indptr[pick]:adj_nn.indptr[pick + 1]]
+            nIS_vec[rmap[pick]] = 1
+            nIS_vec[rmap[nb_v]] = 0
+            best = np.dot(nIS_vec, wts)
+        return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+    def _wrap(self, inner, adj_0, wts_0, **kw):
+        """Per connected component (``mwis_gdpg_call.py:320-341, 386-411``; components via SciPy
+        instead of NetworkX, vertices in ascending order)."""
+        import scipy.sparse.csgraph as csg
+        adj_0 = as_csr(adj_0)
+        wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], self.feature_size))
+        ncomp, labels = csg.connected_components(adj_0, directed=False)
+        total = np.array([0.0])
+        chosen = set()
+        for c in range(ncomp):
+            comp = np.flatnonzero(labels == c)
+            sub, util = inner(adj_0[comp, :][:, comp], wts[comp, :], **kw)
+            total = total + util
+            chosen |= set(int(comp[i]) for i in sub)
+        return chosen, total
+
+    def solve_mwis_cit_wrap(self, adj_0, wts_0, train=False, grd=1.0):
+        return self._wrap(self.solve_mwis_cit, adj_0, wts_0)
+
+    def solve_mwis_rollout_wrap(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        return self._wrap(self.solve_mwis_rollout, adj_0, wts_0, b=b, rng=rng)
+
+
 class DQNAgent(MWISSolver):
     def __init__(self, input_flags=None, memory_size=5000, seed=0):
         super(DQNAgent, self).__init__(input_flags or FLAGS, memory_size)

@@ -153,6 +153,17 @@ int dgcn_lgs_batch(const DgcnBatch* batch, const double* prio, const float* scor
                    int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
                    const double* sum_weights, double* totals, int32_t* status, void* stream);
 
+/* ---- greedy search on many residuals of the same batch: the rollout of mwis_gdpg_call.py:629-645 ----
+ * Instance k (0 <= k < num_instances) runs the local greedy search on the batch with the vertices
+ * whose init_state[k][v] != 0 taken out beforehand - exactly greedy_search(adj_ro, wts_ro) on the
+ * induced subgraph (heuristics.py:13-35) without re-slicing the adjacency.  Arrays are instance-major:
+ * init_state/state [num_instances][num_nodes], rounds/totals [num_instances][num_graphs];
+ * prio [num_nodes] shared by all instances (prio_stride = 0) or one slice per instance.
+ * state keeps the given init_state values for the vertices that were taken out. */
+int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t prio_stride, const uint8_t* init_state,
+                          int32_t num_instances, int32_t max_rounds, uint8_t* state, int32_t* rounds,
+                          const double* sum_weights, double* totals, int32_t* status, void* stream);
+
 /* ---- A1-A10 in one launch: mwis_gdpg_call.py:200-235 solve_mwis for a whole batch ---------------
  * adjacency + vertex weights in, membership out; one workgroup keeps one graph in LDS from support
  * construction (gcn/utils.py:120-127) through every layer (gcn/models.py:536-573) to the greedy

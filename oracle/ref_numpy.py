@@ -352,3 +352,117 @@ def solve_mwis_dqn(layers, adj, wts, feature_size=1, max_degree=1, predict="mwis
     mwis, _ = local_greedy_search(sub, gcn_wts)
     solu = list(mwis)
     return set(keep[solu]), np.sum(wts_nn[solu, 0]), 1.0
+
+
+# =============================================================================
+# iterative solvers built on the same forward + greedy pieces
+# (mwis_gdpg_call.py:278-411, 596-659).  ``scores_fn(adj_nn, wts_nn) -> act_vals [n, 1]`` stands for
+# ``makestate`` + ``act`` (so tests can plug either this module's forward or the C twin's).
+# =============================================================================
+def _default_scores_fn(layers, feature_size=1, max_degree=1, predict="mwis", dtype=np.float32):
+    def fn(adj_nn, wts_nn):
+        state = makestate(sp.csr_matrix(adj_nn), wts_nn, feature_size, max_degree, "gdpg", predict)
+        return gcn_forward(layers, state, dtype)[0]
+    return fn
+
+
+def _residual(adj_0, wts, nIS_vec):
+    remain = nIS_vec == -1
+    rmap = np.argwhere(remain)[:, 0]
+    adj_nn = adj_0[remain, :][:, remain]
+    return adj_nn, wts[remain, :], rmap
+
+
+def solve_mwis_dit(scores_fn, adj_0, wts_0, predict="mwis"):
+    """GCN re-run on the residual graph before every greedy round (mwis_gdpg_call.py:278-318)."""
+    adj_0 = sp.csr_matrix(adj_0)
+    wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
+    nIS_vec = -np.ones(adj_0.shape[0])
+    best = np.array([0.0])
+    while np.sum(nIS_vec == -1) > 0:
+        adj_nn, wts_nn, rmap = _residual(adj_0, wts, nIS_vec)
+        if np.sum(wts_nn) <= 0:
+            break
+        act_vals = scores_fn(adj_nn, wts_nn)
+        gcn_wts = priority(act_vals, wts_nn, predict)
+        sol, _, nb = local_greedy_search_nstep(adj_nn, gcn_wts, nstep=1)
+        nIS_vec[rmap[list(sol)]] = 1
+        nIS_vec[rmap[list(nb)]] = 0
+        best = np.dot(nIS_vec, wts)
+    return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+
+def solve_mwis_cit(scores_fn, adj_0, wts_0, predict="mwis"):
+    """GCN + centralised argmax, one vertex per step (mwis_gdpg_call.py:343-384)."""
+    adj_0 = sp.csr_matrix(adj_0)
+    wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
+    nIS_vec = -np.ones(adj_0.shape[0])
+    best = np.array([0.0])
+    while np.sum(nIS_vec == -1) > 0:
+        adj_nn, wts_nn, rmap = _residual(adj_0, wts, nIS_vec)
+        if np.sum(wts_nn) <= 0:
+            break
+        gcn_wts = priority(scores_fn(adj_nn, wts_nn), wts_nn, predict)
+        pick = int(np.argmax(gcn_wts))
+        _, nb_v = np.nonzero(adj_nn[pick])
+        nIS_vec[rmap[pick]] = 1
+        nIS_vec[rmap[nb_v]] = 0
+        best = np.dot(nIS_vec, wts)
+    return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+
+def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None):
+    """Top-b GCN candidates, each scored by its weight plus a greedy completion of the residual
+    (mwis_gdpg_call.py:596-659).  The reference breaks score ties with ``np.random.choice`` and ranks
+    with an unstable sort; here ties go to the first candidate / lower index unless ``rng`` is given."""
+    adj_0 = sp.csr_matrix(adj_0)
+    wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
+    nIS_vec = -np.ones(adj_0.shape[0])
+    best = np.array([0.0])
+    while np.sum(nIS_vec == -1) > 0:
+        adj_nn, wts_nn, rmap = _residual(adj_0, wts, nIS_vec)
+        n = wts_nn.shape[0]
+        if np.sum(wts_nn) <= 0:
+            break
+        gcn_wts = priority(scores_fn(adj_nn, wts_nn), wts_nn, predict)
+        children = np.argsort(-gcn_wts.flatten(), kind="stable")[0:b]
+        scores = wts_nn[children].copy()
+        if len(scores) > 1:
+            for i, child in enumerate(children):
+                keep = np.ones((n,), dtype=bool)
+                keep[child] = False
+                _, nb_v = np.nonzero(adj_nn[child])
+                keep[nb_v] = False
+                adj_ro = adj_nn[keep, :][:, keep]
+                _, ss = greedy_search(adj_ro, wts_nn[keep])
+                scores[i] += ss
+        # candidates that complete to the same set tie mathematically but not bit for bit (the sums run in
+        # different orders): totals within 1e-12 relative count as tied
+        ties = np.flatnonzero(np.isclose(scores, scores.max(), rtol=1e-12, atol=0.0))
+        i_best = int(rng.choice(ties)) if rng is not None else int(ties[0])
+        pick = int(children[i_best])
+        _, nb_v = np.nonzero(adj_nn[pick])
+        nIS_vec[rmap[pick]] = 1
+        nIS_vec[rmap[nb_v]] = 0
+        best = np.dot(nIS_vec, wts)
+    return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+
+def _components(adj):
+    import scipy.sparse.csgraph as csg
+    ncomp, labels = csg.connected_components(sp.csr_matrix(adj), directed=False)
+    return [np.flatnonzero(labels == c) for c in range(ncomp)]
+
+
+def solve_wrap(inner, scores_fn, adj_0, wts_0, **kw):
+    """``solve_mwis_cit_wrap`` / ``solve_mwis_rollout_wrap`` (mwis_gdpg_call.py:320-341, 386-411): run
+    ``inner`` per connected component and add the utilities."""
+    adj_0 = sp.csr_matrix(adj_0)
+    wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
+    total = np.array([0.0])
+    chosen = set()
+    for comp in _components(adj_0):
+        sub, util = inner(scores_fn, adj_0[comp, :][:, comp], wts[comp, :], **kw)
+        total = total + util
+        chosen |= set(int(comp[i]) for i in sub)
+    return chosen, total

@@ -197,3 +197,70 @@ def test_mixed_size_batch_is_bucketed(engine):
     ref = ctwin.solve(hb, agent.model.layers)
     assert np.array_equal(res["state"], ref["state"]) and np.array_equal(res["rounds"], ref["rounds"])
     assert np.array_equal(res["scores"].view(np.uint32), ref["scores"].view(np.uint32))
+
+
+def _twin_scores_fn(layers):
+    """scores_fn for the oracle's iterative solvers computed by the C twin (kernel operation order),
+    so the GPU solvers must reproduce the oracle's decisions exactly."""
+    from distgcn_amd.batch import HostBatch
+    from oracle import ctwin
+    import scipy.sparse as sp
+
+    def fn(adj_nn, wts_nn):
+        a = sp.csr_matrix(adj_nn)
+        a.sort_indices()
+        hb = HostBatch.from_csr_lists([a.indptr.astype(np.int64)], [a.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        return ctwin.forward(lap, layers, hb.num_nodes)
+    return fn
+
+
+def test_lgs_masked_instances(engine, golden):
+    """dgcn_lgs_masked_batch == greedy on the induced subgraph, for several masks at once."""
+    import torch
+    from oracle import ctwin
+    from distgcn_amd.batch import HostBatch
+    hb = golden.host_batch([0, 9])
+    db = engine.upload(hb)
+    rng = np.random.default_rng(3)
+    K = 5
+    init = (rng.random((K, hb.num_nodes)) < 0.3).astype(np.uint8) * 3
+    res = engine.lgs_masked(db, db.weights, torch.from_numpy(init).to(engine.device), K, sum_weights=db.weights)
+    engine.check_status(res["status"])
+    state = res["state"].cpu().numpy()
+    totals = res["totals"].cpu().numpy()
+    for k in range(K):
+        for g, (n0, n1) in enumerate(hb.graph_slices()):
+            keep = np.flatnonzero(init[k, n0:n1] == 0)
+            sub = hb.scipy_graph(g)[keep][:, keep].tocsr()
+            sub.sort_indices()
+            shb = HostBatch.from_csr_lists([sub.indptr.astype(np.int64)], [sub.indices.astype(np.int64)])
+            w = hb.weights[n0:n1][keep]
+            r = ctwin.lgs(shb.graph_ptr, shb.row_ptr, shb.col_idx, w, sum_weights=w)
+            assert np.array_equal(state[k, n0:n1][keep], r["state"])
+            assert np.all(state[k, n0:n1][init[k, n0:n1] != 0] == 3)
+            assert totals[k, g] == pytest.approx(r["totals"][0], rel=1e-12)
+
+
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout", "cit_wrap", "rollout_wrap"])
+def test_iterative_solvers(engine, golden, which):
+    """solve_mwis_dit / _cit / _rollout (+ _wrap) against the oracle restatement."""
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(_flags(num_layer=3), seed=9)
+    fn = _twin_scores_fn(agent.model.layers)
+    for i in ((2, 7) if "rollout" in which else (1, 2, 8)):
+        adj, w = golden.scipy(i), golden.csr(i)[2]
+        if which == "dit":
+            got, want = agent.solve_mwis_dit(adj, w), orc.solve_mwis_dit(fn, adj, w)
+        elif which == "cit":
+            got, want = agent.solve_mwis_cit(adj, w), orc.solve_mwis_cit(fn, adj, w)
+        elif which == "rollout":
+            got, want = agent.solve_mwis_rollout(adj, w, b=8), orc.solve_mwis_rollout(fn, adj, w, b=8)
+        elif which == "cit_wrap":
+            got, want = agent.solve_mwis_cit_wrap(adj, w), orc.solve_wrap(orc.solve_mwis_cit, fn, adj, w)
+        else:
+            got = agent.solve_mwis_rollout_wrap(adj, w, b=8)
+            want = orc.solve_wrap(orc.solve_mwis_rollout, fn, adj, w, b=8)
+        assert got[0] == want[0], (which, i)
+        assert np.allclose(got[1], want[1], rtol=1e-12)
