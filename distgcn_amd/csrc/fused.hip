@@ -269,12 +269,16 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     // an entry is found by bisection over the row starts kept in LDS.
     double* dinv = reinterpret_cast<double*>(bufB);  // scratch until the first transform
     int* rowstart = reinterpret_cast<int*>(bufA);    // [ng + 1], scratch until the first transform
+    int* hist = reinterpret_cast<int*>(dinv + a.max_nodes);  // [576] entry-count histogram (bufB: 128 B per row)
+    for (int i = threadIdx.x; i < 576; i += kFusedBlock) hist[i] = 0;
+    __syncthreads();
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
     for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
         const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
         const int start = ((rs - e0) + v * extra + v + 1) & ~1;
         rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
         rowstart[v] = rs - e0;
+        atomicAdd(&hist[min(re - rs + extra, 575)], 1);
         if (a.from_adj) {
             const int deg = re - rs;
             double d = 0.0;
@@ -285,6 +289,25 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
     }
     if (threadIdx.x == 0) rowstart[ng] = e1 - e0;
+    __syncthreads();
+    // Row order for the gather phase: counting sort by entry count, descending.  One wave turns the
+    // histogram into start offsets (lane i owns bins 9i..9i+8, suffix-scanned with shuffles); the order
+    // among equal counts is arbitrary - it only decides which rows share a lockstep pass.
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int loc[9], sum = 0;
+#pragma unroll
+        for (int i = 8; i >= 0; --i) { loc[i] = sum; sum += hist[lane * 9 + i]; }  // within-lane suffix (higher bins first)
+        int above = sum;  // inclusive suffix over lanes >= lane, then made exclusive
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(above, off);
+            if (lane + off < 64) above += t;
+        }
+        above -= sum;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hist[lane * 9 + i] = above + loc[i];
+    }
     __syncthreads();
     STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
@@ -325,15 +348,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             }
         }
         STAMP(a, g, 1, tclk);  // P0b: entries
-        // processing order: rank of v by (entry count desc, index asc) -> perm[rank] = v
         for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
-            const unsigned cv = rinfo[v] >> 16;
-            int rank = 0;
-            for (int w = 0; w < ng; ++w) {
-                const unsigned cw = rinfo[w] >> 16;
-                rank += (cw > cv) || (cw == cv && w < v);
-            }
-            perm[rank] = (unsigned short)v;
+            const int c = min((int)(rinfo[v] >> 16), 575);
+            perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
         }
     }
     __syncthreads();  // scratch (bufA, bufB) is dead from here on
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         int cnt = 0;
         if (mine) {
             const double pvv = pr[vv];
+#pragma unroll 4
             for (int w = sub; w < ng; w += lpv) {
                 const double pw = pr[w];
                 cnt += (pw > pvv) || (pw == pvv && w < vv);
@@ -442,12 +460,23 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
         const bool live = mykey != kDead;
         unsigned m = kDead;
-        if (live)
-            for (int j = rs + sub; j < re; j += lpv) {
+        if (live) {
+            int j = rs + sub;
+            for (; j + 3 * lpv < re; j += 4 * lpv) {  // four independent word -> rank chains in flight
+                const int u0 = words[j] >> 7, u1 = words[j + lpv] >> 7, u2 = words[j + 2 * lpv] >> 7,
+                          u3 = words[j + 3 * lpv] >> 7;
+                const unsigned k0 = key[u0], k1 = key[u1], k2 = key[u2], k3 = key[u3];
+                m = min(m, u0 != vv ? k0 : kDead);
+                m = min(m, u1 != vv ? k1 : kDead);
+                m = min(m, u2 != vv ? k2 : kDead);
+                m = min(m, u3 != vv ? k3 : kDead);
+            }
+            for (; j < re; j += lpv) {
                 const int u = words[j] >> 7;
                 const unsigned k = key[u];
                 if (u != vv) m = min(m, k);
             }
+        }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && mykey < m;
         if (!__syncthreads_or(live)) break;  // also orders every rank read before the kills below
