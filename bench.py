@@ -103,8 +103,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if rank != 0:  # only rank 0 reports; keep other ranks' library banners out of the launcher's stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    use_dist = world > 1 or os.environ.get("DGCN_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -122,7 +128,7 @@ def main():
     mode = MODE_FUSED if mode_name == "fused" else MODE_LAYERED
 
     gather_buf = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         gather_buf = torch.empty(world * hb.num_nodes, dtype=torch.uint8, device=dev)
 
     def step():
@@ -138,18 +144,18 @@ def main():
     eng.check_status(res["status"])
 
     eng.timing(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     eng.timing(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -256,9 +262,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline(hb, layers, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        # RCCL writes a version banner to the C stdout buffer; push it out first so that the JSON
+        # line is the LAST line this process prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:  # anything RCCL still holds in its C stdio buffer must not follow the JSON line
+        try:
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 1)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":
