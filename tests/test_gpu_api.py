@@ -264,3 +264,19 @@ def test_iterative_solvers(engine, golden, which):
             want = orc.solve_wrap(orc.solve_mwis_rollout, fn, adj, w, b=8)
         assert got[0] == want[0], (which, i)
         assert np.allclose(got[1], want[1], rtol=1e-12)
+
+
+def test_large_graph_takes_layered_path(engine):
+    """Graphs beyond the fused kernel's 512 vertices / 160 KB image run layer by layer, same results."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.mwis_dqn_call import DQNAgent, solve_host_batch
+    from oracle import ctwin
+    for n, p in ((600, 0.01), (500, 0.02)):
+        hb = datagen.er_batch(3, n, p)
+        agent = DQNAgent(1, flags=_flags(num_layer=4))
+        assert not engine.solve_supported(engine.upload(hb), DeviceModel(agent.model.layers, engine.device))
+        res = solve_host_batch(engine, agent.model, hb)
+        ref = ctwin.solve(hb, agent.model.layers)
+        assert np.array_equal(res["state"], ref["state"])
+        assert np.array_equal(res["scores"].view(np.uint32), ref["scores"].view(np.uint32))
