@@ -51,9 +51,21 @@ __device__ __forceinline__ int nbr_at(const uint16_t* cl, const int32_t* cg, int
     return cg[j] - n0;
 }
 
+// One residual neighbour test: liveness byte, then the float64 priority compare of the total order
+// (priority desc, index asc).  (A variant on precomputed 16-bit ranks, as in the fused kernel, was
+// measured slower here: the O(N^2) ranking costs more than the cheaper tests save.)
+__device__ __forceinline__ void nbr_test(int u, int v, double pv, const uint8_t* st, const double* pr, bool& lost,
+                                         int& resid) {
+    if (st[u] == 0) {
+        const double pu = pr[u];
+        lost |= (pu > pv) || (pu == pv && u < v);
+        ++resid;
+    }
+}
+
 template <int LPV, bool STATS, bool COLS_LDS>
 __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int ng, int e0, double* pr, uint8_t* st,
-                                           uint8_t* nw, const uint16_t* cl, unsigned long long* acc64) {
+                                           uint8_t* nw, const uint16_t* cl, unsigned long long* acc64, const int* ro) {
     constexpr int kVerts = 256 / LPV;
     const int lane = threadIdx.x & 63;
     const int slot = threadIdx.x / LPV, sub = threadIdx.x % LPV;
@@ -83,15 +95,20 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
             int resid = 0;
             if (live) {
                 const double pv = pr[v];
-                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
-                for (int j = rs + sub; j < re; j += LPV) {
-                    const int u = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
-                    if (st[u] == 0) {
-                        const double pu = pr[u];
-                        lost |= (pu > pv) || (pu == pv && u < v);
-                        ++resid;
-                    }
+                const int rs = ro[v], re = ro[v + 1];
+                int j = rs + sub;
+                for (; j + 3 * LPV < re; j += 4 * LPV) {  // four independent neighbour chains in flight
+                    const int u0 = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                    const int u1 = nbr_at<COLS_LDS>(cl, a.col_idx, j + LPV, e0, n0);
+                    const int u2 = nbr_at<COLS_LDS>(cl, a.col_idx, j + 2 * LPV, e0, n0);
+                    const int u3 = nbr_at<COLS_LDS>(cl, a.col_idx, j + 3 * LPV, e0, n0);
+                    nbr_test(u0, v, pv, st, pr, lost, resid);
+                    nbr_test(u1, v, pv, st, pr, lost, resid);
+                    nbr_test(u2, v, pv, st, pr, lost, resid);
+                    nbr_test(u3, v, pv, st, pr, lost, resid);
                 }
+                for (; j < re; j += LPV)
+                    nbr_test(nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0), v, pv, st, pr, lost, resid);
             }
             if (LPV > 1) {
                 const unsigned long long m = __ballot(lost);
@@ -114,7 +131,7 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
         for (int p = 0; p < passes; ++p) {
             const int v = p * kVerts + slot;
             if (v < ng && st[v] == 0 && nw[v]) {
-                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+                const int rs = ro[v], re = ro[v + 1];
                 for (int j = rs + sub; j < re; j += LPV) {
                     const int u = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
                     if (st[u] == 0) st[u] = 2;  // same value from every writer: benign
@@ -175,11 +192,12 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     }
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
-    // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | u8 st | u8 nw | u16 cols]
+    // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | i32 row offsets | u8 st | u8 nw | u16 cols]
     double* pr = reinterpret_cast<double*>(lds_raw);
     double* red = pr + a.max_nodes;
     unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 256);
-    uint8_t* st = reinterpret_cast<uint8_t*>(acc64 + 4);
+    int* rol = reinterpret_cast<int*>(acc64 + 4);
+    uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
     uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
     uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
     if (ng <= 0) {
@@ -205,8 +223,17 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     }
     const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
     const bool cols_lds = (e1 - e0) <= a.cols_cap && ng <= 65536;
-    if (cols_lds)
-        for (int j = e0 + threadIdx.x; j < e1; j += 256) cl[j - e0] = (uint16_t)(a.col_idx[j] - n0);
+    for (int v = threadIdx.x; v <= ng; v += 256) rol[v] = a.row_ptr[n0 + v];  // row bounds: read once, not per round
+    if (cols_lds) {
+        for (int base = e0 + threadIdx.x; base < e1; base += 256 * 4) {  // 4 loads in flight per thread
+            int c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = (base + i * 256 < e1) ? a.col_idx[base + i * 256] : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + i * 256 < e1) cl[base + i * 256 - e0] = (uint16_t)(c[i] - n0);
+        }
+    }
     if (__syncthreads_or(bad)) {
         // the reference would spin forever on a NaN priority: report instead
         if (threadIdx.x == 0) {
@@ -218,8 +245,8 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
         for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = 0;
         return;
     }
-    if (cols_lds) lgs_rounds<LPV, STATS, true>(a, g, n0, ng, e0, pr, st, nw, cl, acc64);
-    else lgs_rounds<LPV, STATS, false>(a, g, n0, ng, e0, pr, st, nw, cl, acc64);
+    if (cols_lds) lgs_rounds<LPV, STATS, true>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+    else lgs_rounds<LPV, STATS, false>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
 
     for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = st[v];
     if (a.totals) {
@@ -240,7 +267,8 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
 
 static size_t lgs_lds_bytes(int max_nodes, int cols_cap) {
     const size_t pad = (size_t)((max_nodes + 15) & ~15);
-    return (size_t)max_nodes * 8 + 256 * 8 + 4 * 8 + 2 * pad + (size_t)cols_cap * 2;
+    const size_t ro = (size_t)((max_nodes + 1 + 3) & ~3) * 4;
+    return (size_t)max_nodes * 8 + 256 * 8 + 4 * 8 + ro + 2 * pad + (size_t)cols_cap * 2;
 }
 
 template <int LPV, bool STATS>
@@ -313,7 +341,7 @@ static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_s
     const bool want_stats = stats != nullptr || overhead != nullptr;
     const char* lpv_s = getenv("DGCN_LGS_LPV");  // tuning / test knob
     const int lpv_env = lpv_s ? atoi(lpv_s) : 0;
-    int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 64 ? 4 : (b->max_nodes <= 128 ? 2 : 1));
+    int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 512 ? 4 : 1);  // measured: 4 lanes per vertex wins at N ~ 200
 #define DGCN_LGS_CASE(L)                                                      \
     if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs * num_instances, lds, s) \
                                     : launch_lgs<L, false>(a, b->num_graphs * num_instances, lds, s)
