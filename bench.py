@@ -177,7 +177,8 @@ def main():
         dom = max(fam_ms, key=lambda k: fam_ms[k][0])
         ms, n = fam_ms[dom]
         avg_s = ms / n * 1e-3
-        tkey = "%s|%dx%d|l%d" % (dom, args.graphs, args.nodes, args.layers)
+        tkey = ("spmm|%dx%d|C%d" % (args.graphs, args.nodes, args.hidden)) if dom == "spmm" else \
+            "%s|%dx%d|l%d" % (dom, args.graphs, args.nodes, args.layers)
         traffic = traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")
         if dom == "spmm":
             per = spmm_algorithmic_bytes(hb, layers, with_y0=True)
