@@ -77,7 +77,7 @@ struct FusedArgs {
 #define STAMP(a, g, i, t0)                                                                    \
     do {                                                                                      \
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
-        if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(g) * 16 + (i)] += _t - (t0); \
+        if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(g) * 64 + (i)] += _t - (t0); \
         (t0) = _t;                                                                            \
     } while (0)
 #else
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.stamps[(size_t)g * 16 + 12] = hw;
-        a.stamps[(size_t)g * 16 + 13] = xcc;
-        a.stamps[(size_t)g * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[(size_t)g * 64 + 12] = hw;
+        a.stamps[(size_t)g * 64 + 13] = xcc;
+        a.stamps[(size_t)g * 64 + 14] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
@@ -363,14 +363,26 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     for (int l = 0; l < a.num_layers; ++l) {
         const FusedLayer& L = a.layers[l];
         if (L.cout == kHid) {
+#ifdef DGCN_DIAG
+            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB);
             else if (!DIAG_ON(a, 1)) hidden_transform(bfrag, ng, bufA, bufB);
+#ifdef DGCN_DIAG
+            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
             STAMP(a, g, l == 0 ? 3 : 5, tclk);  // transform body (wave 0)
             // fetch the next hidden layer's weights now; they land while this layer gathers
             if (l >= 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
             STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
+#ifdef DGCN_DIAG
+            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (!DIAG_ON(a, 0)) hidden_aggregate(L, ng, bufA, bufB, rinfo, perm, vals, words);
+#ifdef DGCN_DIAG
+            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
             STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
             __syncthreads();
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers

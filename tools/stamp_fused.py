@@ -11,11 +11,11 @@ hb = datagen.er_batch(500, 200, 0.1) if kind == "er" else datagen.ba_test2_batch
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
 for _ in range(3): eng.solve(db, model, mode=MODE_FUSED)
 torch.cuda.synchronize()
-st = torch.zeros(hb.num_graphs * 16, dtype=torch.int64, device="cuda")
+st = torch.zeros(hb.num_graphs * 64, dtype=torch.int64, device="cuda")
 os.environ["DGCN_FUSED_STAMPS"] = str(st.data_ptr())
 eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
 os.environ.pop("DGCN_FUSED_STAMPS")
-s = st.cpu().numpy().reshape(-1, 16).astype(np.float64) / 100.0  # s_memtime ticks at 100 MHz -> us
+s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0  # s_memtime ticks at 100 MHz -> us
 names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
          "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]
 print("phase clocks of wave 0, microseconds: mean over graphs / max")
@@ -23,13 +23,16 @@ for i, n in enumerate(names):
     print("%-24s %8.2f %8.2f" % (n, s[:, i].mean(), s[:, i].max()))
 print("%-24s %8.2f" % ("sum of means", s[:, :12].mean(axis=0).sum()))
 
-raw = st.cpu().numpy().reshape(-1, 16)
-hw = raw[:, 12]; xcc = raw[:, 13] & 0xf
-cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
-ident = (xcc << 16) | (se << 8) | (sh << 4) | cu
-import collections
-groups = collections.defaultdict(list)
-for b, i in enumerate(ident): groups[int(i)].append(b)
-print("distinct (xcc,se,sh,cu):", len(groups), " blocks per CU histogram:", collections.Counter(len(v) for v in groups.values()))
-print("first CUs -> blocks:", [groups[k] for k in sorted(groups)[:10]])
-print("xcc of blocks 0..15:", xcc[:16].tolist())
+raw = st.cpu().numpy().reshape(-1, 64)
+print("timeline of co-resident workgroups (block b and b + 256 share a CU), microseconds from the first stamp;")
+print("per hidden layer: transform start-end | gather start-end")
+for b in (27, 31, 61):
+    if b + 256 >= hb.num_graphs:
+        continue
+    t0 = min(raw[b, 16], raw[b + 256, 16])
+    for blk in (b, b + 256):
+        cells = []
+        for l in range(6):
+            ts = [(raw[blk, 16 + 4 * l + k] - t0) / 100.0 for k in range(4)]
+            cells.append("T %5.1f-%5.1f A %5.1f-%5.1f" % tuple(ts))
+        print("  block %3d: %s" % (blk, " | ".join(cells)))
