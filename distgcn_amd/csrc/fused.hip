@@ -66,6 +66,8 @@ struct FusedArgs {
     int32_t num_layers;
     int32_t max_nodes;
     int32_t meta_cap;
+    int32_t prio_second;
+    int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
     FusedLayer layers[kMaxFusedLayers];
@@ -171,13 +173,23 @@ __device__ __forceinline__ float4 fma4(float a, float4 z, float4 acc) {
     return acc;
 }
 
+// Z1 row chunk at ABSOLUTE LDS byte address `addr` (bufB starts at LDS offset 0).
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+__device__ __forceinline__ float4 lds_chunk(unsigned addr) {
+    const f32x4 z = *reinterpret_cast<lds_cf4*>(addr);
+    return make_float4(z[0], z[1], z[2], z[3]);
+}
+
+// The phase is instruction-ISSUE bound (about 5 cycles per instruction per SIMD with four waves each;
+// neither the random rows, nor the metadata dependency, nor packed FMAs, nor more loads in flight change
+// its time), so the loop is built for few instructions per entry: one xor forms a gather address,
+// two words / two values come with one LDS read, 8 entries per trip.
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
                                                  const unsigned* rinfo, const unsigned short* perm,
                                                  const float* vals, const unsigned short* words) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = lane >> 3, q = lane & 7;
     constexpr int kWaves = kFusedBlock / 64;
-    const char* zb = reinterpret_cast<const char*>(bufB);
     const unsigned qx = (unsigned)q << 4;  // gather address = word ^ qx (the word carries the row's swizzle key)
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.bias) bias = *reinterpret_cast<const float4*>(L.bias + 4 * q);
@@ -190,32 +202,49 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
         const unsigned ri = rinfo[v];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = rs;  // even by construction
-        for (; j + 4 <= re; j += 4) {
-            uint2 w;  // entry lists start at even slots: 4-byte aligned word pairs, 8-byte aligned value pairs
-            w.x = *reinterpret_cast<const unsigned*>(words + j);
-            w.y = *reinterpret_cast<const unsigned*>(words + j + 2);
+        int j = rs;  // even by construction: 4-byte aligned word pairs, 8-byte aligned value pairs
+        for (; j + 8 <= re; j += 8) {
+            unsigned w[4];
+            float2 a2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = *reinterpret_cast<const unsigned*>(words + j + 2 * i);
+                a2[i] = *reinterpret_cast<const float2*>(vals + j + 2 * i);
+            }
+            float4 z[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                z[2 * i] = lds_chunk((w[i] & 0xffffu) ^ qx);
+                z[2 * i + 1] = lds_chunk((w[i] >> 16) ^ qx);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc = fma4(a2[i].x, z[2 * i], acc);
+                acc = fma4(a2[i].y, z[2 * i + 1], acc);
+            }
+        }
+        if (j + 4 <= re) {
+            const unsigned w0 = *reinterpret_cast<const unsigned*>(words + j);
+            const unsigned w1 = *reinterpret_cast<const unsigned*>(words + j + 2);
             const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
             const float2 a23 = *reinterpret_cast<const float2*>(vals + j + 2);
-            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((w.x & 0xffffu) ^ qx));
-            const float4 z1 = *reinterpret_cast<const float4*>(zb + ((w.x >> 16) ^ qx));
-            const float4 z2 = *reinterpret_cast<const float4*>(zb + ((w.y & 0xffffu) ^ qx));
-            const float4 z3 = *reinterpret_cast<const float4*>(zb + ((w.y >> 16) ^ qx));
+            const float4 z0 = lds_chunk((w0 & 0xffffu) ^ qx), z1 = lds_chunk((w0 >> 16) ^ qx);
+            const float4 z2 = lds_chunk((w1 & 0xffffu) ^ qx), z3 = lds_chunk((w1 >> 16) ^ qx);
             acc = fma4(a01.x, z0, acc);
             acc = fma4(a01.y, z1, acc);
             acc = fma4(a23.x, z2, acc);
             acc = fma4(a23.y, z3, acc);
+            j += 4;
         }
         if (j + 2 <= re) {
-            const unsigned w = *reinterpret_cast<const unsigned*>(words + j);
+            const unsigned w0 = *reinterpret_cast<const unsigned*>(words + j);
             const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float4 z0 = *reinterpret_cast<const float4*>(zb + ((w & 0xffffu) ^ qx));
-            const float4 z1 = *reinterpret_cast<const float4*>(zb + ((w >> 16) ^ qx));
+            const float4 z0 = lds_chunk((w0 & 0xffffu) ^ qx), z1 = lds_chunk((w0 >> 16) ^ qx);
             acc = fma4(a01.x, z0, acc);
             acc = fma4(a01.y, z1, acc);
             j += 2;
         }
-        if (j < re) acc = fma4(vals[j], *reinterpret_cast<const float4*>(zb + ((unsigned)words[j] ^ qx)), acc);
+        if (j < re) acc = fma4(vals[j], lds_chunk((unsigned)words[j] ^ qx), acc);
         float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
         const float4 z = *own;
         float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
@@ -225,14 +254,30 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
     }
 }
 
+// Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
+// move the dynamic region - and with it bufB - off byte offset 0).  One barrier inside; the caller must
+// pass another barrier before the next call re-uses the flag words.
+__device__ __forceinline__ bool block_or(bool pred, unsigned* wflags) {
+    const unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = m != 0ull;
+    __syncthreads();
+    unsigned any = 0;
+#pragma unroll
+    for (int w = 0; w < kFusedBlock / 64; ++w) any |= wflags[w];
+    return any != 0;
+}
+
 __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
-    float* bufA = reinterpret_cast<float*>(lds_raw);
-    float* bufB = bufA + (size_t)a.max_nodes * kHid;
-    unsigned* rinfo = reinterpret_cast<unsigned*>(bufB + (size_t)a.max_nodes * kHid);
+    // bufB (Z1) sits at LDS byte offset 0 - the kernel has no static LDS - so a gather address is the
+    // metadata word xor-ed with the lane's chunk offset, with no base to add
+    float* bufB = reinterpret_cast<float*>(lds_raw);
+    float* bufA = bufB + (size_t)a.max_nodes * kHid;
+    unsigned* rinfo = reinterpret_cast<unsigned*>(bufA + (size_t)a.max_nodes * kHid);
+    unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
     float* vals = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     unsigned short* words = reinterpret_cast<unsigned short*>(vals + a.meta_cap);
     unsigned short* perm = words + a.meta_cap;
@@ -243,6 +288,11 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
         return;
     }
+    // Two workgroups share a CU and the hardware favours the older one: measured, the first-dispatched
+    // workgroup ran a layer in ~9.5 us, the second in ~13.5 us, and the launch ends with the slower
+    // half.  Waves of every second dispatch wave (observed placement: block b and b + #CUs share a CU;
+    // speed only, never correctness) raise their issue priority to even the two out.
+    if (a.prio_second && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     unsigned long long tclk = 0;
 #ifdef DGCN_DIAG
     tclk = __builtin_amdgcn_s_memtime();
@@ -438,7 +488,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         bad = (p != p);
         pr[threadIdx.x] = p;
     }
-    if (__syncthreads_or(bad)) {
+    const bool any_bad = block_or(bad != 0, wflags);
+    __syncthreads();  // flag words are re-used by the greedy rounds
+    if (any_bad) {
         if (threadIdx.x == 0) {
             atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
             if (a.rounds) a.rounds[g] = -1;
@@ -491,7 +543,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && mykey < m;
-        if (!__syncthreads_or(live)) break;  // also orders every rank read before the kills below
+        if (!block_or(live, wflags)) break;  // its barrier also orders every rank read before the kills below
         ++rounds;
         if (won) {
             for (int j = rs + sub; j < re; j += lpv) {
@@ -528,7 +580,7 @@ static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_
 static size_t fused_lds_bytes(int max_nodes, int meta_cap) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
     const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
-    return bufs + rinfo + (size_t)meta_cap * 6 + (size_t)max_nodes * 2 + 16;
+    return ((bufs + rinfo + (size_t)meta_cap * 6 + (size_t)max_nodes * 2 + 15) & ~(size_t)15) + 64;  // + block-OR flags
 }
 
 static int fused_shape_ok(const DgcnModel* m) {
@@ -565,12 +617,14 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         a->layers[l].pad = 0;
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap);
+    a->flags_off = (int32_t)(*lds - 64);
     if (*lds > 160 * 1024)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who, *lds);
     return DGCN_OK;
 }
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 1;
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
 #endif
