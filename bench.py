@@ -131,15 +131,36 @@ def main():
     if use_dist and not args.no_gather:
         gather_buf = torch.empty(world * hb.num_nodes, dtype=torch.uint8, device=dev)
 
+    pending = []  # (work handle, tensors it reads) of gathers still in flight
+    ring = [eng.solve_buffers(db, want_scores=False) for _ in range(4)] if mode == MODE_FUSED else None
+    counter = [0]
+
     def step():
-        db.lap = None  # supports are part of the path: rebuild them every step
-        res = eng.solve(db, model, mode=mode)
-        if gather_buf is not None:  # the batch gather of SURVEY 8e (membership only; every rank has equal N)
-            dist.all_gather_into_tensor(gather_buf, res["state"])
+        if ring is not None:
+            # steady-state serving loop: output buffers are re-used (4-deep ring: a buffer is rewritten
+            # only after the gather that reads it has been waited for)
+            counter[0] += 1
+            res = eng.solve_fused(db, model, want_scores=False, out=ring[counter[0] % 4])
+        else:
+            db.lap = None  # supports are part of the path: rebuild them every step
+            res = eng.solve(db, model, mode=mode)
+        if gather_buf is not None:
+            # the batch gather of SURVEY 8e (membership only; every rank has equal N).  Issued async: RCCL
+            # runs it on its own stream behind this step's kernel, so it overlaps the NEXT step's compute
+            # instead of stalling the compute stream for a latency-bound ~100 KB collective.
+            work = dist.all_gather_into_tensor(gather_buf, res["state"], async_op=True)
+            pending.append((work, res["state"]))
+            if len(pending) > 2:
+                pending.pop(0)[0].wait()
         return res
+
+    def drain():
+        while pending:
+            pending.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         res = step()
+    drain()
     torch.cuda.synchronize()
     eng.check_status(res["status"])
 
@@ -150,6 +171,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    drain()  # every gather of the timed steps has completed before the clock stops
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

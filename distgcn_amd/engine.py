@@ -237,19 +237,28 @@ class Engine:
     def solve_supported(self, b: DeviceBatch, model: DeviceModel) -> bool:
         return bool(self.lib.dgcn_solve_supported(C.byref(b.c), C.byref(model.c)))
 
-    def solve_fused(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", X=None, x_const=None,
-                    want_scores: bool = True):
-        """The whole path in one launch (dgcn_solve_batch): adjacency + weights in, membership out."""
+    def solve_buffers(self, b: DeviceBatch, want_scores: bool = True):
+        """Output buffers of ``solve_fused`` for a batch, for callers that re-use them across calls
+        (a steady-state serving loop should not pay five allocations per batch)."""
         t = self.torch
+        n, B = b.host.num_nodes, b.host.num_graphs
+        return {"scores": t.empty((max(n, 1), 1), dtype=t.float32, device=self.device) if want_scores else None,
+                "state": t.empty(max(n, 1), dtype=t.uint8, device=self.device),
+                "rounds": t.empty(max(B, 1), dtype=t.int32, device=self.device),
+                "totals": t.empty(max(B, 1), dtype=t.float64, device=self.device),
+                "status": t.zeros(1, dtype=t.int32, device=self.device)}
+
+    def solve_fused(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", X=None, x_const=None,
+                    want_scores: bool = True, out=None):
+        """The whole path in one launch (dgcn_solve_batch): adjacency + weights in, membership out.
+        ``out`` = buffers from ``solve_buffers`` to re-use (its status word accumulates faults)."""
         n, B = b.host.num_nodes, b.host.num_graphs
         if x_const is None:
             x_const = float(np.float32(1.0 / model.in_dim))
         tab = self._dinv(b.host.max_degree)
-        scores = t.empty((max(n, 1), 1), dtype=t.float32, device=self.device) if want_scores else None
-        state = t.empty(max(n, 1), dtype=t.uint8, device=self.device)
-        rounds = t.empty(max(B, 1), dtype=t.int32, device=self.device)
-        totals = t.empty(max(B, 1), dtype=t.float64, device=self.device)
-        status = t.zeros(1, dtype=t.int32, device=self.device)
+        if out is None:
+            out = self.solve_buffers(b, want_scores)
+        scores, state, rounds, totals, status = out["scores"], out["state"], out["rounds"], out["totals"], out["status"]
         p = lambda x: x.data_ptr() if x is not None else None
         _lib.check(self.lib.dgcn_solve_batch(C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X),
                                              x_const, p(b.weights), 1 if predict == "mwis" else 0, p(scores),
