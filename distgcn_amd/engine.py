@@ -224,9 +224,16 @@ class Engine:
             raise ValueError("batch has no vertex weights")
         if model.out_dim != 1:
             raise _lib.DgcnError("solve() needs a model with one output per node (diver_num=1)")
+        status = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+        if b.host.num_nodes == 0:  # nothing but empty graphs: rounds 0, totals 0 (heuristics.py loops do not run)
+            t = self.torch
+            B = b.host.num_graphs
+            return {"state": t.empty(0, dtype=t.uint8, device=self.device),
+                    "rounds": t.zeros(B, dtype=t.int32, device=self.device),
+                    "totals": t.zeros(B, dtype=t.float64, device=self.device), "status": status,
+                    "scores": t.empty((0, 1), dtype=t.float32, device=self.device), "stats": None, "overhead": None}
         if mode == MODE_FUSED:
             return self.solve_fused(b, model, predict=predict, X=X, x_const=x_const)
-        status = self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
         self.supports(b, status=status)  # no host sync on the path: faults surface through res["status"]
         scores = self.forward(b, model, X=X, x_const=x_const, mode=mode)
         res = self.lgs(b, scores=scores, weights=b.weights if predict == "mwis" else None, sum_weights=b.weights,

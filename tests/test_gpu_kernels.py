@@ -308,3 +308,45 @@ def test_argmax(engine, golden):
     got = engine.argmax(db, _dev(engine, s)).cpu().numpy()
     for g, (n0, n1) in enumerate(hb.graph_slices()):
         assert got[g] == int(np.argmax(s[n0:n1, 0]))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_solve_edge_case_batch(engine, mode):
+    """Ragged batch: an empty graph, a single vertex, an edgeless graph, a path, a 512-vertex sparse graph
+    (the fused kernel's size limit) and a star whose hub has degree 300 - sets and scores vs the CPU twin."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    rng = np.random.default_rng(11)
+    adjs = [sp.csr_matrix((0, 0)), sp.csr_matrix((1, 1)), sp.csr_matrix((7, 7))]
+    path = sp.diags([np.ones(9), np.ones(9)], [1, -1], shape=(10, 10)).tocsr()
+    adjs.append(path)
+    big = sp.random(512, 512, density=0.004, random_state=3, format="csr")
+    big = ((big + big.T) > 0).astype(float)
+    big.setdiag(0)
+    big.eliminate_zeros()
+    adjs.append(sp.csr_matrix(big))
+    star = sp.lil_matrix((301, 301))
+    star[0, 1:] = 1
+    star[1:, 0] = 1
+    adjs.append(sp.csr_matrix(star))
+    wts = [rng.random(a.shape[0]) for a in adjs]
+    hb = HostBatch.from_scipy(adjs, wts)
+    layers = datagen.random_model(5, 32, seed=4)
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    if mode == 1:
+        assert engine.solve_supported(db, dm)
+    res = engine.solve(db, dm, mode=mode)
+    engine.check_status(res["status"])
+    ref = ctwin.solve(hb, layers)
+    assert np.array_equal(res["scores"].cpu().numpy().view(np.uint32), ref["scores"].view(np.uint32))
+    assert np.array_equal(res["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(res["rounds"].cpu().numpy(), ref["rounds"])
+    assert res["rounds"].cpu().numpy()[0] == 0 and res["totals"].cpu().numpy()[0] == 0.0
+    # all-empty batch: nothing to do, nothing launched
+    empty = HostBatch.from_scipy([sp.csr_matrix((0, 0))], [np.zeros(0)])
+    r2 = engine.solve(engine.upload(empty), dm, mode=mode)
+    assert r2["state"].numel() == 0
