@@ -68,6 +68,12 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t prio_second;
     int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS
+    // residual-graph variant (k_fused<true>): `state` is in/out, vertices with state != 0 are not part of the graph
+    int32_t feature_mode;  // 1: X[v][*] = (float)(w[v] / (max residual w + 1e-9)), computed here
+    int32_t greedy_mode;   // 0 local greedy rounds, 1 one centralised step (global best joins), 2 one rollout step
+    int32_t max_rounds;    // greedy_mode 0: stop after this many rounds (0 = until every vertex is decided)
+    int32_t beam;          // greedy_mode 2: number of candidates
+    int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
     FusedLayer layers[kMaxFusedLayers];
@@ -98,7 +104,7 @@ __device__ __forceinline__ int swzB(int row, int col) {  // bufB: chunk index ^ 
 
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
 __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const FusedLayer& L, int n0, int ng,
-                                                      float* bufA, float* bufB) {
+                                                      float* bufA, float* bufB, float xfill) {
     const int cin = L.cin, ctot = 2 * L.cout;  // cout == kHid here
     for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
         for (int c0 = 0; c0 < ctot; c0 += 16) {
@@ -106,7 +112,7 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             for (int k = 0; k < cin; ++k) {
-                const float x = a.X ? a.X[(size_t)(n0 + v) * cin + k] : a.x_const;
+                const float x = a.X ? a.X[(size_t)(n0 + v) * cin + k] : xfill;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = fmaf(x, L.W[k * ctot + c0 + i], acc[i]);
             }
@@ -267,6 +273,80 @@ __device__ __forceinline__ bool block_or(bool pred, unsigned* wflags) {
     return any != 0;
 }
 
+// One wave turns the entry-count histogram into start offsets of a descending counting sort (lane i owns
+// bins 9i..9i+8, suffix-scanned with shuffles).
+__device__ __forceinline__ void hist_to_offsets(int* hist) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int loc[9], sum = 0;
+#pragma unroll
+        for (int i = 8; i >= 0; --i) { loc[i] = sum; sum += hist[lane * 9 + i]; }  // within-lane suffix (higher bins first)
+        int above = sum;  // inclusive suffix over lanes >= lane, then made exclusive
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(above, off);
+            if (lane + off < 64) above += t;
+        }
+        above -= sum;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hist[lane * 9 + i] = above + loc[i];
+    }
+}
+
+// Greedy rounds over the rank keys in LDS (residual-graph variant).  A live vertex wins a round iff its
+// rank is below every live neighbour's (`central`: iff it holds rank 0 - the global best); winners get
+// mark[v] = 1, their live neighbours mark[u] = kill_mark (when non-zero), both leave the graph.
+// Returns the number of rounds run.  The caller passes a barrier before and after.
+__device__ __forceinline__ int greedy_rounds(unsigned short* key, uint8_t* mark, int kill_mark,
+                                             const unsigned short* words, int rs, int re, int vv, int sub, int lpv,
+                                             bool mine, unsigned* wflags, int max_rounds, bool central) {
+    constexpr unsigned kDead = 0xFFFFu;
+    int rounds = 0;
+    while (true) {
+        const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
+        const bool live = mykey != kDead;
+        unsigned m = kDead;
+        if (live && !central) {
+            for (int j = rs + sub; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                const unsigned k = key[u];
+                if (u != vv) m = min(m, k);
+            }
+        }
+        for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
+        const bool won = live && (central ? mykey == 0u : mykey < m);
+        if (!block_or(live, wflags)) break;  // its barrier also orders every rank read before the kills below
+        ++rounds;
+        if (won) {
+            for (int j = rs + sub; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                if (u != vv && key[u] != kDead) {
+                    key[u] = (unsigned short)kDead;
+                    if (kill_mark) mark[u] = (uint8_t)kill_mark;
+                }
+            }
+            if (sub == 0) { key[vv] = (unsigned short)kDead; mark[vv] = 1; }
+        }
+        __syncthreads();
+        if (central || (max_rounds > 0 && rounds >= max_rounds)) break;
+    }
+    return rounds;
+}
+
+// Block-wide sum of one double per thread, fixed tree order; result valid on every thread.
+__device__ __forceinline__ double block_sum(double part, double* red) {
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int off = kFusedBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+template <bool MASKED>
 __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int g = blockIdx.x;
@@ -320,6 +400,102 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     double* dinv = reinterpret_cast<double*>(bufB);  // scratch until the first transform
     int* rowstart = reinterpret_cast<int*>(bufA);    // [ng + 1], scratch until the first transform
     int* hist = reinterpret_cast<int*>(dinv + a.max_nodes);  // [576] entry-count histogram (bufB: 128 B per row)
+    float xfill = a.x_const;   // first-layer input when X is null
+    bool was_alive = true;     // vertex threadIdx.x is part of the (residual) graph
+    if constexpr (MASKED) {
+        // Residual graph: rows and entries of removed vertices (state != 0) are dropped while the image is
+        // built, so everything after P0 runs unchanged on the induced subgraph - the reference re-slices
+        // the SciPy matrix instead (mwis_gdpg_call.py:284-285).  Row-parallel (8 lanes per row) because
+        // an entry's slot depends on how many earlier entries of its row survive.
+        uint8_t* al = reinterpret_cast<uint8_t*>(rowstart + 520);              // [512] 1 = in the residual graph
+        unsigned short* acount = reinterpret_cast<unsigned short*>(al + 512);  // [512] surviving neighbours
+        double* wred = reinterpret_cast<double*>(hist + 576);                  // per-wave partial maxima
+        const int tv0 = threadIdx.x;
+        was_alive = tv0 < ng && a.state[n0 + tv0] == 0;
+        const double w0 = (tv0 < ng && a.weights) ? a.weights[n0 + tv0] : 1.0;
+        if (tv0 < ng) al[tv0] = was_alive;
+        for (int i = threadIdx.x; i < 576; i += kFusedBlock) hist[i] = 0;
+        // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286)
+        if (!block_or(was_alive && w0 > 0.0, wflags)) {
+            if (a.scores && tv0 < ng) a.scores[n0 + tv0] = 0.f;
+            if (threadIdx.x == 0) {
+                if (a.rounds) a.rounds[g] = 0;
+                if (a.totals) a.totals[g] = 0.0;
+            }
+            return;
+        }
+        if (a.feature_mode == 1) {
+            double mx = was_alive ? w0 : -1.0 / 0.0;
+            for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+            if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mx;
+        }
+        __syncthreads();
+        if (a.feature_mode == 1) {
+            double mx = wred[0];
+#pragma unroll
+            for (int w = 1; w < kFusedBlock / 64; ++w) mx = fmax(mx, wred[w]);
+            xfill = was_alive ? (float)(w0 / (mx + 1e-9)) : 0.f;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = lane >> 3, q = lane & 7;
+        for (int vb = wave * 8; vb < ng; vb += kFusedBlock / 8) {
+            const int v = vb + gw;
+            int cnt = 0;
+            if (v < ng && al[v]) {
+                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+                for (int j = rs + q; j < re; j += 8) {
+                    const int u = a.col_idx[j] - n0;
+                    if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
+                    else {
+                        if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                        cnt += al[u];
+                    }
+                }
+            }
+            cnt += __shfl_xor(cnt, 1);
+            cnt += __shfl_xor(cnt, 2);
+            cnt += __shfl_xor(cnt, 4);
+            if (q == 0 && v < ng) acount[v] = (unsigned short)cnt;
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+            const int rs = a.row_ptr[n0 + v];
+            const int start = ((rs - e0) + 2 * v + 1) & ~1;  // the full row's slots stay reserved
+            const int deg = acount[v];
+            const int cnt = al[v] ? deg + 1 : 0;
+            rinfo[v] = (unsigned)start | ((unsigned)cnt << 16);
+            atomicAdd(&hist[min(cnt, 575)], 1);
+            double d = 0.0;
+            if (deg < a.table_len) d = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+            dinv[v] = d;
+            if (al[v]) { words[start] = enc_word(v); vals[start] = 1.0f; }
+        }
+        __syncthreads();
+        hist_to_offsets(hist);
+        for (int vb = wave * 8; vb < ng; vb += kFusedBlock / 8) {
+            const int v = vb + gw;
+            const bool act = v < ng && al[v];
+            const int rs = act ? a.row_ptr[n0 + v] : 0, re = act ? a.row_ptr[n0 + v + 1] : 0;
+            const int start = act ? (int)(rinfo[v] & 0xffff) : 0;
+            int base = 1;  // slot 0 of the row is the diagonal
+            for (int j0 = rs; __any(j0 < re); j0 += 8) {
+                const int j = j0 + q;
+                int u = j < re ? a.col_idx[j] - n0 : -1;
+                const bool keep = u >= 0 && u < ng && al[u];
+                const unsigned bits = (unsigned)(__ballot(keep) >> (gw * 8)) & 0xffu;
+                if (keep) {
+                    const int slot = start + base + __popc(bits & ((1u << q) - 1u));
+                    words[slot] = enc_word(u);
+                    vals[slot] = (float)(-(dinv[u] * dinv[v]));
+                }
+                base += __popc(bits);
+            }
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+            const int c = min((int)(rinfo[v] >> 16), 575);
+            perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
+        }
+    } else {
     for (int i = threadIdx.x; i < 576; i += kFusedBlock) hist[i] = 0;
     __syncthreads();
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
@@ -343,21 +519,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     // Row order for the gather phase: counting sort by entry count, descending.  One wave turns the
     // histogram into start offsets (lane i owns bins 9i..9i+8, suffix-scanned with shuffles); the order
     // among equal counts is arbitrary - it only decides which rows share a lockstep pass.
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int loc[9], sum = 0;
-#pragma unroll
-        for (int i = 8; i >= 0; --i) { loc[i] = sum; sum += hist[lane * 9 + i]; }  // within-lane suffix (higher bins first)
-        int above = sum;  // inclusive suffix over lanes >= lane, then made exclusive
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_down(above, off);
-            if (lane + off < 64) above += t;
-        }
-        above -= sum;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) hist[lane * 9 + i] = above + loc[i];
-    }
+    hist_to_offsets(hist);
     __syncthreads();
     STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
@@ -403,6 +565,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
         }
     }
+    }
     __syncthreads();  // scratch (bufA, bufB) is dead from here on
     STAMP(a, g, 2, tclk);  // P0c: row order
 
@@ -416,7 +579,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB);
+            if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB, xfill);
             else if (!DIAG_ON(a, 1)) hidden_transform(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -444,7 +607,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             if (v < ng) {
                 for (int k = 0; k < L.cin; ++k) {
                     float h;
-                    if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : a.x_const;
+                    if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : xfill;
                     else h = bufA[swz(v, k)];
                     z0 = fmaf(h, L.W[k * 2 + 0], z0);
                     z1 = fmaf(h, L.W[k * 2 + 1], z1);
@@ -460,7 +623,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
                 float o = z0 + acc;
                 if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
-                if (a.scores) a.scores[n0 + v] = score;
+                if (a.scores) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -476,6 +639,135 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     // (priority desc, index asc) once; a removed vertex gets rank 0xFFFF.  A round is then: every
     // live vertex takes the minimum rank over its adjacency (one LDS read per neighbour), wins iff
     // its own rank is smaller; winners join and kill their neighbours.  lpv lanes share a vertex.
+    if constexpr (MASKED) {
+        // Residual-graph variant: ranks are taken among the remaining vertices only, removed ones keep
+        // their state byte, and one launch is one step of an iterative solver:
+        //   greedy_mode 0  `max_rounds` local-greedy rounds   (solve_mwis_dit, mwis_gdpg_call.py:278-318)
+        //   greedy_mode 1  the global best joins              (solve_mwis_cit, :343-384)
+        //   greedy_mode 2  top-`beam` candidates, each completed greedily by weight; the best total joins
+        //                  (solve_mwis_rollout, :596-659)
+        double* pr = reinterpret_cast<double*>(bufB);
+        double* red = pr + a.max_nodes;          // [kFusedBlock]
+        double* wl = red + kFusedBlock;          // [max_nodes] vertex weights (rollout totals)
+        unsigned short* key = reinterpret_cast<unsigned short*>(bufA);
+        unsigned short* gkey = key + a.max_nodes;   // GCN-priority ranks (rollout candidates)
+        unsigned short* wkey = gkey + a.max_nodes;  // weight ranks (rollout completions)
+        uint8_t* st = reinterpret_cast<uint8_t*>(wkey + a.max_nodes);
+        uint8_t* jn = st + a.max_nodes;             // joined flags of one rollout completion
+        int* pick = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(bufA) + ((8 * a.max_nodes + 15) & ~15));  // [4]
+        double* cand = reinterpret_cast<double*>(pick + 4);                               // [64] candidate totals
+        constexpr unsigned kDead = 0xFFFFu;
+        const int tv = threadIdx.x;
+        int bad = 0;
+        double wmine = 0.0;
+        if (tv < ng) {
+            double p = (double)score;
+            wmine = a.weights ? a.weights[n0 + tv] : 0.0;
+            if (a.predict_mwis && a.weights) p *= wmine;
+            bad = was_alive && (p != p);
+            pr[tv] = p;
+            wl[tv] = wmine;
+            st[tv] = was_alive ? 0 : a.state[n0 + tv];
+        }
+        const bool any_bad = block_or(bad != 0, wflags);
+        __syncthreads();
+        if (any_bad) {
+            if (threadIdx.x == 0) {
+                atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+                if (a.rounds) a.rounds[g] = -1;
+                if (a.totals) a.totals[g] = 0.0;
+            }
+            return;
+        }
+        int lsh = 0;
+        while (lsh < 3 && (ng << (lsh + 1)) <= kFusedBlock) ++lsh;
+        const int lpv = 1 << lsh;
+        const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
+        const bool mine = vv < ng;
+        {
+            int cnt = 0, cntw = 0;
+            const bool alive_v = mine && st[vv] == 0;
+            if (alive_v) {
+                const double pvv = pr[vv], wvv = wl[vv];
+                for (int w = sub; w < ng; w += lpv) {
+                    if (st[w] != 0) continue;
+                    const double pw = pr[w];
+                    cnt += (pw > pvv) || (pw == pvv && w < vv);
+                    if (a.greedy_mode == 2) {
+                        const double ww = wl[w];
+                        cntw += (ww > wvv) || (ww == wvv && w < vv);
+                    }
+                }
+            }
+            for (int off = 1; off < lpv; off <<= 1) { cnt += __shfl_xor(cnt, off); cntw += __shfl_xor(cntw, off); }
+            if (mine && sub == 0) {
+                key[vv] = alive_v ? (unsigned short)cnt : (unsigned short)kDead;
+                gkey[vv] = key[vv];
+                wkey[vv] = alive_v ? (unsigned short)cntw : (unsigned short)kDead;
+            }
+        }
+        __syncthreads();
+        const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
+        int rounds = 0;
+        if (a.greedy_mode != 2) {
+            rounds = greedy_rounds(key, st, 2, words, rs, re, vv, sub, lpv, mine, wflags, a.max_rounds, a.greedy_mode == 1);
+        } else {
+            // candidates in GCN-priority order (stable argsort of -priority = the rank keys)
+            int nc = 0;
+            for (int i = 0; i < a.beam && i < 64; ++i) {
+                if (threadIdx.x == 0) pick[0] = -1;
+                __syncthreads();
+                if (tv < ng && gkey[tv] == (unsigned short)i) pick[0] = tv;
+                __syncthreads();
+                const int c = pick[0];
+                if (c < 0) break;  // fewer remaining vertices than candidates
+                ++nc;
+                // the residual graph minus the candidate's closed neighbourhood, ranked by weight
+                if (tv < ng) { key[tv] = wkey[tv]; jn[tv] = 0; }
+                __syncthreads();
+                {
+                    const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
+                    for (int j = crs + tv; j < cre; j += kFusedBlock) key[words[j] >> 7] = (unsigned short)kDead;  // diagonal entry: c itself
+                }
+                __syncthreads();
+                greedy_rounds(key, jn, 0, words, rs, re, vv, sub, lpv, mine, wflags, 0, false);
+                const double tot = block_sum((tv < ng && jn[tv] == 1) ? wl[tv] : 0.0, red);
+                if (threadIdx.x == 0) cand[i] = wl[c] + tot;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                // np.isclose(cand, cand.max(), rtol=1e-12, atol=0): the first candidate within tolerance wins
+                double mx = cand[0];
+                for (int i = 1; i < nc; ++i) mx = fmax(mx, cand[i]);
+                int best = 0;
+                for (int i = 0; i < nc; ++i)
+                    if (fabs(cand[i] - mx) <= 1e-12 * fabs(mx)) { best = i; break; }
+                pick[1] = best;
+            }
+            __syncthreads();
+            const int best = pick[1];
+            if (tv < ng && gkey[tv] == (unsigned short)best) pick[0] = tv;
+            __syncthreads();
+            const int c = pick[0];
+            const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
+            for (int j = crs + tv; j < cre; j += kFusedBlock) {
+                const int u = words[j] >> 7;
+                st[u] = (u == c) ? 1 : 2;
+            }
+            rounds = 1;
+            __syncthreads();
+        }
+        if (tv < ng && was_alive) a.state[n0 + tv] = st[tv];
+        if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+        if (threadIdx.x == 0 && a.progress) atomicAdd(a.progress, 1);
+        if (a.totals) {
+            double part = 0.0;
+            if (tv < ng && was_alive && st[tv] == 1) part = a.weights ? wl[tv] : pr[tv];
+            const double tot = block_sum(part, red);
+            if (threadIdx.x == 0) a.totals[g] = tot;
+        }
+        if (fault) atomicOr(a.status, fault);
+    } else {
     double* pr = reinterpret_cast<double*>(bufB);
     double* red = pr + a.max_nodes;  // [kFusedBlock] slots; bufB has 128 B per row and max_nodes >= 64 rows
     unsigned short* key = reinterpret_cast<unsigned short*>(bufA);
@@ -571,6 +863,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     }
     if (fault) atomicOr(a.status, fault);
     STAMP(a, g, 11, tclk);  // totals, output
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -623,7 +916,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     return DGCN_OK;
 }
 
-static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked = false) {
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 1;
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
@@ -632,13 +925,14 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
+    const void* fn = masked ? reinterpret_cast<const void*>(&k_fused<true>) : reinterpret_cast<const void*>(&k_fused<false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t(family, s);
-    hipLaunchKernelGGL(k_fused, dim3(B), dim3(kFusedBlock), lds, s, a);
+    if (masked) hipLaunchKernelGGL(k_fused<true>, dim3(B), dim3(kFusedBlock), lds, s, a);
+    else hipLaunchKernelGGL(k_fused<false>, dim3(B), dim3(kFusedBlock), lds, s, a);
     return check_launch("k_fused");
 }
 
@@ -703,4 +997,48 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch");
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream);
+}
+
+extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
+                                         int32_t table_len, const float* X, float x_const, int32_t feature_mode,
+                                         const double* weights, int32_t predict_mwis, int32_t greedy_mode,
+                                         int32_t max_rounds, int32_t beam, float* scores, uint8_t* state,
+                                         int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
+                                         void* stream) {
+    if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
+        return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: null argument");
+    if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_residual_batch: only [I, L] supports");
+    if (greedy_mode < 0 || greedy_mode > 2) return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: greedy_mode %d", greedy_mode);
+    if (greedy_mode == 2 && (beam < 1 || beam > 64 || !weights))
+        return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: rollout needs weights and 1 <= beam <= 64");
+    if (feature_mode == 1 && (!weights || X))
+        return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: feature_mode 1 derives X from the weights");
+    if (b->num_graphs <= 0) return DGCN_OK;
+    FusedArgs args = {};
+    args.row_ptr = b->row_ptr;
+    args.col_idx = b->col_idx;
+    args.vals = nullptr;
+    args.dinv_table = dinv_table;
+    args.table_len = table_len;
+    args.from_adj = 1;
+    args.meta_cap = fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes);
+    args.X = X;
+    args.x_const = x_const;
+    args.feature_mode = feature_mode;
+    args.scores = scores;
+    args.weights = weights;
+    args.predict_mwis = predict_mwis;
+    args.do_lgs = 1;
+    args.greedy_mode = greedy_mode;
+    args.max_rounds = max_rounds;
+    args.beam = beam;
+    args.state = state;
+    args.rounds = rounds;
+    args.totals = totals;
+    args.progress = progress;
+    args.status = status;
+    size_t lds = 0;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch");
+    if (rc) return rc;
+    return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true);
 }

@@ -274,6 +274,40 @@ class Engine:
         return {"state": state[:n], "rounds": rounds[:B], "totals": totals[:B], "status": status,
                 "scores": None if scores is None else scores[:n], "stats": None, "overhead": None}
 
+    GREEDY_ROUNDS, GREEDY_CENTRAL, GREEDY_ROLLOUT = 0, 1, 2
+
+    def solve_residual(self, b: DeviceBatch, model: DeviceModel, state, predict: str = "mwis", greedy: int = 0,
+                       max_rounds: int = 0, beam: int = 16, X=None, x_const=None, weight_features: bool = False,
+                       want_scores: bool = False, max_steps: Optional[int] = None, out=None):
+        """Iterative solvers on the device (dgcn_solve_residual_batch): repeat one launch per step on the
+        residual graphs until no graph makes progress.  ``state`` (uint8 [num_nodes], 0 = undecided) is
+        updated in place.  greedy = GREEDY_ROUNDS with max_rounds=1 is solve_mwis_dit, GREEDY_CENTRAL is
+        solve_mwis_cit, GREEDY_ROLLOUT is solve_mwis_rollout (mwis_gdpg_call.py:278-318, 343-384, 596-659)
+        for every graph of the batch at once.  -> {"state", "steps", "status", "scores" (last step)}"""
+        t = self.torch
+        n, B = b.host.num_nodes, b.host.num_graphs
+        if x_const is None:
+            x_const = float(np.float32(1.0 / model.in_dim))
+        tab = self._dinv(b.host.max_degree)
+        if out is None:
+            out = self.solve_buffers(b, want_scores)
+        progress = t.zeros(1, dtype=t.int32, device=self.device)
+        p = lambda x: x.data_ptr() if x is not None else None
+        steps = 0
+        limit = max_steps if max_steps is not None else max(b.host.max_nodes, 1) + 1
+        while n > 0 and steps < limit:
+            progress.zero_()
+            _lib.check(self.lib.dgcn_solve_residual_batch(
+                C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
+                1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
+                int(max_rounds), int(beam), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
+                progress.data_ptr(), out["status"].data_ptr(), self._stream()), "dgcn_solve_residual_batch")
+            if int(progress.item()) == 0:
+                break
+            steps += 1
+        return {"state": state, "steps": steps, "status": out["status"],
+                "scores": None if out["scores"] is None else out["scores"][:n]}
+
     # ------------------------------------------------------------------ timing hooks (bench.py)
     def timing(self, on: bool):
         """on=True clears earlier records and starts recording; on=False stops (records stay readable)."""

@@ -93,8 +93,10 @@ class MWISSolver(object):
 
 
     # ---- iterative solvers on the same kernels ------------------------------
-    # Residual graphs are re-sliced on the host exactly as the reference does (SciPy); every
-    # forward pass, greedy round and rollout completion runs on the device.
+    # Shapes the fused kernel handles run entirely on the device (solve_iterative_batch: the residual
+    # graph is a mask applied while the LDS image is built).  Other shapes re-slice the residual graph
+    # on the host exactly as the reference does (SciPy) and run every forward pass, greedy round and
+    # rollout completion on the device.
     def _residual_scores(self, adj_nn, wts_nn):
         """(DeviceBatch, device scores [n,1]) of one residual graph: ``makestate`` + ``act``."""
         eng = get_engine()
@@ -122,9 +124,42 @@ class MWISSolver(object):
         act_vals = scores.cpu().numpy().flatten()
         return act_vals * wts_nn.flatten() if self.flags.predict == "mwis" else act_vals.astype(np.float64)
 
+    # ---- device-resident variants: the residual graph is masked inside the fused kernel
+    device_iterative = True  # False: always re-slice on the host (the path for shapes outside the fused kernel)
+
+    def solve_iterative_batch(self, adjs: Sequence, wts_list: Sequence, which: str = "dit", b: int = 16):
+        """``solve_mwis_dit`` / ``_cit`` / ``_rollout`` for many graphs at once, one launch per step for the
+        whole batch (``Engine.solve_residual``); None when the shapes are outside the fused kernel."""
+        import torch
+        csrs = [as_csr(a) for a in adjs]
+        hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs],
+                                      [c.indices.astype(np.int64) for c in csrs],
+                                      [np.asarray(w, dtype=np.float64).reshape(-1, self.feature_size)[:, 0] for w in wts_list])
+        eng = get_engine()
+        db = eng.upload(hb)
+        dm = self.model.device_model(eng)
+        if hb.num_nodes == 0 or not eng.solve_supported(db, dm) or (which == "rollout" and not 1 <= b <= 64):
+            return None
+        greedy = {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL, "rollout": eng.GREEDY_ROLLOUT}[which]
+        state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
+        res = eng.solve_residual(db, dm, state, predict=self.flags.predict, greedy=greedy, max_rounds=1, beam=b,
+                                 weight_features=self.flags.predict != "mwis")
+        eng.check_status(res["status"])
+        st = res["state"].cpu().numpy()
+        out = []
+        for n0, n1 in hb.graph_slices():
+            sel = np.flatnonzero(st[n0:n1] == 1)
+            # np.dot(nIS_vec, wts) with undecided vertices (only left when no positive weight remains) at -1
+            nis = np.where(st[n0:n1] == 1, 1.0, np.where(st[n0:n1] == 0, -1.0, 0.0))
+            out.append((set(int(i) for i in sel), np.dot(nis, hb.weights[n0:n1].reshape(-1, 1))))
+        return out
+
     def solve_mwis_dit(self, adj_0, wts_0, train=False, grd=1.0):
         """GCN embedded into the greedy iteration (``mwis_gdpg_call.py:278-318``): scores are
         recomputed on the residual graph before every round.  -> (mwis, best_IS_util)"""
+        dev = self.solve_iterative_batch([adj_0], [wts_0], "dit") if self.device_iterative else None
+        if dev is not None:
+            return dev[0]
         adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
         best = np.array([0.0])
         while np.sum(nIS_vec == -1) > 0:
@@ -143,6 +178,9 @@ class MWISSolver(object):
 
     def solve_mwis_cit(self, adj_0, wts_0, train=False, grd=1.0):
         """GCN + centralised argmax, one vertex per step (``mwis_gdpg_call.py:343-384``)."""
+        dev = self.solve_iterative_batch([adj_0], [wts_0], "cit") if self.device_iterative else None
+        if dev is not None:
+            return dev[0]
         adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
         best = np.array([0.0])
         while np.sum(nIS_vec == -1) > 0:
@@ -164,6 +202,10 @@ class MWISSolver(object):
         (unseeded) and ranks with an unstable sort: here ties go to the first candidate / lower index
         unless ``rng`` (a ``numpy.random.Generator``) is given."""
         import torch
+        if rng is None and self.device_iterative:
+            dev = self.solve_iterative_batch([adj_0], [wts_0], "rollout", b=b)
+            if dev is not None:
+                return dev[0]
         adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
         best = np.array([0.0])
         while np.sum(nIS_vec == -1) > 0:

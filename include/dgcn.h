@@ -178,6 +178,31 @@ int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const doubl
                      const float* X, float x_const, const double* weights, int32_t predict_mwis,
                      float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* stream);
 
+/* ---- F1/F2: one step of the iterative solvers on the RESIDUAL graph, batched, in one launch ------
+ * mwis_gdpg_call.py:278-318 (solve_mwis_dit), :343-384 (solve_mwis_cit), :596-659 (solve_mwis_rollout)
+ * re-slice the SciPy matrix to the undecided vertices before every GCN pass.  Here `state` (uint8 per
+ * vertex, in/out) plays nIS_vec: 0 = undecided (in the residual graph), 1 = in the set, 2 = excluded;
+ * vertices with state != 0 are dropped while the LDS image is built, so the forward pass runs on the
+ * induced subgraph with its own degrees, exactly as the re-sliced matrix would.
+ *   greedy_mode 0: `max_rounds` local-greedy rounds by priority (0 = until all decided); dit uses 1
+ *   greedy_mode 1: the best-priority vertex joins (np.argmax: lowest index among equals)
+ *   greedy_mode 2: the first `beam` (<= 64) vertices by priority are candidates; each is completed by
+ *                  a local greedy search by weight on the residual graph minus its closed
+ *                  neighbourhood; the candidate with the largest weight + completion total joins
+ *                  (totals within 1e-12 relative count as tied: first candidate wins)
+ * feature_mode 0: X / x_const as in dgcn_solve_batch (X rows of removed vertices are ignored);
+ * feature_mode 1: every feature of vertex v is (float)(w[v] / (max residual w + 1e-9)) (X must be NULL).
+ * A graph with no undecided vertex, or no positive weight left (np.sum(wts_nn) <= 0 -> break), is left
+ * untouched; otherwise *progress += 1.  The caller repeats the launch until *progress stays 0.
+ * rounds[g]: rounds run by this launch; totals[g]: weight (or priority) of the vertices that joined in
+ * THIS launch; scores: residual-graph scores (0 for removed vertices).  Same shape limits as
+ * dgcn_solve_batch. */
+int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table,
+                              int32_t table_len, const float* X, float x_const, int32_t feature_mode,
+                              const double* weights, int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds,
+                              int32_t beam, float* scores, uint8_t* state, int32_t* rounds, double* totals,
+                              int32_t* progress, int32_t* status, void* stream);
+
 /* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
  * enable(1) makes every launch of the named kernel families record an event pair;
  * read() synchronises those events and returns the summed milliseconds and launch count. */
