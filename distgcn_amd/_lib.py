@@ -25,7 +25,7 @@ FAULT_NAMES = {
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
     "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
-    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_batch", "dgcn_solve_residual_batch",
+    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
 
@@ -103,11 +103,13 @@ def load():
     lib.dgcn_solve_supported.restype = C.c_int
     lib.dgcn_solve_supported.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel)]
     lib.dgcn_solve_batch.restype = C.c_int
+    lib.dgcn_solve_workspace.restype = C.c_size_t
+    lib.dgcn_solve_workspace.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel)]
     lib.dgcn_solve_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), vp, i32, vp, f32, vp, i32,
-                                     vp, vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.dgcn_solve_residual_batch.restype = C.c_int
     lib.dgcn_solve_residual_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), vp, i32, vp, f32, i32, vp, i32,
-                                              i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+                                              i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.dgcn_timing_enable.restype = C.c_int
     lib.dgcn_timing_enable.argtypes = [i32]
     lib.dgcn_timing_reset.restype = C.c_int

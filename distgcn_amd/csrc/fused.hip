@@ -50,6 +50,7 @@ struct FusedArgs {
     const int32_t* row_ptr;
     const int32_t* col_idx;
     const float* vals;         // values of the given support CSR; unused when from_adj
+    float* gvals;              // k_fused<*, true>: [num_graphs][meta_cap] entry values kept in global memory
     const double* dinv_table;  // from_adj: float64 d^-1/2 table
     int32_t table_len;
     int32_t from_adj;          // CSR is the adjacency: build L (diagonal first) on the fly
@@ -346,7 +347,10 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
     return r;
 }
 
-template <bool MASKED>
+// GVALS: graphs whose full image exceeds the LDS keep the entry VALUES (4 of the 6 metadata bytes per
+// entry) in a global scratch slice (L2-resident, read as broadcast float2 per 8-lane group); hidden
+// states, gather words, row table and row order stay in LDS.  Same arithmetic, slower gathers.
+template <bool MASKED, bool GVALS>
 __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int g = blockIdx.x;
@@ -358,8 +362,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     float* bufA = bufB + (size_t)a.max_nodes * kHid;
     unsigned* rinfo = reinterpret_cast<unsigned*>(bufA + (size_t)a.max_nodes * kHid);
     unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
-    float* vals = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
-    unsigned short* words = reinterpret_cast<unsigned short*>(vals + a.meta_cap);
+    float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
+    float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
+    unsigned short* words = reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
     unsigned short* perm = words + a.meta_cap;
     if (ng <= 0) {
         if (threadIdx.x == 0 && a.do_lgs) {
@@ -870,10 +875,19 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
 // entry slots: the entries themselves plus at most one padding slot per row (even row starts)
 static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 3) & ~3; }
 
-static size_t fused_lds_bytes(int max_nodes, int meta_cap) {
+static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
     const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
-    return ((bufs + rinfo + (size_t)meta_cap * 6 + (size_t)max_nodes * 2 + 15) & ~(size_t)15) + 64;  // + block-OR flags
+    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 2 + 15) & ~(size_t)15) + 64;  // + block-OR flags
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// 0: everything in LDS; 1: entry values in global scratch; -1: the image does not fit either way
+static int fused_variant(int max_nodes, int meta_cap) {
+    if (fused_lds_bytes(max_nodes, meta_cap, false) <= kLdsLimit) return 0;
+    if (fused_lds_bytes(max_nodes, meta_cap, true) <= kLdsLimit) return 1;
+    return -1;
 }
 
 static int fused_shape_ok(const DgcnModel* m) {
@@ -891,7 +905,8 @@ static int fused_shape_ok(const DgcnModel* m) {
 }
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
-static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who) {
+static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
+                         void* workspace, size_t workspace_bytes, bool* gvals) {
     if (!fused_shape_ok(m))
         return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->32->...->32->1 layer stacks only", who);
     if (b->max_nodes > kFusedBlock)
@@ -909,14 +924,36 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         a->layers[l].act = L.act;
         a->layers[l].pad = 0;
     }
-    *lds = fused_lds_bytes(a->max_nodes, a->meta_cap);
+    const int variant = fused_variant(a->max_nodes, a->meta_cap);
+    if (variant < 0)
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who,
+                    fused_lds_bytes(a->max_nodes, a->meta_cap, true));
+    *gvals = variant == 1;
+    if (*gvals) {
+        const size_t need = (size_t)b->num_graphs * a->meta_cap * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry values of large graphs), got %zu", who,
+                        need, workspace ? workspace_bytes : (size_t)0);
+        a->gvals = static_cast<float*>(workspace);
+    }
+    *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
     a->flags_off = (int32_t)(*lds - 64);
-    if (*lds > 160 * 1024)
-        return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who, *lds);
     return DGCN_OK;
 }
 
-static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked = false) {
+template <bool MASKED, bool GVALS>
+static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+    }
+    TimedLaunch t(family, s);
+    hipLaunchKernelGGL((k_fused<MASKED, GVALS>), dim3(B), dim3(kFusedBlock), lds, s, a);
+    return check_launch("k_fused");
+}
+
+static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 1;
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
@@ -925,21 +962,23 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
-    const void* fn = masked ? reinterpret_cast<const void*>(&k_fused<true>) : reinterpret_cast<const void*>(&k_fused<false>);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
-    }
-    TimedLaunch t(family, s);
-    if (masked) hipLaunchKernelGGL(k_fused<true>, dim3(B), dim3(kFusedBlock), lds, s, a);
-    else hipLaunchKernelGGL(k_fused<false>, dim3(B), dim3(kFusedBlock), lds, s, a);
-    return check_launch("k_fused");
+    if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
+    return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
 }
 
-size_t fused_workspace(const DgcnBatch*, const DgcnModel*) { return 256; }  // everything lives in LDS
+// bytes of global scratch the fused kernel needs for this batch: a token amount when every image fits
+// the LDS, otherwise one float per entry slot
+static size_t fused_scratch(const DgcnBatch* b, int meta_cap) {
+    if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) return (size_t)b->num_graphs * meta_cap * sizeof(float);
+    return 256;
+}
+
+size_t fused_workspace(const DgcnBatch* b, const DgcnModel*) {
+    return fused_scratch(b, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
+}
 
 int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
-                  float* scores, void*, size_t, hipStream_t s) {
+                  float* scores, void* workspace, size_t workspace_bytes, hipStream_t s) {
     FusedArgs args = {};
     args.row_ptr = lap->row_ptr;
     args.col_idx = lap->col_idx;
@@ -951,9 +990,10 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     args.scores = scores;
     args.do_lgs = 0;
     size_t lds = 0;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)");
+    bool gvals = false;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)", workspace, workspace_bytes, &gvals);
     if (rc) return rc;
-    return fused_launch(args, b->num_graphs, lds, "fused_forward", s);
+    return fused_launch(args, b->num_graphs, lds, "fused_forward", s, false, gvals);
 }
 
 }  // namespace dgcn
@@ -964,13 +1004,18 @@ extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m || !m->layers_host || m->num_supports != 2) return 0;
     if (!fused_shape_ok(m) || b->max_nodes > kFusedBlock) return 0;
     const int cap = fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes);
-    return fused_lds_bytes(max(b->max_nodes, 64), cap) <= 160 * 1024;
+    return fused_variant(max(b->max_nodes, 64), cap) >= 0;
+}
+
+extern "C" size_t dgcn_solve_workspace(const DgcnBatch* b, const DgcnModel* m) {
+    if (!b || !m) return 0;
+    return fused_scratch(b, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
 }
 
 extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len,
                                 const float* X, float x_const, const double* weights, int32_t predict_mwis,
                                 float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status,
-                                void* stream) {
+                                void* workspace, size_t workspace_bytes, void* stream) {
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
@@ -994,9 +1039,10 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     args.totals = totals;
     args.status = status;
     size_t lds = 0;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch");
+    bool gvals = false;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch", workspace, workspace_bytes, &gvals);
     if (rc) return rc;
-    return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream);
+    return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream, false, gvals);
 }
 
 extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
@@ -1004,7 +1050,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
                                          const double* weights, int32_t predict_mwis, int32_t greedy_mode,
                                          int32_t max_rounds, int32_t beam, float* scores, uint8_t* state,
                                          int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
-                                         void* stream) {
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_residual_batch: only [I, L] supports");
@@ -1038,7 +1084,8 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.progress = progress;
     args.status = status;
     size_t lds = 0;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch");
+    bool gvals = false;
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals);
     if (rc) return rc;
-    return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true);
+    return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals);
 }

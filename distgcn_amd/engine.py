@@ -267,9 +267,12 @@ class Engine:
             out = self.solve_buffers(b, want_scores)
         scores, state, rounds, totals, status = out["scores"], out["state"], out["rounds"], out["totals"], out["status"]
         p = lambda x: x.data_ptr() if x is not None else None
+        need = int(self.lib.dgcn_solve_workspace(C.byref(b.c), C.byref(model.c)))
+        ws = self._workspace(need)
         _lib.check(self.lib.dgcn_solve_batch(C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X),
                                              x_const, p(b.weights), 1 if predict == "mwis" else 0, p(scores),
-                                             p(state), p(rounds), p(totals), p(status), self._stream()),
+                                             p(state), p(rounds), p(totals), p(status), ws.data_ptr(), need,
+                                             self._stream()),
                    "dgcn_solve_batch")
         return {"state": state[:n], "rounds": rounds[:B], "totals": totals[:B], "status": status,
                 "scores": None if scores is None else scores[:n], "stats": None, "overhead": None}
@@ -293,6 +296,8 @@ class Engine:
             out = self.solve_buffers(b, want_scores)
         progress = t.zeros(1, dtype=t.int32, device=self.device)
         p = lambda x: x.data_ptr() if x is not None else None
+        need = int(self.lib.dgcn_solve_workspace(C.byref(b.c), C.byref(model.c)))
+        ws = self._workspace(need)
         steps = 0
         limit = max_steps if max_steps is not None else max(b.host.max_nodes, 1) + 1
         while n > 0 and steps < limit:
@@ -301,7 +306,8 @@ class Engine:
                 C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
                 1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
                 int(max_rounds), int(beam), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
-                progress.data_ptr(), out["status"].data_ptr(), self._stream()), "dgcn_solve_residual_batch")
+                progress.data_ptr(), out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
+                "dgcn_solve_residual_batch")
             if int(progress.item()) == 0:
                 break
             steps += 1

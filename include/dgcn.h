@@ -169,14 +169,20 @@ int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t pr
  * construction (gcn/utils.py:120-127) through every layer (gcn/models.py:536-573) to the greedy
  * rounds (heuristics.py:77-116).  Same arithmetic contract as the separate entry points, so scores
  * and sets are bit-identical to supports -> forward(mode 0) -> lgs.
- * Handles F->32->..->32->1 layer stacks on graphs of <= 512 vertices whose image fits the LDS;
+ * Handles F->32->..->32->1 layer stacks on graphs of <= 512 vertices whose image (with the entry values
+ * in LDS or, for larger graphs, in the global scratch) fits the LDS;
  * dgcn_solve_supported() tells (1/0) so the caller can route other shapes through the separate calls.
  * scores (float[num_nodes]), rounds, totals may be NULL.  weights NULL or predict_mwis = 0: the
  * priority is the score itself (mwis_dqn_call.py:234). */
 int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
+/* Bytes of device scratch dgcn_solve_batch / dgcn_solve_residual_batch need for this batch.  Graphs whose
+ * whole image fits the LDS need a token amount; larger ones (e.g. 500 vertices, 5 000 edges) keep their
+ * entry values in this scratch (one float per entry slot) and only states + gather words in LDS. */
+size_t dgcn_solve_workspace(const DgcnBatch* batch, const DgcnModel* model);
 int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table, int32_t table_len,
                      const float* X, float x_const, const double* weights, int32_t predict_mwis,
-                     float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* stream);
+                     float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- F1/F2: one step of the iterative solvers on the RESIDUAL graph, batched, in one launch ------
  * mwis_gdpg_call.py:278-318 (solve_mwis_dit), :343-384 (solve_mwis_cit), :596-659 (solve_mwis_rollout)
@@ -201,7 +207,8 @@ int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, co
                               int32_t table_len, const float* X, float x_const, int32_t feature_mode,
                               const double* weights, int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds,
                               int32_t beam, float* scores, uint8_t* state, int32_t* rounds, double* totals,
-                              int32_t* progress, int32_t* status, void* stream);
+                              int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
  * enable(1) makes every launch of the named kernel families record an event pair;

@@ -365,16 +365,45 @@ def test_residual_weight_features(engine, golden, which):
             assert res[True][0] == want[0]
 
 
+@pytest.mark.parametrize("family", ["er", "ba"])
+def test_c5_rollout_n500(engine, family):
+    """BASELINE config 5: GCN-guided tree search + 1-step rollout (b=16) on N=500 conflict graphs
+    (stand-ins ER G(500, 0.02) and BA(500, 5)), solved on the device, against the oracle."""
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    rng = np.random.default_rng(20230605)
+    if family == "er":
+        indptr, indices = datagen.er_graph(500, 0.02, rng)
+    else:
+        indptr, indices = datagen.ba_graph(500, 5, rng)
+    w = rng.random(500)
+    import scipy.sparse as sp
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(500, 500))
+    agent = DQNAgent(_flags(num_layer=3), seed=21)
+    fn = _twin_scores_fn(agent.model.layers)
+    got = agent.solve_iterative_batch([adj], [w], "rollout", b=16)
+    assert got is not None  # ran through dgcn_solve_residual_batch
+    want = orc.solve_mwis_rollout(fn, adj, w, b=16)
+    assert got[0][0] == want[0]
+    assert np.allclose(got[0][1], want[1], rtol=1e-12)
+    # independent set, maximal
+    sel = np.zeros(500, bool); sel[list(got[0][0])] = True
+    assert not (adj[sel][:, sel]).nnz
+    assert np.all((adj @ sel.astype(np.float64) > 0) | sel)
+
+
 def test_large_graph_takes_layered_path(engine):
     """Graphs beyond the fused kernel's 512 vertices / 160 KB image run layer by layer, same results."""
     from distgcn_amd import datagen
     from distgcn_amd.engine import DeviceModel
     from distgcn_amd.mwis_dqn_call import DQNAgent, solve_host_batch
     from oracle import ctwin
-    for n, p in ((600, 0.01), (500, 0.02)):
+    for n, p, fused in ((600, 0.01, False), (500, 0.1, False), (500, 0.02, True)):
         hb = datagen.er_batch(3, n, p)
         agent = DQNAgent(1, flags=_flags(num_layer=4))
-        assert not engine.solve_supported(engine.upload(hb), DeviceModel(agent.model.layers, engine.device))
+        # N=500 with ~5 000 edges fits the fused kernel with its entry values in global scratch
+        assert engine.solve_supported(engine.upload(hb), DeviceModel(agent.model.layers, engine.device)) == fused
         res = solve_host_batch(engine, agent.model, hb)
         ref = ctwin.solve(hb, agent.model.layers)
         assert np.array_equal(res["state"], ref["state"])
