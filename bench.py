@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--mode", choices=["layered", "fused", "auto"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-cpu-pool", action="store_true", help="skip the all-cores CPU figure (forked workers)")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step membership gather at N>1")
     ap.add_argument("--no-spmm-probe", action="store_true", help="skip the stand-alone SpMM kernel measurement")
     return ap.parse_args()
@@ -91,6 +92,31 @@ def cpu_baseline(hb, layers, budget_s):
             "sample": "%d graph solves over rank 0's %d-graph batch, %.1f s, python oracle/ref_numpy.solve_mwis_gdpg"
                       % (done, hb.num_graphs, dt),
             "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_all_cores(args, seconds):
+    """SURVEY 8d's generous figure: the same restatement in one forked worker per host core
+    (oracle/cpu_pool.py, a child process that never touches the GPU).  None if it cannot run."""
+    import subprocess
+    try:
+        procs = len(os.sched_getaffinity(0))
+    except AttributeError:
+        procs = os.cpu_count() or 1
+    procs = max(1, min(procs, 128))
+    models = os.path.join(ROOT, "tests", "golden", "models.npz")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_pool.py"), str(min(args.graphs, 64)), str(args.nodes),
+           str(args.p), str(args.layers), str(args.hidden), str(seconds), str(procs), models]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=seconds * 4 + 60)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": "graphs/s", "cores": d["cores"],
+                "effective_cores": round(d.get("effective_cores", 0.0), 1),
+                "sample": "%d graph solves in %d forked workers, %.1f s each; effective_cores = CPU-seconds per "
+                          "second the workers were given" % (d["solves"], d["cores"], seconds)}
+    except Exception as e:  # a reported extra; never fails the bench
+        return {"value": None, "error": repr(e)[:200]}
 
 
 def main():
@@ -283,6 +309,8 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(hb, layers, args.cpu_seconds)
+            if not args.no_cpu_pool:
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args, min(args.cpu_seconds, 6.0))
         else:
             out["cpu_baseline"] = None
         # RCCL writes a version banner to the C stdout buffer; push it out first so that the JSON
