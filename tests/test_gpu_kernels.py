@@ -350,3 +350,38 @@ def test_solve_edge_case_batch(engine, mode):
     empty = HostBatch.from_scipy([sp.csr_matrix((0, 0))], [np.zeros(0)])
     r2 = engine.solve(engine.upload(empty), dm, mode=mode)
     assert r2["state"].numel() == 0
+
+
+def test_every_shipped_checkpoint(engine, golden, all_models):
+    """All 44 shipped cheb1 checkpoints (hidden 1..64, F in {1, 2, 16, 32}, 1..20 layers) through the product
+    path the agents use (fused when the shape allows, layer-by-layer otherwise): scores bit-equal to the twin
+    and within tolerance of the float64 oracle, sets equal to the oracle greedy run on the same priorities and
+    - unless near-ties reorder priorities - to the reference's own local_greedy_search on the restatement."""
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin, ref_numpy as orc
+    hb = golden.host_batch(all_models.graph_ids)
+    db = engine.upload(hb)
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    fused, same_as_reference, total = 0, 0, 0
+    for name in all_models.names:
+        layers, meta = all_models.layers(name), all_models.meta(name)
+        dm = DeviceModel(layers, engine.device)
+        mode = 1 if engine.solve_supported(db, dm) else 0
+        fused += mode
+        res = engine.solve(db, dm, predict=meta["predict"], mode=mode)
+        engine.check_status(res["status"])
+        got = res["scores"].cpu().numpy().reshape(-1)
+        state = res["state"].cpu().numpy()
+        twin = ctwin.forward(lap, layers, hb.num_nodes)[:, 0]
+        assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), name
+        prio = got.astype(np.float64) * hb.weights if meta["predict"] == "mwis" else got.astype(np.float64)
+        for gi, (n0, n1) in zip(all_models.graph_ids, hb.graph_slices()):
+            f64, f32 = all_models.expect(gi, name, "f64"), all_models.expect(gi, name, "f32")
+            assert np.abs(got[n0:n1] - f64).max() <= max(TOL, 2.0 * np.abs(f32 - f64).max()), (name, gi)
+            p, c, _ = golden.csr(gi)
+            st, _ = orc.lgs_vectorised(p, c, prio[n0:n1])
+            assert np.array_equal(state[n0:n1] == 1, st == 1), (name, gi)
+            total += 1
+            same_as_reference += set(np.flatnonzero(state[n0:n1] == 1)) == set(all_models.expect(gi, name, "set").tolist())
+    assert fused >= 10  # the c32 stacks take the fused kernel
+    assert same_as_reference >= total - 2, (same_as_reference, total)

@@ -170,3 +170,25 @@ def test_reference_import_agrees_when_available(golden):
     a = ref_u.simple_polynomials(adj, 1)[1]
     b = orc.simple_polynomials(adj, 1)[1]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_twin_on_every_shipped_checkpoint(golden, all_models):
+    """The C twin (kernel operation order) against the NumPy restatement on all 44 shipped cheb1 models:
+    hidden widths 1..64, input widths 1/2/16/32, 1..20 layers, two with a bias."""
+    from oracle import ctwin
+    from distgcn_amd.batch import HostBatch
+    assert len(all_models.names) == 44
+    seen_widths = set()
+    for gi in all_models.graph_ids:
+        hb = golden.host_batch([gi])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        for name in all_models.names:
+            layers = all_models.layers(name)
+            meta = all_models.meta(name)
+            assert layers[0]["weights"][0].shape[0] == meta["feature_size"] and len(layers) == meta["num_layer"]
+            seen_widths.add(meta["hidden"])
+            got = ctwin.forward(lap, layers, hb.num_nodes)[:, 0]
+            f64, f32 = all_models.expect(gi, name, "f64"), all_models.expect(gi, name, "f32")
+            bar = max(1e-5, 2.0 * np.abs(f32 - f64).max())
+            assert np.abs(got - f64).max() <= bar, (name, gi)
+    assert {1, 2, 3, 4, 8, 16, 32, 48, 64} <= seen_widths
