@@ -897,32 +897,94 @@ static int fused_shape_ok(const DgcnModel* m) {
         const DgcnLayer& L = m->layers_host[l];
         const bool last = l == Lc - 1;
         if (last) { if (L.out_dim != 1) return 0; }
-        else if (L.out_dim != kHid) return 0;
-        if (l > 0 && L.in_dim != kHid) return 0;
+        else if (L.out_dim < 1 || L.out_dim > kHid) return 0;
+        if (l > 0 && L.in_dim != m->layers_host[l - 1].out_dim) return 0;
         if (l == 0 && L.in_dim > 64) return 0;
     }
     return 1;
 }
 
+// ---- hidden widths below 32 --------------------------------------------------------------------
+// k_fused is written for 32-wide hidden states.  A narrower stack runs as a 32-wide one whose extra weight
+// rows / columns (and biases) are zero: the extra features are exactly 0 in every layer and the extra chain
+// terms are fmaf(0, 0, acc) = acc, so the real features keep their bits.  k_pad_model writes the padded
+// copies into the caller's workspace (one tiny launch per call; nothing is cached between calls).
+constexpr size_t kPadLayerFloats = 64 * 64 + 64;  // [in <= 64][2 * 32] weights + 32 bias (+ slack), per layer
+
+struct PadArgs {
+    int32_t num_layers;
+    float* out;  // [num_layers][kPadLayerFloats]
+    struct { const float* W; const float* bias; int32_t in, out; } src[kMaxFusedLayers];
+};
+
+__global__ void k_pad_model(PadArgs a) {
+    const int l = blockIdx.x;
+    const bool last = l == a.num_layers - 1;
+    const int in = a.src[l].in, out = a.src[l].out;
+    const int in_p = l == 0 ? in : kHid, out_p = last ? 1 : kHid;
+    float* W = a.out + (size_t)l * kPadLayerFloats;
+    float* bias = W + 64 * 64;
+    for (int i = threadIdx.x; i < in_p * 2 * out_p; i += blockDim.x) {
+        const int k = i / (2 * out_p), j = i % (2 * out_p);
+        const int half = j / out_p, c = j % out_p;
+        W[i] = (k < in && c < out) ? a.src[l].W[k * 2 * out + half * out + c] : 0.f;
+    }
+    for (int c = threadIdx.x; c < kHid; c += blockDim.x) bias[c] = (a.src[l].bias && c < out) ? a.src[l].bias[c] : 0.f;
+}
+
+static bool fused_needs_padding(const DgcnModel* m) {
+    for (int l = 0; l + 1 < m->num_layers; ++l)
+        if (m->layers_host[l].out_dim != kHid) return true;
+    return false;
+}
+
+static size_t fused_pad_bytes(const DgcnModel* m) {
+    return fused_needs_padding(m) ? (size_t)m->num_layers * kPadLayerFloats * sizeof(float) : 0;
+}
+
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
-                         void* workspace, size_t workspace_bytes, bool* gvals) {
+                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream) {
     if (!fused_shape_ok(m))
-        return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->32->...->32->1 layer stacks only", who);
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 only", who);
     if (b->max_nodes > kFusedBlock)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: graphs of %d vertices exceed the fused kernel's %d", who, b->max_nodes,
                     kFusedBlock);
     a->graph_ptr = b->graph_ptr;
     a->max_nodes = max(b->max_nodes, 64);  // >= 64 rows: the greedy phase re-uses bufB for priorities + reduction
     a->num_layers = m->num_layers;
+    const size_t pad_bytes = fused_pad_bytes(m);
+    if (pad_bytes && (!workspace || workspace_bytes < pad_bytes))
+        return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (zero-padded weights), got %zu", who, pad_bytes,
+                    workspace ? workspace_bytes : (size_t)0);
+    float* padded = static_cast<float*>(workspace);  // the padded model sits first in the workspace
     for (int l = 0; l < m->num_layers; ++l) {
         const DgcnLayer& L = m->layers_host[l];
-        a->layers[l].W = L.weights;
-        a->layers[l].bias = L.bias;
-        a->layers[l].cin = L.in_dim;
-        a->layers[l].cout = L.out_dim;
+        const bool last = l == m->num_layers - 1;
+        a->layers[l].W = pad_bytes ? padded + (size_t)l * kPadLayerFloats : L.weights;
+        a->layers[l].bias = pad_bytes ? (L.bias ? padded + (size_t)l * kPadLayerFloats + 64 * 64 : nullptr) : L.bias;
+        a->layers[l].cin = (pad_bytes && l > 0) ? kHid : L.in_dim;
+        a->layers[l].cout = (pad_bytes && !last) ? kHid : L.out_dim;
         a->layers[l].act = L.act;
         a->layers[l].pad = 0;
+    }
+    if (pad_bytes) {
+        PadArgs pa = {};
+        pa.num_layers = m->num_layers;
+        pa.out = padded;
+        for (int l = 0; l < m->num_layers; ++l) {
+            const DgcnLayer& L = m->layers_host[l];
+            pa.src[l].W = L.weights;
+            pa.src[l].bias = L.bias;
+            pa.src[l].in = L.in_dim;
+            pa.src[l].out = L.out_dim;
+        }
+        TimedLaunch t("fused_pad", stream);
+        hipLaunchKernelGGL(k_pad_model, dim3(m->num_layers), dim3(256), 0, stream, pa);
+        int rc = check_launch("k_pad_model");
+        if (rc) return rc;
+        workspace = static_cast<char*>(workspace) + pad_bytes;
+        workspace_bytes -= pad_bytes;
     }
     const int variant = fused_variant(a->max_nodes, a->meta_cap);
     if (variant < 0)
@@ -968,13 +1030,14 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
 
 // bytes of global scratch the fused kernel needs for this batch: a token amount when every image fits
 // the LDS, otherwise one float per entry slot
-static size_t fused_scratch(const DgcnBatch* b, int meta_cap) {
-    if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) return (size_t)b->num_graphs * meta_cap * sizeof(float);
-    return 256;
+static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap) {
+    size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
+    if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
+    return need ? need : 256;
 }
 
-size_t fused_workspace(const DgcnBatch* b, const DgcnModel*) {
-    return fused_scratch(b, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
+size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m) {
+    return fused_scratch(b, m, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
 }
 
 int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
@@ -991,7 +1054,7 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     args.do_lgs = 0;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)", workspace, workspace_bytes, &gvals);
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)", workspace, workspace_bytes, &gvals, s);
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_forward", s, false, gvals);
 }
@@ -1009,7 +1072,7 @@ extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
 
 extern "C" size_t dgcn_solve_workspace(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m) return 0;
-    return fused_scratch(b, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
+    return fused_scratch(b, m, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
 }
 
 extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len,
@@ -1040,7 +1103,7 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     args.status = status;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch", workspace, workspace_bytes, &gvals);
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream);
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream, false, gvals);
 }
@@ -1085,7 +1148,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.status = status;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals);
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream);
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals);
 }

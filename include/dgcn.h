@@ -169,7 +169,8 @@ int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t pr
  * construction (gcn/utils.py:120-127) through every layer (gcn/models.py:536-573) to the greedy
  * rounds (heuristics.py:77-116).  Same arithmetic contract as the separate entry points, so scores
  * and sets are bit-identical to supports -> forward(mode 0) -> lgs.
- * Handles F->32->..->32->1 layer stacks on graphs of <= 512 vertices whose image (with the entry values
+ * Handles F->c->..->c->1 layer stacks with hidden widths c <= 32 (narrower than 32: computed 32 wide with
+ * zero weights, which leaves the real features' bits unchanged) on graphs of <= 512 vertices whose image (with the entry values
  * in LDS or, for larger graphs, in the global scratch) fits the LDS;
  * dgcn_solve_supported() tells (1/0) so the caller can route other shapes through the separate calls.
  * scores (float[num_nodes]), rounds, totals may be NULL.  weights NULL or predict_mwis = 0: the

@@ -120,16 +120,10 @@ def test_forward_golden_models(engine, golden, mode):
     hb = golden.host_batch()
     db = engine.upload(hb)
     lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
-    from distgcn_amd._lib import DgcnError
     ran = 0
     for mname in golden.model_names:
         layers = golden.layers(mname)
-        try:
-            got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
-        except DgcnError as e:
-            # the fused kernel covers F->32->..->32->1 stacks; other widths must say so loudly
-            assert mode == 1 and "fused kernel handles" in str(e) and "_c16_l4_" in mname, (mname, str(e))
-            continue
+        got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
         ran += 1
         twin = ctwin.forward(lap, layers, hb.num_nodes)
         assert np.array_equal(got.view(np.uint32), twin.view(np.uint32)), mname
@@ -138,7 +132,23 @@ def test_forward_golden_models(engine, golden, mode):
             f32 = golden.scores["g%02d|%s|f32" % (i, mname)]
             bar = max(TOL, 2.0 * np.abs(f32 - f64).max())
             assert np.abs(got[n0:n1, 0] - f64).max() <= bar, (mname, golden.names[i])
-    assert ran >= len(golden.model_names) - 1
+    assert ran == len(golden.model_names)
+
+
+def test_fused_rejects_wide_hidden_loudly(engine, golden, all_models):
+    """The fused kernel covers hidden widths <= 32 (narrower ones run zero-padded); 48 / 64 must say so."""
+    from distgcn_amd._lib import DgcnError
+    from distgcn_amd.engine import DeviceModel
+    db = engine.upload(golden.host_batch([0]))
+    for name in all_models.names:
+        layers = all_models.layers(name)
+        dm = DeviceModel(layers, engine.device)
+        # (the checkpoint named ld32_c32_l2 really holds a 48-wide hidden layer)
+        ok = all(lyr["weights"][0].shape[1] <= 32 for lyr in layers[:-1])
+        assert engine.solve_supported(db, dm) == ok, name
+        if not ok:
+            with pytest.raises(DgcnError, match="fused kernel handles"):
+                engine.forward(db, dm, mode=1)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -383,5 +393,5 @@ def test_every_shipped_checkpoint(engine, golden, all_models):
             assert np.array_equal(state[n0:n1] == 1, st == 1), (name, gi)
             total += 1
             same_as_reference += set(np.flatnonzero(state[n0:n1] == 1)) == set(all_models.expect(gi, name, "set").tolist())
-    assert fused >= 10  # the c32 stacks take the fused kernel
+    assert fused >= 37  # every stack whose hidden width is <= 32 takes the fused kernel
     assert same_as_reference >= total - 2, (same_as_reference, total)
