@@ -34,7 +34,9 @@
 namespace dgcn {
 
 constexpr int kMaxFusedLayers = 64;
-constexpr int kFusedBlock = 512;
+constexpr int kFusedBlock = 512;      // threads per workgroup when two or more graphs share a CU
+constexpr int kFusedBlockBig = 1024;  // ... when one graph's image takes more than half the LDS (it has the CU to itself)
+constexpr int kFusedMaxNodes = 512;
 constexpr int kHid = 32;  // hidden width of the LDS image
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -104,10 +106,11 @@ __device__ __forceinline__ int swzB(int row, int col) {  // bufB: chunk index ^ 
 }
 
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
+template <int BLOCK>
 __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const FusedLayer& L, int n0, int ng,
                                                       float* bufA, float* bufB, float xfill) {
     const int cin = L.cin, ctot = 2 * L.cout;  // cout == kHid here
-    for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
         for (int c0 = 0; c0 < ctot; c0 += 16) {
             float acc[16];
 #pragma unroll
@@ -140,10 +143,11 @@ __device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4]) {
         for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
 }
 
+template <int BLOCK>
 __device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    constexpr int kWaves = kFusedBlock / 64;
+    constexpr int kWaves = BLOCK / 64;
     const int tiles = (ng + 15) >> 4;
     for (int t = wave; t < tiles; t += kWaves) {
         const int row = t * 16 + r;
@@ -191,12 +195,13 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 // neither the random rows, nor the metadata dependency, nor packed FMAs, nor more loads in flight change
 // its time), so the loop is built for few instructions per entry: one xor forms a gather address,
 // two words / two values come with one LDS read, 8 entries per trip.
+template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
                                                  const unsigned* rinfo, const unsigned short* perm,
                                                  const float* vals, const unsigned short* words) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = lane >> 3, q = lane & 7;
-    constexpr int kWaves = kFusedBlock / 64;
+    constexpr int kWaves = BLOCK / 64;
     const unsigned qx = (unsigned)q << 4;  // gather address = word ^ qx (the word carries the row's swizzle key)
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.bias) bias = *reinterpret_cast<const float4*>(L.bias + 4 * q);
@@ -264,13 +269,14 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
 // move the dynamic region - and with it bufB - off byte offset 0).  One barrier inside; the caller must
 // pass another barrier before the next call re-uses the flag words.
+template <int BLOCK>
 __device__ __forceinline__ bool block_or(bool pred, unsigned* wflags) {
     const unsigned long long m = __ballot(pred);
     if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = m != 0ull;
     __syncthreads();
     unsigned any = 0;
 #pragma unroll
-    for (int w = 0; w < kFusedBlock / 64; ++w) any |= wflags[w];
+    for (int w = 0; w < BLOCK / 64; ++w) any |= wflags[w];
     return any != 0;
 }
 
@@ -298,6 +304,7 @@ __device__ __forceinline__ void hist_to_offsets(int* hist) {
 // rank is below every live neighbour's (`central`: iff it holds rank 0 - the global best); winners get
 // mark[v] = 1, their live neighbours mark[u] = kill_mark (when non-zero), both leave the graph.
 // Returns the number of rounds run.  The caller passes a barrier before and after.
+template <int BLOCK>
 __device__ __forceinline__ int greedy_rounds(unsigned short* key, uint8_t* mark, int kill_mark,
                                              const unsigned short* words, int rs, int re, int vv, int sub, int lpv,
                                              bool mine, unsigned* wflags, int max_rounds, bool central) {
@@ -316,7 +323,7 @@ __device__ __forceinline__ int greedy_rounds(unsigned short* key, uint8_t* mark,
         }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && (central ? mykey == 0u : mykey < m);
-        if (!block_or(live, wflags)) break;  // its barrier also orders every rank read before the kills below
+        if (!block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every rank read before the kills below
         ++rounds;
         if (won) {
             for (int j = rs + sub; j < re; j += lpv) {
@@ -335,10 +342,11 @@ __device__ __forceinline__ int greedy_rounds(unsigned short* key, uint8_t* mark,
 }
 
 // Block-wide sum of one double per thread, fixed tree order; result valid on every thread.
+template <int BLOCK>
 __device__ __forceinline__ double block_sum(double part, double* red) {
     red[threadIdx.x] = part;
     __syncthreads();
-    for (int off = kFusedBlock / 2; off > 0; off >>= 1) {
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
@@ -350,8 +358,8 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
 // GVALS: graphs whose full image exceeds the LDS keep the entry VALUES (4 of the 6 metadata bytes per
 // entry) in a global scratch slice (L2-resident, read as broadcast float2 per 8-lane group); hidden
 // states, gather words, row table and row order stay in LDS.  Same arithmetic, slower gathers.
-template <bool MASKED, bool GVALS>
-__global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
+template <bool MASKED, bool GVALS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
@@ -419,9 +427,9 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         was_alive = tv0 < ng && a.state[n0 + tv0] == 0;
         const double w0 = (tv0 < ng && a.weights) ? a.weights[n0 + tv0] : 1.0;
         if (tv0 < ng) al[tv0] = was_alive;
-        for (int i = threadIdx.x; i < 576; i += kFusedBlock) hist[i] = 0;
+        for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
         // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286)
-        if (!block_or(was_alive && w0 > 0.0, wflags)) {
+        if (!block_or<BLOCK>(was_alive && w0 > 0.0, wflags)) {
             if (a.scores && tv0 < ng) a.scores[n0 + tv0] = 0.f;
             if (threadIdx.x == 0) {
                 if (a.rounds) a.rounds[g] = 0;
@@ -438,11 +446,11 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         if (a.feature_mode == 1) {
             double mx = wred[0];
 #pragma unroll
-            for (int w = 1; w < kFusedBlock / 64; ++w) mx = fmax(mx, wred[w]);
+            for (int w = 1; w < BLOCK / 64; ++w) mx = fmax(mx, wred[w]);
             xfill = was_alive ? (float)(w0 / (mx + 1e-9)) : 0.f;
         }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = lane >> 3, q = lane & 7;
-        for (int vb = wave * 8; vb < ng; vb += kFusedBlock / 8) {
+        for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
             const int v = vb + gw;
             int cnt = 0;
             if (v < ng && al[v]) {
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             if (q == 0 && v < ng) acount[v] = (unsigned short)cnt;
         }
         __syncthreads();
-        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int rs = a.row_ptr[n0 + v];
             const int start = ((rs - e0) + 2 * v + 1) & ~1;  // the full row's slots stay reserved
             const int deg = acount[v];
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
         __syncthreads();
         hist_to_offsets(hist);
-        for (int vb = wave * 8; vb < ng; vb += kFusedBlock / 8) {
+        for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
             const int v = vb + gw;
             const bool act = v < ng && al[v];
             const int rs = act ? a.row_ptr[n0 + v] : 0, re = act ? a.row_ptr[n0 + v + 1] : 0;
@@ -496,15 +504,15 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             }
         }
         __syncthreads();
-        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
             perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
         }
     } else {
-    for (int i = threadIdx.x; i < 576; i += kFusedBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
     __syncthreads();
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
-    for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
         const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
         const int start = ((rs - e0) + v * extra + v + 1) & ~1;
         rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
@@ -529,12 +537,12 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
     STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
         const int total = e1 - e0;
-        for (int base = threadIdx.x; base < total; base += kFusedBlock * 4) {
+        for (int base = threadIdx.x; base < total; base += BLOCK * 4) {
             int c[4];
             float gv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int j = base + i * kFusedBlock;
+                const int j = base + i * BLOCK;
                 c[i] = 0;
                 gv[i] = 0.f;
                 if (j < total) {
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int j = base + i * kFusedBlock;
+                const int j = base + i * BLOCK;
                 if (j >= total) continue;
                 int lo = 0, hi = ng;  // last row whose start is <= j
                 while (hi - lo > 1) {
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             }
         }
         STAMP(a, g, 1, tclk);  // P0b: entries
-        for (int v = threadIdx.x; v < ng; v += kFusedBlock) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
             perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
         }
@@ -584,8 +592,8 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (l == 0) first_layer_transform(a, L, n0, ng, bufA, bufB, xfill);
-            else if (!DIAG_ON(a, 1)) hidden_transform(bfrag, ng, bufA, bufB);
+            if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);
+            else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (!DIAG_ON(a, 0)) hidden_aggregate(L, ng, bufA, bufB, rinfo, perm, vals, words);
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words);
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -652,8 +660,8 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         //   greedy_mode 2  top-`beam` candidates, each completed greedily by weight; the best total joins
         //                  (solve_mwis_rollout, :596-659)
         double* pr = reinterpret_cast<double*>(bufB);
-        double* red = pr + a.max_nodes;          // [kFusedBlock]
-        double* wl = red + kFusedBlock;          // [max_nodes] vertex weights (rollout totals)
+        double* red = pr + a.max_nodes;          // [BLOCK]
+        double* wl = red + BLOCK;          // [max_nodes] vertex weights (rollout totals)
         unsigned short* key = reinterpret_cast<unsigned short*>(bufA);
         unsigned short* gkey = key + a.max_nodes;   // GCN-priority ranks (rollout candidates)
         unsigned short* wkey = gkey + a.max_nodes;  // weight ranks (rollout completions)
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             wl[tv] = wmine;
             st[tv] = was_alive ? 0 : a.state[n0 + tv];
         }
-        const bool any_bad = block_or(bad != 0, wflags);
+        const bool any_bad = block_or<BLOCK>(bad != 0, wflags);
         __syncthreads();
         if (any_bad) {
             if (threadIdx.x == 0) {
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             return;
         }
         int lsh = 0;
-        while (lsh < 3 && (ng << (lsh + 1)) <= kFusedBlock) ++lsh;
+        while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
         const int lpv = 1 << lsh;
         const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
         const bool mine = vv < ng;
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
         int rounds = 0;
         if (a.greedy_mode != 2) {
-            rounds = greedy_rounds(key, st, 2, words, rs, re, vv, sub, lpv, mine, wflags, a.max_rounds, a.greedy_mode == 1);
+            rounds = greedy_rounds<BLOCK>(key, st, 2, words, rs, re, vv, sub, lpv, mine, wflags, a.max_rounds, a.greedy_mode == 1);
         } else {
             // candidates in GCN-priority order (stable argsort of -priority = the rank keys)
             int nc = 0;
@@ -732,11 +740,11 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
                 __syncthreads();
                 {
                     const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
-                    for (int j = crs + tv; j < cre; j += kFusedBlock) key[words[j] >> 7] = (unsigned short)kDead;  // diagonal entry: c itself
+                    for (int j = crs + tv; j < cre; j += BLOCK) key[words[j] >> 7] = (unsigned short)kDead;  // diagonal entry: c itself
                 }
                 __syncthreads();
-                greedy_rounds(key, jn, 0, words, rs, re, vv, sub, lpv, mine, wflags, 0, false);
-                const double tot = block_sum((tv < ng && jn[tv] == 1) ? wl[tv] : 0.0, red);
+                greedy_rounds<BLOCK>(key, jn, 0, words, rs, re, vv, sub, lpv, mine, wflags, 0, false);
+                const double tot = block_sum<BLOCK>((tv < ng && jn[tv] == 1) ? wl[tv] : 0.0, red);
                 if (threadIdx.x == 0) cand[i] = wl[c] + tot;
             }
             __syncthreads();
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
             __syncthreads();
             const int c = pick[0];
             const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
-            for (int j = crs + tv; j < cre; j += kFusedBlock) {
+            for (int j = crs + tv; j < cre; j += BLOCK) {
                 const int u = words[j] >> 7;
                 st[u] = (u == c) ? 1 : 2;
             }
@@ -768,13 +776,13 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         if (a.totals) {
             double part = 0.0;
             if (tv < ng && was_alive && st[tv] == 1) part = a.weights ? wl[tv] : pr[tv];
-            const double tot = block_sum(part, red);
+            const double tot = block_sum<BLOCK>(part, red);
             if (threadIdx.x == 0) a.totals[g] = tot;
         }
         if (fault) atomicOr(a.status, fault);
     } else {
     double* pr = reinterpret_cast<double*>(bufB);
-    double* red = pr + a.max_nodes;  // [kFusedBlock] slots; bufB has 128 B per row and max_nodes >= 64 rows
+    double* red = pr + a.max_nodes;  // [BLOCK] slots; bufB has 128 B per row and max_nodes >= 64 rows
     unsigned short* key = reinterpret_cast<unsigned short*>(bufA);
     uint8_t* st = reinterpret_cast<uint8_t*>(key + a.max_nodes);
     constexpr unsigned kDead = 0xFFFFu;
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         bad = (p != p);
         pr[threadIdx.x] = p;
     }
-    const bool any_bad = block_or(bad != 0, wflags);
+    const bool any_bad = block_or<BLOCK>(bad != 0, wflags);
     __syncthreads();  // flag words are re-used by the greedy rounds
     if (any_bad) {
         if (threadIdx.x == 0) {
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         return;
     }
     int lsh = 0;  // lanes per vertex = 1 << lsh, as many as the block affords (<= 8)
-    while (lsh < 3 && (ng << (lsh + 1)) <= kFusedBlock) ++lsh;
+    while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
     const int lpv = 1 << lsh;
     const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
     const bool mine = vv < ng;
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && mykey < m;
-        if (!block_or(live, wflags)) break;  // its barrier also orders every rank read before the kills below
+        if (!block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every rank read before the kills below
         ++rounds;
         if (won) {
             for (int j = rs + sub; j < re; j += lpv) {
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(kFusedBlock) void k_fused(FusedArgs a) {
         if (tv < ng && st[tv] == 1) part = a.weights ? a.weights[n0 + tv] : pr[tv];
         red[threadIdx.x] = part;
         __syncthreads();
-        for (int off = kFusedBlock / 2; off > 0; off >>= 1) {
+        for (int off = BLOCK / 2; off > 0; off >>= 1) {
             if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
             __syncthreads();
         }
@@ -947,9 +955,9 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
                          void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream) {
     if (!fused_shape_ok(m))
         return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 only", who);
-    if (b->max_nodes > kFusedBlock)
+    if (b->max_nodes > kFusedMaxNodes)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: graphs of %d vertices exceed the fused kernel's %d", who, b->max_nodes,
-                    kFusedBlock);
+                    kFusedMaxNodes);
     a->graph_ptr = b->graph_ptr;
     a->max_nodes = max(b->max_nodes, 64);  // >= 64 rows: the greedy phase re-uses bufB for priorities + reduction
     a->num_layers = m->num_layers;
@@ -1003,16 +1011,26 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     return DGCN_OK;
 }
 
-template <bool MASKED, bool GVALS>
-static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+template <bool MASKED, bool GVALS, int BLOCK>
+static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t(family, s);
-    hipLaunchKernelGGL((k_fused<MASKED, GVALS>), dim3(B), dim3(kFusedBlock), lds, s, a);
+    hipLaunchKernelGGL((k_fused<MASKED, GVALS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
+}
+
+// An image above half the LDS leaves its graph alone on a CU: 16 waves instead of 8 then work on it
+// (at 128 VGPRs both fit the register file exactly).  DGCN_FUSED_BLOCK=512|1024 overrides (tuning / tests).
+template <bool MASKED, bool GVALS>
+static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    bool big = lds > kLdsLimit / 2 && a.max_nodes >= 128;
+    if (const char* e = getenv("DGCN_FUSED_BLOCK")) big = atoi(e) == kFusedBlockBig && a.max_nodes >= 128;
+    return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig>(a, B, lds, family, s)
+               : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
 }
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
@@ -1065,7 +1083,7 @@ using namespace dgcn;
 
 extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m || !m->layers_host || m->num_supports != 2) return 0;
-    if (!fused_shape_ok(m) || b->max_nodes > kFusedBlock) return 0;
+    if (!fused_shape_ok(m) || b->max_nodes > kFusedMaxNodes) return 0;
     const int cap = fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes);
     return fused_variant(max(b->max_nodes, 64), cap) >= 0;
 }
