@@ -25,6 +25,14 @@ for mode in ("fused", "layered"):
             open(os.path.join(DST, "%s_bench_%s.json" % (TAG, mode)), "w").write(lines[-1])
 
 
+f = first(os.path.join(SRC, "iterative", "**", "*kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(DST, "%s_iterative_n500_kernel_stats.csv" % TAG))
+    j = os.path.join(SRC, "iterative.json")
+    if os.path.isfile(j):
+        open(os.path.join(DST, "%s_iterative_n500.json" % TAG), "w").write("".join(l for l in open(j) if l.startswith("{")))
+
+
 def pmc(kind, counter, match):
     f = first(os.path.join(SRC, "pmc_%s_%s" % (kind, counter), "**", "*counter_collection.csv"))
     if not f:
