@@ -341,23 +341,21 @@ __device__ __forceinline__ int greedy_rounds(unsigned short* key, uint8_t* mark,
     return rounds;
 }
 
-// Block-wide sum of one double per thread, fixed tree order; result valid on every thread.
+// Block-wide sum of one double per thread in a fixed order (shuffle tree inside a wave, then the wave
+// partials in wave order); result valid on every thread.  One barrier + one trailing barrier.
 template <int BLOCK>
 __device__ __forceinline__ double block_sum(double part, double* red) {
-    red[threadIdx.x] = part;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    for (int off = BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    const double r = red[0];
+    double r = red[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; ++w) r += red[w];
     __syncthreads();
     return r;
 }
 
-// GVALS: graphs whose full image exceeds the LDS keep the entry VALUES (4 of the 6 metadata bytes per
-// entry) in a global scratch slice (L2-resident, read as broadcast float2 per 8-lane group); hidden
-// states, gather words, row table and row order stay in LDS.  Same arithmetic, slower gathers.
 template <bool MASKED, bool GVALS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -866,13 +864,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     if (a.totals) {
         double part = 0.0;
         if (tv < ng && st[tv] == 1) part = a.weights ? a.weights[n0 + tv] : pr[tv];
-        red[threadIdx.x] = part;
-        __syncthreads();
-        for (int off = BLOCK / 2; off > 0; off >>= 1) {
-            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) a.totals[g] = red[0];
+        const double tot = block_sum<BLOCK>(part, red);
+        if (threadIdx.x == 0) a.totals[g] = tot;
     }
     if (fault) atomicOr(a.status, fault);
     STAMP(a, g, 11, tclk);  // totals, output
