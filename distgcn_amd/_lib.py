@@ -109,7 +109,7 @@ def load():
                                      vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.dgcn_solve_residual_batch.restype = C.c_int
     lib.dgcn_solve_residual_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), vp, i32, vp, f32, i32, vp, i32,
-                                              i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+                                              i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.dgcn_timing_enable.restype = C.c_int
     lib.dgcn_timing_enable.argtypes = [i32]
     lib.dgcn_timing_reset.restype = C.c_int

@@ -76,6 +76,7 @@ struct FusedArgs {
     int32_t greedy_mode;   // 0 local greedy rounds, 1 one centralised step (global best joins), 2 one rollout step
     int32_t max_rounds;    // greedy_mode 0: stop after this many rounds (0 = until every vertex is decided)
     int32_t beam;          // greedy_mode 2: number of candidates
+    int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
         // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286)
         if (!block_or<BLOCK>(was_alive && w0 > 0.0, wflags)) {
-            if (a.scores && tv0 < ng) a.scores[n0 + tv0] = 0.f;
+            if (a.scores && tv0 < ng && !(a.options & DGCN_RESIDUAL_SCORES_GIVEN)) a.scores[n0 + tv0] = 0.f;
             if (threadIdx.x == 0) {
                 if (a.rounds) a.rounds[g] = 0;
                 if (a.totals) a.totals[g] = 0.0;
@@ -582,9 +583,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
 
     // ------------------------------------------------------------ layers
     float score = 0.f;  // final output of vertex threadIdx.x (ng <= block, checked by the host)
+    const bool scores_given = MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN);
+    if (scores_given && (int)threadIdx.x < ng) score = a.scores[n0 + threadIdx.x];
     float bfrag[8][4];
-    if (a.num_layers > 2) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
-    for (int l = 0; l < a.num_layers; ++l) {
+    if (a.num_layers > 2 && !scores_given) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
+    for (int l = 0; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
         if (L.cout == kHid) {
 #ifdef DGCN_DIAG
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 if (c < 0) break;  // fewer remaining vertices than candidates
                 ++nc;
                 // the residual graph minus the candidate's closed neighbourhood, ranked by weight
-                if (tv < ng) { key[tv] = wkey[tv]; jn[tv] = 0; }
+                if (tv < ng) { key[tv] = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey[tv] : wkey[tv]; jn[tv] = 0; }
                 __syncthreads();
                 {
                     const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
@@ -1122,7 +1125,7 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
 extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
                                          int32_t table_len, const float* X, float x_const, int32_t feature_mode,
                                          const double* weights, int32_t predict_mwis, int32_t greedy_mode,
-                                         int32_t max_rounds, int32_t beam, float* scores, uint8_t* state,
+                                         int32_t max_rounds, int32_t beam, int32_t options, float* scores, uint8_t* state,
                                          int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
@@ -1131,6 +1134,8 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     if (greedy_mode < 0 || greedy_mode > 2) return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: greedy_mode %d", greedy_mode);
     if (greedy_mode == 2 && (beam < 1 || beam > 64 || !weights))
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: rollout needs weights and 1 <= beam <= 64");
+    if ((options & DGCN_RESIDUAL_SCORES_GIVEN) && !scores)
+        return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: DGCN_RESIDUAL_SCORES_GIVEN needs the scores array");
     if (feature_mode == 1 && (!weights || X))
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: feature_mode 1 derives X from the weights");
     if (b->num_graphs <= 0) return DGCN_OK;
@@ -1152,6 +1157,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.greedy_mode = greedy_mode;
     args.max_rounds = max_rounds;
     args.beam = beam;
+    args.options = options;
     args.state = state;
     args.rounds = rounds;
     args.totals = totals;

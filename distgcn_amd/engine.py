@@ -278,10 +278,12 @@ class Engine:
                 "scores": None if scores is None else scores[:n], "stats": None, "overhead": None}
 
     GREEDY_ROUNDS, GREEDY_CENTRAL, GREEDY_ROLLOUT = 0, 1, 2
+    SCORES_GIVEN, COMPLETE_BY_PRIORITY = 1, 2  # DGCN_RESIDUAL_* option bits
 
     def solve_residual(self, b: DeviceBatch, model: DeviceModel, state, predict: str = "mwis", greedy: int = 0,
                        max_rounds: int = 0, beam: int = 16, X=None, x_const=None, weight_features: bool = False,
-                       want_scores: bool = False, max_steps: Optional[int] = None, out=None):
+                       want_scores: bool = False, max_steps: Optional[int] = None, out=None, options: int = 0,
+                       scores=None):
         """Iterative solvers on the device (dgcn_solve_residual_batch): repeat one launch per step on the
         residual graphs until no graph makes progress.  ``state`` (uint8 [num_nodes], 0 = undecided) is
         updated in place.  greedy = GREEDY_ROUNDS with max_rounds=1 is solve_mwis_dit, GREEDY_CENTRAL is
@@ -294,6 +296,10 @@ class Engine:
         tab = self._dinv(b.host.max_degree)
         if out is None:
             out = self.solve_buffers(b, want_scores)
+        if options & self.SCORES_GIVEN:
+            if scores is None:
+                raise ValueError("options & SCORES_GIVEN needs scores")
+            out = dict(out, scores=scores)
         progress = t.zeros(1, dtype=t.int32, device=self.device)
         p = lambda x: x.data_ptr() if x is not None else None
         need = int(self.lib.dgcn_solve_workspace(C.byref(b.c), C.byref(model.c)))
@@ -305,7 +311,7 @@ class Engine:
             _lib.check(self.lib.dgcn_solve_residual_batch(
                 C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
                 1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
-                int(max_rounds), int(beam), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
+                int(max_rounds), int(beam), int(options), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
                 progress.data_ptr(), out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
                 "dgcn_solve_residual_batch")
             if int(progress.item()) == 0:

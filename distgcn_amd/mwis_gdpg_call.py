@@ -19,6 +19,11 @@ from .mwis_dqn_call import _State, solve_host_batch
 from .runtime_config import FLAGS, flags  # noqa: F401
 
 
+# which -> (GCN re-run on every residual graph, completions ordered by GCN priority instead of weight)
+ROLLOUT_VARIANTS = {"rollout": (True, False), "rollout00": (False, False), "rollout0": (False, True),
+                    "rollout1": (True, True)}
+
+
 class MWISSolver(object):
     def __init__(self, input_flags, memory_size=5000):
         self.flags = input_flags
@@ -128,8 +133,9 @@ class MWISSolver(object):
     device_iterative = True  # False: always re-slice on the host (the path for shapes outside the fused kernel)
 
     def solve_iterative_batch(self, adjs: Sequence, wts_list: Sequence, which: str = "dit", b: int = 16):
-        """``solve_mwis_dit`` / ``_cit`` / ``_rollout`` for many graphs at once, one launch per step for the
-        whole batch (``Engine.solve_residual``); None when the shapes are outside the fused kernel."""
+        """``solve_mwis_dit`` / ``_cit`` / ``_rollout`` (and ``rollout00`` / ``rollout0`` / ``rollout1``) for
+        many graphs at once, one launch per step for the whole batch (``Engine.solve_residual``); None when
+        the shapes are outside the fused kernel."""
         import torch
         csrs = [as_csr(a) for a in adjs]
         hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs],
@@ -138,12 +144,18 @@ class MWISSolver(object):
         eng = get_engine()
         db = eng.upload(hb)
         dm = self.model.device_model(eng)
-        if hb.num_nodes == 0 or not eng.solve_supported(db, dm) or (which == "rollout" and not 1 <= b <= 64):
+        if hb.num_nodes == 0 or not eng.solve_supported(db, dm) or (which.startswith("rollout") and not 1 <= b <= 64):
             return None
-        greedy = {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL, "rollout": eng.GREEDY_ROLLOUT}[which]
+        greedy = eng.GREEDY_ROLLOUT if which.startswith("rollout") else \
+            {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL}[which]
+        rescore, by_prio = ROLLOUT_VARIANTS.get(which, (True, False))
+        options, scores = (eng.COMPLETE_BY_PRIORITY if by_prio else 0), None
+        if not rescore:  # one forward pass on the full graphs; every step re-uses its scores
+            options |= eng.SCORES_GIVEN
+            scores = self.model.forward_batch(eng, db, X=self._features(hb), mode=1)
         state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
         res = eng.solve_residual(db, dm, state, predict=self.flags.predict, greedy=greedy, max_rounds=1, beam=b,
-                                 weight_features=self.flags.predict != "mwis")
+                                 weight_features=self.flags.predict != "mwis", options=options, scores=scores)
         eng.check_status(res["status"])
         st = res["state"].cpu().numpy()
         out = []
@@ -195,33 +207,44 @@ class MWISSolver(object):
             best = np.dot(nIS_vec, wts)
         return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
-    def solve_mwis_rollout(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
-        """Top-``b`` GCN candidates, each scored by its weight plus a greedy completion of what is left
-        (``mwis_gdpg_call.py:596-659``).  The ``b`` completions are ONE launch of the masked greedy
-        kernel over the residual graph.  The reference breaks score ties with ``np.random.choice``
-        (unseeded) and ranks with an unstable sort: here ties go to the first candidate / lower index
-        unless ``rng`` (a ``numpy.random.Generator``) is given."""
+    def _rollout(self, which, adj_0, wts_0, b=16, rng=None):
+        """The four rollout searches of the reference share one loop; ``ROLLOUT_VARIANTS[which]`` says
+        whether the GCN is re-run on every residual graph and what orders the greedy completions."""
         import torch
+        rescore, by_prio = ROLLOUT_VARIANTS[which]
         if rng is None and self.device_iterative:
-            dev = self.solve_iterative_batch([adj_0], [wts_0], "rollout", b=b)
+            dev = self.solve_iterative_batch([adj_0], [wts_0], which, b=b)
             if dev is not None:
                 return dev[0]
         adj_0, wts, nIS_vec = self._start(adj_0, wts_0, self.feature_size)
         best = np.array([0.0])
+        full_scores = None
+        if not rescore:
+            full_scores = self._residual_scores(adj_0, wts)[2].cpu().numpy()
         while np.sum(nIS_vec == -1) > 0:
             adj_nn, wts_nn, rmap = self._slice(adj_0, wts, nIS_vec)
             n = wts_nn.shape[0]
             if np.sum(wts_nn) <= 0:
                 break
-            eng, db, scores = self._residual_scores(adj_nn, wts_nn)
-            children = np.argsort(-self._gcn_wts(scores, wts_nn), kind="stable")[0:b]
+            eng = get_engine()
+            if rescore:
+                eng, db, scores = self._residual_scores(adj_nn, wts_nn)
+                act_vals = scores.cpu().numpy().flatten()
+            else:
+                hb = HostBatch.from_csr_lists([adj_nn.indptr.astype(np.int64)], [adj_nn.indices.astype(np.int64)],
+                                              [wts_nn[:, 0]])
+                db = eng.upload(hb)
+                act_vals = full_scores.flatten()[rmap]
+            gcn_wts = act_vals * wts_nn.flatten() if self.flags.predict == "mwis" else act_vals.astype(np.float64)
+            children = np.argsort(-gcn_wts, kind="stable")[0:b]
             cand = wts_nn[children].copy()
             if len(cand) > 1:
                 init = np.zeros((len(children), n), dtype=np.uint8)
                 for i, child in enumerate(children):
                     init[i, child] = 3
                     init[i, adj_nn.indices[adj_nn.indptr[child]:adj_nn.indptr[child + 1]]] = 3
-                ro = eng.lgs_masked(db, db.weights, torch.from_numpy(init).to(eng.device), len(children),
+                prio = torch.from_numpy(np.ascontiguousarray(gcn_wts)).to(eng.device) if by_prio else db.weights
+                ro = eng.lgs_masked(db, prio, torch.from_numpy(init).to(eng.device), len(children),
                                     sum_weights=db.weights)
                 eng.check_status(ro["status"])
                 cand[:, 0] += ro["totals"].cpu().numpy()[:, 0]
@@ -235,6 +258,61 @@ class MWISSolver(object):
             nIS_vec[rmap[nb_v]] = 0
             best = np.dot(nIS_vec, wts)
         return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
+
+    def solve_mwis_rollout(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        """Top-``b`` GCN candidates, each scored by its weight plus a greedy completion (by weight) of what is
+        left; the GCN is re-run on every residual graph (``mwis_gdpg_call.py:596-659``).  On the device the
+        whole step is one launch; on the host-re-slicing path the ``b`` completions are ONE launch of the
+        masked greedy kernel.  The reference breaks score ties with ``np.random.choice`` (unseeded) and ranks
+        with an unstable sort: here ties go to the first candidate / lower index unless ``rng`` (a
+        ``numpy.random.Generator``) is given."""
+        return self._rollout("rollout", adj_0, wts_0, b=b, rng=rng)
+
+    def solve_mwis_rollout00(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        """``mwis_gdpg_call.py:413-472``: the GCN runs ONCE on the full graph; completions by weight."""
+        return self._rollout("rollout00", adj_0, wts_0, b=b, rng=rng)
+
+    def solve_mwis_rollout0(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        """``:474-533``: GCN once; completions ordered by the GCN priority, valued by weight."""
+        return self._rollout("rollout0", adj_0, wts_0, b=b, rng=rng)
+
+    def solve_mwis_rollout1(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+        """``:535-594``: GCN on every residual graph; completions ordered by the GCN priority."""
+        return self._rollout("rollout1", adj_0, wts_0, b=b, rng=rng)
+
+    # ---- thin inference helpers of the reference class ------------------------------------------------
+    @staticmethod
+    def mellowmax(q_vec, omega, beta=None):
+        """``mwis_gdpg_call.py:140-145``."""
+        q_vec = np.asarray(q_vec)
+        c = np.max(q_vec)
+        return c + np.log(np.sum(np.exp(omega * (q_vec - c))) / np.size(q_vec)) / omega
+
+    def utility(self, adj_0, wts_0, train=False):
+        """``:147-160`` -> (gcn_wts = act_values, state).  (The reference passes ``act()``'s tuple on as if it
+        were the array - SURVEY 2 notes the latent bug; this returns the array.)"""
+        wts_nn = np.reshape(np.asarray(wts_0, dtype=np.float64), (-1, self.feature_size))
+        state = self.makestate(as_csr(adj_0), wts_nn)
+        return self.predict(state)[0], state
+
+    def topology_encode(self, adj_0, wts_0, train=False):
+        """``:189-198`` -> act_values [N, 1]."""
+        return self.utility(adj_0, np.reshape(wts_0, (-1, 1)))[0]
+
+    def schedule(self, adj_0, wts_0, train=False):
+        """``:162-187`` -> (mwis, total_wt, state, act_vals): GCN followed by the local greedy search."""
+        wts_nn = np.reshape(np.asarray(wts_0, dtype=np.float64), (-1, self.feature_size))
+        act_vals, state = self.utility(adj_0, wts_nn)
+        mwis, total = self.solve_mwis(adj_0, wts_nn)
+        return mwis, total, state, act_vals
+
+    def solve_mwis_util(self, adj_0, wts_0, wts_u, train=False, grd=1.0):
+        """``:237-276`` (inference branch): the set is chosen with ``wts_0``, valued with ``wts_u``."""
+        if train:
+            raise NotImplementedError("train=True (replay memory) is outside the inference drop-in")
+        mwis, _ = self.solve_mwis(adj_0, wts_0)
+        wts_u = np.asarray(wts_u, dtype=np.float64)
+        return mwis, np.sum(wts_u[sorted(mwis)])
 
     def _wrap(self, inner, adj_0, wts_0, **kw):
         """Per connected component (``mwis_gdpg_call.py:320-341, 386-411``; components via SciPy

@@ -201,13 +201,18 @@ int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const doubl
  * feature_mode 1: every feature of vertex v is (float)(w[v] / (max residual w + 1e-9)) (X must be NULL).
  * A graph with no undecided vertex, or no positive weight left (np.sum(wts_nn) <= 0 -> break), is left
  * untouched; otherwise *progress += 1.  The caller repeats the launch until *progress stays 0.
+ * options: DGCN_RESIDUAL_* bits (the rollout variants mwis_gdpg_call.py:413-594).
  * rounds[g]: rounds run by this launch; totals[g]: weight (or priority) of the vertices that joined in
  * THIS launch; scores: residual-graph scores (0 for removed vertices).  Same shape limits as
  * dgcn_solve_batch. */
+#define DGCN_RESIDUAL_SCORES_GIVEN 1        /* `scores` is an INPUT (one forward pass on the full graph, done by the
+                                              caller): no forward pass here - solve_mwis_rollout00 / rollout0 */
+#define DGCN_RESIDUAL_COMPLETE_BY_PRIORITY 2 /* rollout completions ordered by priority instead of weight
+                                              (greedy_search(adj_ro, gw_ro)): solve_mwis_rollout0 / rollout1 */
 int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table,
                               int32_t table_len, const float* X, float x_const, int32_t feature_mode,
                               const double* weights, int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds,
-                              int32_t beam, float* scores, uint8_t* state, int32_t* rounds, double* totals,
+                              int32_t beam, int32_t options, float* scores, uint8_t* state, int32_t* rounds, double* totals,
                               int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream);
 

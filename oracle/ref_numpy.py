@@ -411,20 +411,25 @@ def solve_mwis_cit(scores_fn, adj_0, wts_0, predict="mwis"):
     return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
 
-def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None):
+def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, rescore=True, by_priority=False):
     """Top-b GCN candidates, each scored by its weight plus a greedy completion of the residual
     (mwis_gdpg_call.py:596-659).  The reference breaks score ties with ``np.random.choice`` and ranks
-    with an unstable sort; here ties go to the first candidate / lower index unless ``rng`` is given."""
+    with an unstable sort; here ties go to the first candidate / lower index unless ``rng`` is given.
+    Variants (mwis_gdpg_call.py:413-594): ``rescore=False`` runs the GCN once on the full graph (rollout00,
+    rollout0); ``by_priority=True`` orders the greedy completions by the GCN priority instead of the weight,
+    still valuing them by weight (rollout0, rollout1)."""
     adj_0 = sp.csr_matrix(adj_0)
     wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
     nIS_vec = -np.ones(adj_0.shape[0])
     best = np.array([0.0])
+    full_scores = None if rescore else np.asarray(scores_fn(adj_0, wts))
     while np.sum(nIS_vec == -1) > 0:
         adj_nn, wts_nn, rmap = _residual(adj_0, wts, nIS_vec)
         n = wts_nn.shape[0]
         if np.sum(wts_nn) <= 0:
             break
-        gcn_wts = priority(scores_fn(adj_nn, wts_nn), wts_nn, predict)
+        act_vals = scores_fn(adj_nn, wts_nn) if rescore else full_scores[rmap]
+        gcn_wts = priority(act_vals, wts_nn, predict)
         children = np.argsort(-gcn_wts.flatten(), kind="stable")[0:b]
         scores = wts_nn[children].copy()
         if len(scores) > 1:
@@ -434,7 +439,11 @@ def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None):
                 _, nb_v = np.nonzero(adj_nn[child])
                 keep[nb_v] = False
                 adj_ro = adj_nn[keep, :][:, keep]
-                _, ss = greedy_search(adj_ro, wts_nn[keep])
+                if by_priority:
+                    ps, _ = greedy_search(adj_ro, gcn_wts.flatten()[keep])
+                    ss = np.sum(wts_nn[keep][sorted(ps)])
+                else:
+                    _, ss = greedy_search(adj_ro, wts_nn[keep])
                 scores[i] += ss
         # candidates that complete to the same set tie mathematically but not bit for bit (the sums run in
         # different orders): totals within 1e-12 relative count as tied

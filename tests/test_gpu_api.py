@@ -243,7 +243,7 @@ def test_lgs_masked_instances(engine, golden):
 
 
 @pytest.mark.parametrize("on_device", [True, False])
-@pytest.mark.parametrize("which", ["dit", "cit", "rollout", "cit_wrap", "rollout_wrap"])
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout", "cit_wrap", "rollout_wrap", "rollout00", "rollout0", "rollout1"])
 def test_iterative_solvers(engine, golden, which, on_device):
     """solve_mwis_dit / _cit / _rollout (+ _wrap) against the oracle restatement, both
     with the residual graph masked on the device and with the host re-slicing fallback."""
@@ -262,6 +262,10 @@ def test_iterative_solvers(engine, golden, which, on_device):
             got, want = agent.solve_mwis_rollout(adj, w, b=8), orc.solve_mwis_rollout(fn, adj, w, b=8)
         elif which == "cit_wrap":
             got, want = agent.solve_mwis_cit_wrap(adj, w), orc.solve_wrap(orc.solve_mwis_cit, fn, adj, w)
+        elif which in ("rollout00", "rollout0", "rollout1"):  # the variants mwis_gdpg_call.py:413-594
+            rescore, by_prio = {"rollout00": (False, False), "rollout0": (False, True), "rollout1": (True, True)}[which]
+            got = getattr(agent, "solve_mwis_" + which)(adj, w, b=8)
+            want = orc.solve_mwis_rollout(fn, adj, w, b=8, rescore=rescore, by_priority=by_prio)
         else:
             got = agent.solve_mwis_rollout_wrap(adj, w, b=8)
             want = orc.solve_wrap(orc.solve_mwis_rollout, fn, adj, w, b=8)
@@ -408,3 +412,22 @@ def test_large_graph_takes_layered_path(engine):
         ref = ctwin.solve(hb, agent.model.layers)
         assert np.array_equal(res["state"], ref["state"])
         assert np.array_equal(res["scores"].view(np.uint32), ref["scores"].view(np.uint32))
+
+
+def test_agent_helper_methods(engine, golden):
+    """utility / topology_encode / schedule / solve_mwis_util / mellowmax (mwis_gdpg_call.py:140-276)."""
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=3), seed=9)
+    adj, w = golden.scipy(2), golden.csr(2)[2]
+    act_vals, state = agent.utility(adj, w)
+    assert act_vals.shape == (w.size, 1) and act_vals.dtype == np.float32
+    assert np.array_equal(agent.topology_encode(adj, w), act_vals)
+    mwis, total, _, av = agent.schedule(adj, w)
+    ref_set, ref_total = agent.solve_mwis(adj, w)
+    assert mwis == ref_set and total == ref_total and np.array_equal(av, act_vals)
+    wu = np.arange(w.size, dtype=np.float64)
+    s2, t2 = agent.solve_mwis_util(adj, w, wu)
+    assert s2 == ref_set and t2 == pytest.approx(sum(wu[list(ref_set)]))
+    q = np.array([0.1, 0.7, 0.3])
+    c = q.max()
+    assert agent.mellowmax(q, 5.0) == pytest.approx(c + np.log(np.mean(np.exp(5.0 * (q - c)))) / 5.0)
