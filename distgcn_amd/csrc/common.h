@@ -1,6 +1,7 @@
 // Shared host-side helpers for libdgcn.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -18,12 +19,24 @@ void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 
 // kernel-family timing (dgcn_timing_*): RAII pair of events around one launch
+// With timing enabled a launch goes through hipExtLaunchKernelGGL, which stamps the slot's two events with
+// the kernel's own begin / end (the duration rocprofv3 reports), not with the gaps around it.
 struct TimedLaunch {
     TimedLaunch(const char* family, hipStream_t stream);
-    ~TimedLaunch();
+    bool timed() const { return slot >= 0; }
+    hipEvent_t start_ev() const;
+    hipEvent_t stop_ev() const;
     int slot;
     hipStream_t stream;
 };
+
+#define DGCN_LAUNCH(t, kernel, grid, block, lds, stream, ...)                                                  \
+    do {                                                                                                       \
+        if ((t).timed())                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (t).start_ev(), (t).stop_ev(), 0, __VA_ARGS__); \
+        else                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

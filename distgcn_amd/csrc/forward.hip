@@ -132,6 +132,6 @@ extern "C" int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t*
     if (!scores || !graph_ptr || !arg_out || ld <= 0) return fail(DGCN_ERR_ARG, "dgcn_argmax_batch: bad argument");
     if (num_graphs <= 0) return DGCN_OK;
     TimedLaunch t("argmax", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_argmax, dim3(num_graphs), dim3(256), 0, (hipStream_t)stream, scores, ld, graph_ptr, arg_out);
+    DGCN_LAUNCH(t, k_argmax, dim3(num_graphs), dim3(256), 0, (hipStream_t)stream, scores, ld, graph_ptr, arg_out);
     return check_launch("k_argmax");
 }

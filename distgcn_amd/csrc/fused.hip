@@ -984,7 +984,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
             pa.src[l].out = L.out_dim;
         }
         TimedLaunch t("fused_pad", stream);
-        hipLaunchKernelGGL(k_pad_model, dim3(m->num_layers), dim3(256), 0, stream, pa);
+        DGCN_LAUNCH(t, k_pad_model, dim3(m->num_layers), dim3(256), 0, stream, pa);
         int rc = check_launch("k_pad_model");
         if (rc) return rc;
         workspace = static_cast<char*>(workspace) + pad_bytes;
@@ -1015,7 +1015,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t(family, s);
-    hipLaunchKernelGGL((k_fused<MASKED, GVALS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
 }
 

@@ -279,7 +279,7 @@ static int launch_lgs(const LgsArgs& a, int B, size_t lds, hipStream_t s) {
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_lgs: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t("lgs", s);
-    hipLaunchKernelGGL((k_lgs<LPV, STATS>), dim3(B), dim3(256), lds, s, a);
+    DGCN_LAUNCH(t, (k_lgs<LPV, STATS>), dim3(B), dim3(256), lds, s, a);
     return check_launch("k_lgs");
 }
 

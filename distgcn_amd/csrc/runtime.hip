@@ -26,8 +26,8 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Timing: when enabled, each TimedLaunch records (start, stop) events on the launch stream.
-// Nothing is synchronised until dgcn_timing_read().
+// Timing: when enabled, each TimedLaunch owns a (start, stop) event pair that the launch itself stamps
+// (DGCN_LAUNCH -> hipExtLaunchKernelGGL).  Nothing is synchronised until dgcn_timing_read().
 struct TimingSlot {
     std::string family;
     hipEvent_t start, stop;
@@ -51,13 +51,16 @@ TimedLaunch::TimedLaunch(const char* family, hipStream_t s) : slot(-1), stream(s
     slot = (int)g_live++;
     g_slots[slot].family = family;
     g_slots[slot].used = true;
-    (void)hipEventRecord(g_slots[slot].start, stream);
 }
 
-TimedLaunch::~TimedLaunch() {
-    if (slot < 0) return;
+hipEvent_t TimedLaunch::start_ev() const {
     std::lock_guard<std::mutex> lk(g_tmu);
-    (void)hipEventRecord(g_slots[slot].stop, stream);
+    return g_slots[slot].start;
+}
+
+hipEvent_t TimedLaunch::stop_ev() const {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    return g_slots[slot].stop;
 }
 
 }  // namespace dgcn

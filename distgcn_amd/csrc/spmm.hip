@@ -231,7 +231,7 @@ static int launch_spmm_lds(const DgcnCsr* S, const int32_t* graph_ptr, int B, in
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_spmm_lds: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t("spmm", s);
-    hipLaunchKernelGGL((k_spmm_lds<VEC, LPR, G, BLOCK>), dim3((unsigned)tiles * (unsigned)B), dim3(BLOCK), lds, s,
+    DGCN_LAUNCH(t, (k_spmm_lds<VEC, LPR, G, BLOCK>), dim3((unsigned)tiles * (unsigned)B), dim3(BLOCK), lds, s,
                        S->row_ptr, S->col_idx, S->values, graph_ptr, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, Y0,
                        ldy0, bias, act, Y, ldy);
     return check_launch("k_spmm_lds");
@@ -286,7 +286,7 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
     int blocks = ceil_div(S->num_rows, kSlots);
     blocks = min(blocks, 256 * 16);
     TimedLaunch t("spmm", s);
-    hipLaunchKernelGGL((k_spmm_global<VEC, LPR, G>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values,
+    DGCN_LAUNCH(t, (k_spmm_global<VEC, LPR, G>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values,
                        S->num_rows, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy);
     return check_launch("k_spmm_global");
 }

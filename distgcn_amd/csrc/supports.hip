@@ -68,7 +68,7 @@ extern "C" int dgcn_supports_batch(const DgcnBatch* b, const double* dinv_table,
     const int tiles = ceil_div(b->max_nodes, kSupRowsPerBlock);
     dim3 grid((unsigned)tiles * (unsigned)b->num_graphs);
     TimedLaunch t("supports", s);
-    hipLaunchKernelGGL(k_supports, grid, dim3(256), 0, s, b->graph_ptr, b->row_ptr, b->col_idx, b->num_nodes,
+    DGCN_LAUNCH(t, k_supports, grid, dim3(256), 0, s, b->graph_ptr, b->row_ptr, b->col_idx, b->num_nodes,
                        tiles, dinv_table, table_len, lap_row_ptr, lap_col, lap_val, status);
     return check_launch("k_supports");
 }

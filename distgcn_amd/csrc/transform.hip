@@ -118,7 +118,7 @@ int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin
     const int mfma_blocks = min(ceil_div(rows, 128), 256 * 8);
 #define DGCN_TF_CASE(CI, CO)                                                                                     \
     if (aligned && cin == CI && ctot == CO) {                                                                    \
-        hipLaunchKernelGGL((k_transform_mfma<CI, CO>), dim3(mfma_blocks), dim3(256), 0, s, H, ldh, rows, W, Z, ldz); \
+        DGCN_LAUNCH(t, (k_transform_mfma<CI, CO>), dim3(mfma_blocks), dim3(256), 0, s, H, ldh, rows, W, Z, ldz); \
         return check_launch("k_transform_mfma");                                                                 \
     }
     DGCN_TF_CASE(32, 64)
@@ -130,13 +130,13 @@ int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin
     DGCN_TF_CASE(8, 32)
 #undef DGCN_TF_CASE
     if (H && ctot == 2) {
-        hipLaunchKernelGGL((k_transform_narrow<2>), dim3(min(ceil_div(rows, 256), 4096)), dim3(256), 0, s, H, ldh, rows,
+        DGCN_LAUNCH(t, (k_transform_narrow<2>), dim3(min(ceil_div(rows, 256), 4096)), dim3(256), 0, s, H, ldh, rows,
                            cin, W, Z, ldz);
         return check_launch("k_transform_narrow");
     }
     const long total = (long)rows * ctot;
     const int blocks = (int)min((total + 255) / 256, (long)256 * 16);
-    hipLaunchKernelGGL(k_transform_valu, dim3(blocks), dim3(256), 0, s, H, ldh, h_const, rows, cin, W, ctot, Z, ldz);
+    DGCN_LAUNCH(t, k_transform_valu, dim3(blocks), dim3(256), 0, s, H, ldh, h_const, rows, cin, W, ctot, Z, ldz);
     return check_launch("k_transform_valu");
 }
 
