@@ -1,5 +1,7 @@
 """GPU: the drop-in modules (same names, arguments and return types as the reference) against the
 oracle and the reference-derived goldens."""
+import os
+
 import numpy as np
 import pytest
 
@@ -431,3 +433,35 @@ def test_agent_helper_methods(engine, golden):
     q = np.array([0.1, 0.7, 0.3])
     c = q.max()
     assert agent.mellowmax(q, 5.0) == pytest.approx(c + np.log(np.mean(np.exp(5.0 * (q - c)))) / 5.0)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_bench_contract(force_dist):
+    """bench.py prints ONE JSON line (the last line of stdout) with the driver's keys, the roofline and
+    cpu_baseline objects; with DGCN_BENCH_FORCE_DIST=1 the RCCL gather path runs on one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if force_dist:
+        env.update(DGCN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-seconds", "1",
+                        "--no-cpu-pool"], env=env, capture_output=True, text=True, timeout=500, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["unit"] == "graphs/s"
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0.05 < rf["frac"] < 1.0
+    assert d["value"] == pytest.approx(500 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert d["value"] > 10 * cb["value"]  # the north star's >= 10x CPU reference
