@@ -129,14 +129,25 @@ class DeviceBatch:
         import torch
         self.host = host
         self.device = torch.device(device)
-        self.graph_ptr = torch.from_numpy(host.graph_ptr).to(self.device, non_blocking=True)
-        self.row_ptr = torch.from_numpy(host.row_ptr).to(self.device, non_blocking=True)
-        # torch refuses zero-size from_numpy().to() only on some builds; keep one slot at least
-        col = host.col_idx if host.col_idx.size else np.zeros(1, dtype=np.int32)
-        self.col_idx = torch.from_numpy(col).to(self.device, non_blocking=True)
-        self.weights = None
+        # one host-to-device copy for the whole batch: [graph_ptr | row_ptr | col_idx | weights], 16-byte aligned
+        parts = [("graph_ptr", host.graph_ptr), ("row_ptr", host.row_ptr),
+                 ("col_idx", host.col_idx if host.col_idx.size else np.zeros(1, dtype=np.int32))]
         if host.weights is not None:
-            self.weights = torch.from_numpy(host.weights).to(self.device, non_blocking=True)
+            parts.append(("weights", host.weights if host.weights.size else np.zeros(1, dtype=np.float64)))
+        offs, off = {}, 0
+        for name, arr in parts:
+            offs[name] = (off, arr.nbytes)
+            off = (off + arr.nbytes + 15) & ~15
+        staging = np.empty(max(off, 16), dtype=np.uint8)
+        for name, arr in parts:
+            o, nb = offs[name]
+            staging[o:o + nb] = arr.view(np.uint8).reshape(-1)
+        self._flat = torch.from_numpy(staging).to(self.device, non_blocking=True)
+        cut = lambda name, dt: self._flat[offs[name][0]:offs[name][0] + offs[name][1]].view(dt)
+        self.graph_ptr = cut("graph_ptr", torch.int32)
+        self.row_ptr = cut("row_ptr", torch.int32)
+        self.col_idx = cut("col_idx", torch.int32)
+        self.weights = cut("weights", torch.float64)[:host.num_nodes] if host.weights is not None else None
         self.c = _lib.DgcnBatch(host.num_graphs, host.num_nodes, host.num_edges, host.max_nodes,
                                 host.max_graph_edges, self.graph_ptr.data_ptr(), self.row_ptr.data_ptr(),
                                 self.col_idx.data_ptr())

@@ -92,7 +92,10 @@ class Engine:
             return DeviceBatch(host, self.device)
 
     def check_status(self, status) -> None:
-        bits = int(status.item())
+        self.check_status_bits(int(status.item()))
+
+    @staticmethod
+    def check_status_bits(bits: int) -> None:
         if bits:
             raise _lib.DgcnError("device-side validation failed: " + _lib.fault_text(bits))
 
@@ -246,14 +249,34 @@ class Engine:
 
     def solve_buffers(self, b: DeviceBatch, want_scores: bool = True):
         """Output buffers of ``solve_fused`` for a batch, for callers that re-use them across calls
-        (a steady-state serving loop should not pay five allocations per batch)."""
+        (a steady-state serving loop should not pay five allocations per batch).  All of them are views
+        into ONE byte tensor (``"flat"``), so a caller can fetch everything with a single device-to-host
+        copy (``fetch_solve_buffers``)."""
         t = self.torch
-        n, B = b.host.num_nodes, b.host.num_graphs
-        return {"scores": t.empty((max(n, 1), 1), dtype=t.float32, device=self.device) if want_scores else None,
-                "state": t.empty(max(n, 1), dtype=t.uint8, device=self.device),
-                "rounds": t.empty(max(B, 1), dtype=t.int32, device=self.device),
-                "totals": t.empty(max(B, 1), dtype=t.float64, device=self.device),
-                "status": t.zeros(1, dtype=t.int32, device=self.device)}
+        n, B = max(b.host.num_nodes, 1), max(b.host.num_graphs, 1)
+        off, lay = 0, {}
+        for name, count, width in (("totals", B, 8), ("scores", n if want_scores else 0, 4), ("rounds", B, 4),
+                                   ("status", 1, 4), ("state", n, 1)):
+            lay[name] = (off, count * width)
+            off = (off + count * width + 15) & ~15
+        flat = t.zeros(off, dtype=t.uint8, device=self.device)
+        view = lambda name, dt: flat[lay[name][0]:lay[name][0] + lay[name][1]].view(dt)
+        return {"flat": flat, "layout": lay,
+                "scores": view("scores", t.float32).reshape(n, 1) if want_scores else None,
+                "state": view("state", t.uint8), "rounds": view("rounds", t.int32),
+                "totals": view("totals", t.float64), "status": view("status", t.int32)}
+
+    @staticmethod
+    def fetch_solve_buffers(out, num_nodes: int, num_graphs: int):
+        """One device-to-host copy of everything ``solve_fused(out=...)`` wrote -> dict of NumPy arrays
+        (state, totals, rounds, scores or None, status as int)."""
+        host = out["flat"].cpu().numpy()
+        lay = out["layout"]
+        cut = lambda name, dt: host[lay[name][0]:lay[name][0] + lay[name][1]].view(dt)
+        return {"state": cut("state", np.uint8)[:num_nodes], "totals": cut("totals", np.float64)[:num_graphs],
+                "rounds": cut("rounds", np.int32)[:num_graphs],
+                "scores": cut("scores", np.float32)[:num_nodes].reshape(-1, 1) if out["scores"] is not None else None,
+                "status": int(cut("status", np.int32)[0])}
 
     def solve_fused(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", X=None, x_const=None,
                     want_scores: bool = True, out=None):

@@ -146,6 +146,12 @@ def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str
         raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")
     use_fused = fused_ok if mode == "auto" else (mode == "fused")
     from .engine import MODE_FUSED, MODE_LAYERED
+    if use_fused and hb.num_nodes > 0:  # one launch, one device-to-host copy
+        out = eng.solve_buffers(db, True)
+        eng.solve_fused(db, dm, predict=predict, X=X, out=out)
+        res = eng.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
+        eng.check_status_bits(res.pop("status"))
+        return res
     res = eng.solve(db, dm, predict=predict, mode=MODE_FUSED if use_fused else MODE_LAYERED, X=X)
     eng.check_status(res["status"])
     return {"state": res["state"].cpu().numpy(), "totals": res["totals"].cpu().numpy(),
