@@ -87,6 +87,35 @@ class Engine:
             self._ws = self.torch.empty(max(nbytes, 256), dtype=self.torch.uint8, device=self.device)
         return self._ws
 
+    _NP = {"uint8": np.uint8, "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
+
+    def _packed(self, specs):
+        """Device arrays as views into ONE byte tensor, so a caller can fetch them all with a single
+        device-to-host copy (``fetch_packed``).  specs: (name, element count, dtype name); count 0 = absent."""
+        t = self.torch
+        off, lay = 0, {}
+        for name, count, dt in sorted(specs, key=lambda x: -np.dtype(self._NP[x[2]]).itemsize):
+            if count <= 0:
+                continue
+            nb = count * np.dtype(self._NP[dt]).itemsize
+            lay[name] = (off, nb, dt)
+            off = (off + nb + 15) & ~15
+        flat = t.zeros(max(off, 16), dtype=t.uint8, device=self.device)
+        out = {"flat": flat, "layout": lay}
+        for name, _, _ in specs:
+            if name in lay:
+                o, nb, dt = lay[name]
+                out[name] = flat[o:o + nb].view(getattr(t, dt))
+            else:
+                out[name] = None
+        return out
+
+    @classmethod
+    def fetch_packed(cls, out):
+        """One device-to-host copy -> {name: NumPy array} for everything ``_packed`` laid out."""
+        host = out["flat"].cpu().numpy()
+        return {name: host[o:o + nb].view(cls._NP[dt]) for name, (o, nb, dt) in out["layout"].items()}
+
     def upload(self, host: HostBatch) -> DeviceBatch:
         with self.torch.cuda.device(self.device):
             return DeviceBatch(host, self.device)
@@ -184,22 +213,22 @@ class Engine:
     def lgs(self, b: DeviceBatch, prio=None, scores=None, weights=None, max_rounds: int = 0, want_stats=False,
             want_overhead=False, sum_weights=None, want_totals=True, status=None):
         """Local greedy search over the batch.  Returns a dict of device tensors."""
-        t = self.torch
         n, B = b.host.num_nodes, b.host.num_graphs
-        state = t.empty(max(n, 1), dtype=t.uint8, device=self.device)
-        rounds = t.empty(max(B, 1), dtype=t.int32, device=self.device)
-        stats = t.empty((max(B, 1), 2), dtype=t.int64, device=self.device) if want_stats or want_overhead else None
-        overhead = t.empty(max(n, 1), dtype=t.int32, device=self.device) if want_overhead else None
-        totals = t.empty(max(B, 1), dtype=t.float64, device=self.device) if want_totals else None
         own = status is None
+        pk = self._packed([("totals", max(B, 1) if want_totals else 0, "float64"),
+                           ("stats", 2 * max(B, 1) if want_stats or want_overhead else 0, "int64"),
+                           ("rounds", max(B, 1), "int32"), ("overhead", max(n, 1) if want_overhead else 0, "int32"),
+                           ("status", 1 if own else 0, "int32"), ("state", max(n, 1), "uint8")])
+        state, rounds, totals, overhead = pk["state"], pk["rounds"], pk["totals"], pk["overhead"]
+        stats = pk["stats"].reshape(-1, 2) if pk["stats"] is not None else None
         if own:
-            status = t.zeros(1, dtype=t.int32, device=self.device)
+            status = pk["status"]
         p = lambda x: x.data_ptr() if x is not None else None
         _lib.check(self.lib.dgcn_lgs_batch(C.byref(b.c), p(prio), p(scores), p(weights), int(max_rounds), p(state),
                                            p(rounds), p(stats), p(overhead), p(sum_weights), p(totals), p(status),
                                            self._stream()), "dgcn_lgs_batch")
         return {"state": state[:n], "rounds": rounds[:B], "stats": stats, "overhead": overhead,
-                "totals": totals, "status": status}
+                "totals": totals, "status": status, "flat": pk["flat"], "layout": pk["layout"]}
 
     def lgs_masked(self, b: DeviceBatch, prio, init_state, num_instances: int, sum_weights=None, max_rounds: int = 0,
                    prio_stride: int = 0):
@@ -250,33 +279,22 @@ class Engine:
     def solve_buffers(self, b: DeviceBatch, want_scores: bool = True):
         """Output buffers of ``solve_fused`` for a batch, for callers that re-use them across calls
         (a steady-state serving loop should not pay five allocations per batch).  All of them are views
-        into ONE byte tensor (``"flat"``), so a caller can fetch everything with a single device-to-host
-        copy (``fetch_solve_buffers``)."""
-        t = self.torch
+        into ONE byte tensor, so everything comes back with a single device-to-host copy
+        (``fetch_solve_buffers``)."""
         n, B = max(b.host.num_nodes, 1), max(b.host.num_graphs, 1)
-        off, lay = 0, {}
-        for name, count, width in (("totals", B, 8), ("scores", n if want_scores else 0, 4), ("rounds", B, 4),
-                                   ("status", 1, 4), ("state", n, 1)):
-            lay[name] = (off, count * width)
-            off = (off + count * width + 15) & ~15
-        flat = t.zeros(off, dtype=t.uint8, device=self.device)
-        view = lambda name, dt: flat[lay[name][0]:lay[name][0] + lay[name][1]].view(dt)
-        return {"flat": flat, "layout": lay,
-                "scores": view("scores", t.float32).reshape(n, 1) if want_scores else None,
-                "state": view("state", t.uint8), "rounds": view("rounds", t.int32),
-                "totals": view("totals", t.float64), "status": view("status", t.int32)}
+        out = self._packed([("totals", B, "float64"), ("scores", n if want_scores else 0, "float32"),
+                            ("rounds", B, "int32"), ("status", 1, "int32"), ("state", n, "uint8")])
+        if want_scores:
+            out["scores"] = out["scores"].reshape(n, 1)
+        return out
 
-    @staticmethod
-    def fetch_solve_buffers(out, num_nodes: int, num_graphs: int):
-        """One device-to-host copy of everything ``solve_fused(out=...)`` wrote -> dict of NumPy arrays
-        (state, totals, rounds, scores or None, status as int)."""
-        host = out["flat"].cpu().numpy()
-        lay = out["layout"]
-        cut = lambda name, dt: host[lay[name][0]:lay[name][0] + lay[name][1]].view(dt)
-        return {"state": cut("state", np.uint8)[:num_nodes], "totals": cut("totals", np.float64)[:num_graphs],
-                "rounds": cut("rounds", np.int32)[:num_graphs],
-                "scores": cut("scores", np.float32)[:num_nodes].reshape(-1, 1) if out["scores"] is not None else None,
-                "status": int(cut("status", np.int32)[0])}
+    @classmethod
+    def fetch_solve_buffers(cls, out, num_nodes: int, num_graphs: int):
+        """-> dict of NumPy arrays (state, totals, rounds, scores or None, status as int)."""
+        h = cls.fetch_packed(out)
+        return {"state": h["state"][:num_nodes], "totals": h["totals"][:num_graphs], "rounds": h["rounds"][:num_graphs],
+                "scores": h["scores"][:num_nodes].reshape(-1, 1) if "scores" in h else None,
+                "status": int(h["status"][0])}
 
     def solve_fused(self, b: DeviceBatch, model: DeviceModel, predict: str = "mwis", X=None, x_const=None,
                     want_scores: bool = True, out=None):

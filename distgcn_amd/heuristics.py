@@ -17,7 +17,6 @@ from .api_common import get_engine, single_batch
 
 
 def _run(adj, wts, max_rounds=0, want_stats=False, want_overhead=False):
-    import torch
     eng = get_engine()
     w = np.array(wts, dtype=np.float64).flatten()
     hb = single_batch(adj)
@@ -29,19 +28,18 @@ def _run(adj, wts, max_rounds=0, want_stats=False, want_overhead=False):
         return out
     if hb.num_nodes and np.any(hb.col_idx == np.repeat(np.arange(hb.num_nodes), np.diff(hb.row_ptr))):
         raise _lib.DgcnError("adjacency has a self-loop (heuristics.py:94 would never terminate)")
+    hb.weights = w  # the priorities ride along in the batch's single host-to-device copy
     db = eng.upload(hb)
-    prio = torch.from_numpy(w).to(eng.device)
-    res = eng.lgs(db, prio=prio, max_rounds=max_rounds, want_stats=want_stats, want_overhead=want_overhead)
-    eng.check_status(res["status"])
-    state = res["state"].cpu().numpy()
+    res = eng.lgs(db, prio=db.weights, max_rounds=max_rounds, want_stats=want_stats, want_overhead=want_overhead)
+    h = eng.fetch_packed(res)  # one device-to-host copy
+    eng.check_status_bits(int(h["status"][0]))
+    state = h["state"][:w.size]
     out = {"state": state, "mwis": set(int(i) for i in np.flatnonzero(state == 1)),
-           "total": np.float64(res["totals"].cpu().numpy()[0]) if w.size else np.float64(0.0),
-           "rounds": int(res["rounds"].cpu().numpy()[0]) if w.size else 0}
+           "total": np.float64(h["totals"][0]), "rounds": int(h["rounds"][0])}
     if want_stats or want_overhead:
-        st = res["stats"].cpu().numpy()
-        out["p2p"], out["bst"] = int(st[0, 0]), int(st[0, 1])
+        out["p2p"], out["bst"] = int(h["stats"][0]), int(h["stats"][1])
     if want_overhead:
-        out["overhead"] = res["overhead"].cpu().numpy().astype(np.float64)
+        out["overhead"] = h["overhead"][:w.size].astype(np.float64)
     return out
 
 
