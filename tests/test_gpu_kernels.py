@@ -395,3 +395,45 @@ def test_every_shipped_checkpoint(engine, golden, all_models):
             same_as_reference += set(np.flatnonzero(state[n0:n1] == 1)) == set(all_models.expect(gi, name, "set").tolist())
     assert fused >= 37  # every stack whose hidden width is <= 32 takes the fused kernel
     assert same_as_reference >= total - 2, (same_as_reference, total)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_graphs_with_ties_all_paths(engine, seed):
+    """Randomised sweep: 120 small graphs per seed (1..70 vertices, density 0..0.6, isolated vertices, weights
+    drawn from a handful of values so ties are everywhere, some zero / negative): the greedy kernel, the
+    layered solve and the fused solve against the twin and the vectorised oracle."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin, ref_numpy as orc
+    rng = np.random.default_rng(1000 + seed)
+    ps, cs, ws = [], [], []
+    for _ in range(120):
+        n = int(rng.integers(1, 71))
+        p = float(rng.choice([0.0, 0.05, 0.2, 0.6]))
+        indptr, indices = datagen.er_graph(n, p, rng)
+        ps.append(indptr); cs.append(indices)
+        ws.append(rng.choice([-1.0, 0.0, 0.25, 0.5, 0.5, 1.0, 2.0], size=n))
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
+    db = engine.upload(hb)
+    # greedy kernel on the raw weights (ties broken by index)
+    res = engine.lgs(db, prio=db.weights, sum_weights=db.weights)
+    engine.check_status(res["status"])
+    st = res["state"].cpu().numpy()
+    rounds = res["rounds"].cpu().numpy()
+    for g, (n0, n1) in enumerate(hb.graph_slices()):
+        want, r = orc.lgs_vectorised(ps[g], cs[g], ws[g])
+        assert np.array_equal(st[n0:n1], want), g
+        assert rounds[g] == r
+    # whole path, both modes, positive weights (the agents' precondition)
+    hb2 = HostBatch.from_csr_lists(ps, cs, [np.abs(w) + 0.125 for w in ws])
+    db2 = engine.upload(hb2)
+    layers = datagen.random_model(4, 32, seed=seed)
+    ref = ctwin.solve(hb2, layers)
+    for mode in (0, 1):
+        out = engine.solve(db2, DeviceModel(layers, engine.device), mode=mode)
+        engine.check_status(out["status"])
+        assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), ref["scores"].view(np.uint32))
+        assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
+        assert np.array_equal(out["rounds"].cpu().numpy(), ref["rounds"])
+        assert np.allclose(out["totals"].cpu().numpy(), ref["totals"], rtol=1e-12, atol=0)
