@@ -1,0 +1,141 @@
+"""The wireless link-scheduling simulation of the reference's ``wireless_dqn_test.py`` with
+the scheduler on the GPU and every (conflict graph, load) instance advanced in lockstep.
+
+The reference walks ``timeslots`` slots per instance (``wireless_dqn_test.py:219-293``): queues grow by the
+slot's arrivals, per-link weights are built from queue lengths and link rates (``wt_sel``: ``qr`` / ``q`` /
+``qor`` / ``qrm``, ``:222-233``), a solver picks an independent set of the conflict graph, and the scheduled
+links drain ``min(queue, rate)`` packets (``:285-293``).  One solver call per slot per instance there; here one
+launch per slot for ALL instances: queues, weights, schedule and departures stay on the device.
+
+Solvers (``algo``): ``"Greedy"`` = ``local_greedy_search`` on the raw weights (``:236-238``); ``"DGCN-LGS"`` =
+``mwis_dqn_call.DQNAgent.solve_mwis`` (``:271-283``), i.e. zero-weight links are dropped from the conflict graph
+before the GCN runs (``mwis_dqn_call.py:202-207``) - a mask of the residual-graph kernel
+(``dgcn_solve_residual_batch``) instead of a re-sliced matrix.  The Gurobi denominators (``mlp_gurobi``) and the
+Poisson-disk topology generator (``graph_util``, absent from the reference) are out of scope: callers bring
+their conflict graphs; ``total_wt`` per slot is returned so that any denominator can be applied.
+Multi-channel graphs (vertex = channel * nflows + flow, ``order='F'`` at ``:234``): when several channels
+schedule the same flow the reference keeps whichever its Python set iterates last; here the highest channel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+from .api_common import as_csr, get_engine
+from .batch import HostBatch
+
+
+def make_traffic(nflows: int, timeslots: int, load: float, rate_lo: int = 0, rate_hi: int = 100, n_ch: int = 1,
+                 seed: int = 0) -> Dict[str, np.ndarray]:
+    """Arrivals and link rates of one instance, call for call what ``wireless_dqn_test.py:181-199`` draws after
+    ``np.random.seed(seed)`` (a ``RandomState(seed)`` yields the same stream).
+    -> {"arrival_pkts": [timeslots, nflows], "link_rates": int [timeslots, nflows, n_ch]}"""
+    rs = np.random.RandomState(seed)
+    arrival_rate = 0.5 * (rate_lo + rate_hi) * load
+    interarrivals = rs.exponential(1.0 / arrival_rate, (nflows, int(2 * timeslots * arrival_rate)))
+    arrival_time = np.cumsum(interarrivals, axis=1)
+    acc_pkts = np.zeros(shape=(nflows, timeslots))
+    for t in range(0, timeslots):
+        acc_pkts[:, t] = np.count_nonzero(arrival_time < t, axis=1)
+    arrival_pkts = np.diff(acc_pkts, prepend=0).transpose()
+    link_rates = rs.normal(0.5 * (rate_lo + rate_hi), 0.25 * (rate_hi - rate_lo), size=[timeslots, nflows, n_ch])
+    link_rates = link_rates.astype(int)
+    link_rates[link_rates < rate_lo] = rate_lo
+    link_rates[link_rates > rate_hi] = rate_hi
+    return {"arrival_pkts": arrival_pkts, "link_rates": link_rates}
+
+
+def slot_weights(queue, rates, wt_sel: str):
+    """``wireless_dqn_test.py:222-233`` for one slot; works on NumPy arrays and torch tensors alike."""
+    if wt_sel == "qr":
+        return queue * rates
+    if wt_sel == "q":
+        return queue * 1.0
+    if wt_sel == "qor":
+        return queue / rates
+    if wt_sel == "qrm":
+        return np.minimum(queue, rates) if isinstance(queue, np.ndarray) else queue.minimum(rates)
+    raise ValueError("wt_sel must be one of qr, q, qor, qrm (the reference's random weights are unseeded per slot)")
+
+
+def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: str = "DGCN-LGS", agent=None,
+             wt_sel: str = "qr") -> List[Dict[str, np.ndarray]]:
+    """Run all instances (``adjs[i]``: conflict graph on ``nflows_i * n_ch`` vertices, ``traffics[i]`` from
+    ``make_traffic``) for their common number of slots.  -> per instance ``{"queue": [T, nflows], "depart":
+    [T, nflows], "total_wt": [T], "scheduled": [T]}`` (queue lengths AFTER the slot's departures, as the
+    reference's ``queue_mtx_dict``)."""
+    import torch
+    if algo not in ("Greedy", "DGCN-LGS"):
+        raise ValueError("algo must be 'Greedy' or 'DGCN-LGS'")
+    if algo == "DGCN-LGS" and agent is None:
+        raise ValueError("DGCN-LGS needs an agent (mwis_dqn_call.DQNAgent)")
+    eng = get_engine()
+    t = torch
+    csrs = [as_csr(a) for a in adjs]
+    T = int(traffics[0]["arrival_pkts"].shape[0])
+    chans = [int(tr["link_rates"].shape[2]) for tr in traffics]  # channels may differ between instances
+    flows = [int(tr["arrival_pkts"].shape[1]) for tr in traffics]
+    for c, f, k, tr in zip(csrs, flows, chans, traffics):
+        if c.shape[0] != f * k or tr["arrival_pkts"].shape[0] != T or tr["link_rates"].shape[:2] != (T, f):
+            raise ValueError("conflict graph / traffic shapes disagree")
+    hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs], [c.indices.astype(np.int64) for c in csrs],
+                                  [np.zeros(c.shape[0]) for c in csrs])
+    db = eng.upload(hb)
+    foff = np.concatenate([[0], np.cumsum(flows)])
+    # vertex -> (global flow, channel, instance); vertex v of instance i is channel v // F_i, flow v % F_i
+    vflow = np.concatenate([foff[i] + np.arange(f * k) % f for i, (f, k) in enumerate(zip(flows, chans))])
+    vch = np.concatenate([np.arange(f * k) // f for f, k in zip(flows, chans)])
+    vinst = np.concatenate([np.full(f * k, i) for i, (f, k) in enumerate(zip(flows, chans))])
+    arr = t.from_numpy(np.concatenate([tr["arrival_pkts"] for tr in traffics], axis=1).astype(np.float64)).to(eng.device)
+    rates = t.from_numpy(np.concatenate([tr["link_rates"].transpose(0, 2, 1).reshape(T, -1) for tr in traffics],
+                                        axis=1).astype(np.float64)).to(eng.device)  # [T, vertices], vertex order
+    vflow_d = t.from_numpy(vflow).to(eng.device)
+    vinst_d = t.from_numpy(vinst).to(eng.device)
+    ch_masks = [t.from_numpy(vch == c).to(eng.device) for c in range(max(chans))]
+    F, I = int(foff[-1]), len(flows)
+    q = t.zeros(F, dtype=t.float64, device=eng.device)
+    queue_out = t.zeros((T, F), dtype=t.float64, device=eng.device)
+    dep_out = t.zeros((T, F), dtype=t.float64, device=eng.device)
+    tot_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
+    cnt_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
+    dm = agent.model.device_model(eng) if algo == "DGCN-LGS" else None
+    if dm is not None and not eng.solve_supported(db, dm):
+        raise NotImplementedError("conflict graphs / model outside the fused kernel (<= 512 vertices, hidden <= 32)")
+    out = eng.solve_buffers(db, False) if dm is not None else None
+    state = t.zeros(max(hb.num_nodes, 1), dtype=t.uint8, device=eng.device)
+    for ts in range(1, T):
+        q += arr[ts]
+        w = slot_weights(q[vflow_d], rates[ts], wt_sel)
+        db.weights.copy_(w)
+        if algo == "Greedy":
+            res = eng.lgs(db, prio=db.weights, want_totals=False)
+            st = res["state"]
+            status = res["status"]
+        else:
+            state.copy_((w <= 0).to(t.uint8) * 2)  # zero-weight links leave the graph (mwis_dqn_call.py:202-207)
+            res = eng.solve_residual(db, dm, state, predict=agent.flags.predict, greedy=eng.GREEDY_ROUNDS, max_rounds=0,
+                                     max_steps=1, out=out)
+            st, status = state[:hb.num_nodes], res["status"]
+        sel = st == 1
+        cap = t.zeros(F, dtype=t.float64, device=eng.device)
+        for m in ch_masks:  # ascending channel: the highest scheduled channel of a flow sets its capacity
+            mm = sel & m
+            cap[vflow_d[mm]] = rates[ts][mm]
+        dep = t.minimum(q, cap)
+        q -= dep
+        queue_out[ts] = q
+        dep_out[ts] = dep
+        tot_out[ts].index_add_(0, vinst_d[sel], w[sel])
+        cnt_out[ts].index_add_(0, vinst_d[sel], t.ones_like(w[sel]))
+    eng.check_status(status)
+    queue_h, dep_h, tot_h, cnt_h = (x.cpu().numpy() for x in (queue_out, dep_out, tot_out, cnt_out))
+    return [{"queue": queue_h[:, foff[i]:foff[i + 1]], "depart": dep_h[:, foff[i]:foff[i + 1]], "total_wt": tot_h[:, i],
+             "scheduled": cnt_h[:, i].astype(np.int64)} for i in range(I)]
+
+
+def summarize(result: Dict[str, np.ndarray]) -> Dict[str, float]:
+    """The per-run metrics the reference writes to its CSV (``wireless_dqn_test.py:303-336``)."""
+    qm = result["queue"]
+    return {"avg_queue_len": float(np.mean(np.mean(qm, axis=1))), "50p_queue_len": float(np.mean(np.median(qm, axis=1))),
+            "95p_queue_len": float(np.percentile(qm, 95)), "5p_queue_len": float(np.percentile(qm, 5))}

@@ -465,3 +465,48 @@ def test_bench_contract(force_dist):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert d["value"] > 10 * cb["value"]  # the north star's >= 10x CPU reference
+
+
+@pytest.mark.parametrize("algo", ["Greedy", "DGCN-LGS"])
+def test_wireless_simulation_matches_restatement(engine, algo):
+    """the slot loop of wireless_dqn_test.py:219-293, all instances in lockstep on the device,
+    against the per-instance CPU restatement (oracle/ref_wireless.py) with the twin as its scheduler."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen, wireless
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ctwin, ref_numpy as orc, ref_wireless
+    rng = np.random.default_rng(77)
+    agent = DQNAgent(1, flags=_flags(num_layer=3))
+    layers = agent.model.layers
+    adjs, traffics = [], []
+    for i, (nflows, n_ch, p) in enumerate([(30, 1, 0.15), (45, 1, 0.08), (20, 2, 0.1)]):
+        indptr, indices = datagen.er_graph(nflows * n_ch, p, rng)
+        adjs.append(sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(nflows * n_ch,) * 2))
+        traffics.append(wireless.make_traffic(nflows, 25, 0.03, n_ch=n_ch, seed=i))
+
+    def greedy_fn(adj, w):
+        st, _ = orc.lgs_vectorised(adj.indptr, adj.indices, w)
+        return set(np.flatnonzero(st == 1).tolist())
+
+    def dgcn_fn(adj, w):  # mwis_dqn_call.py:198-241: prune zero weights, GCN, priority, local greedy, map back
+        keep = np.flatnonzero(w > 0)
+        if keep.size == 0:
+            return set()
+        sub = sp.csr_matrix(adj[keep][:, keep])
+        sub.sort_indices()
+        hb = HostBatch.from_csr_lists([sub.indptr.astype(np.int64)], [sub.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        prio = ctwin.forward(lap, layers, hb.num_nodes)[:, 0].astype(np.float64) * w[keep]
+        st, _ = orc.lgs_vectorised(sub.indptr, sub.indices, prio)
+        return set(keep[np.flatnonzero(st == 1)].tolist())
+
+    got = wireless.simulate(adjs, traffics, algo=algo, agent=agent, wt_sel="qr")
+    for i in range(len(adjs)):
+        want = ref_wireless.simulate_one(adjs[i], traffics[i]["arrival_pkts"], traffics[i]["link_rates"],
+                                         greedy_fn if algo == "Greedy" else dgcn_fn, "qr")
+        assert np.array_equal(got[i]["queue"], want["queue"]), i
+        assert np.array_equal(got[i]["depart"], want["depart"]), i
+        assert np.allclose(got[i]["total_wt"], want["total_wt"], rtol=1e-12)
+        assert got[i]["queue"].max() > 0 and got[i]["depart"].sum() > 0
+    assert set(wireless.summarize(got[0])) == {"avg_queue_len", "50p_queue_len", "95p_queue_len", "5p_queue_len"}

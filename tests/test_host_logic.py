@@ -101,3 +101,29 @@ def test_mat_loader_when_reference_available():
     d = harness.load_mat_folder(path, limit=3)
     assert len(d["adjs"]) == 3 and d["adjs"][0].shape[0] == d["weights"][0].size
     assert d["greedy_utility"][0] > 0 and d["adjs"][0].format == "csr"
+
+
+def test_wireless_traffic_follows_reference_draws():
+    """make_traffic draws what wireless_dqn_test.py:181-199 draws after np.random.seed(seed)."""
+    from distgcn_amd import wireless
+    tr = wireless.make_traffic(7, 20, 0.05, seed=3)
+    np.random.seed(3)
+    arrival_rate = 0.5 * (0 + 100) * 0.05
+    inter = np.random.exponential(1.0 / arrival_rate, (7, int(2 * 20 * arrival_rate)))
+    at = np.cumsum(inter, axis=1)
+    acc = np.zeros((7, 20))
+    for t in range(20):
+        acc[:, t] = np.count_nonzero(at < t, axis=1)
+    lr = np.random.normal(50, 25, size=[20, 7, 1]).astype(int)
+    lr[lr < 0] = 0
+    lr[lr > 100] = 100
+    assert np.array_equal(np.diff(acc, prepend=0).transpose(), tr["arrival_pkts"])
+    assert np.array_equal(lr, tr["link_rates"])
+    # the restated slot loop conserves packets: arrivals = departures + backlog
+    from oracle import ref_wireless
+    import scipy.sparse as sp
+    adj = sp.csr_matrix(np.triu(np.random.RandomState(1).rand(7, 7) < 0.3, 1).astype(float))
+    adj = adj + adj.T
+    res = ref_wireless.simulate_one(adj, tr["arrival_pkts"], tr["link_rates"],
+                                    lambda a, w: set(np.flatnonzero(w == w.max()).tolist()[:1]), "qr")
+    assert np.isclose(tr["arrival_pkts"][1:].sum(), res["depart"].sum() + res["queue"][-1].sum())
