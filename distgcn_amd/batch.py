@@ -100,10 +100,11 @@ class HostBatch:
         return HostBatch.from_csr_lists(ps, cs, ws if self.weights is not None else None)
 
     def size_buckets(self, lds_budget: int = 80 * 1024, hidden: int = 32):
-        """Group graphs by the LDS image the fused kernel needs (``csrc/fused.hip``): graphs that fit
-        two-per-CU in one bucket, the rest in another.  A launch sizes LDS for its largest graph, so a
-        few big graphs would otherwise halve the residency of all the small ones.  Returns a list of
-        index arrays (a single one when the batch is homogeneous)."""
+        """A launch of the fused kernel sizes LDS for its largest graph (``csrc/fused.hip``), so a FEW big
+        graphs would halve (or worse) the residency of many small ones: then the two groups go in separate
+        launches.  When the big graphs are a sizeable share of the batch the launch time is their latency
+        anyway and one launch is faster (measured on the BA test2 mix: 477 us vs 497 us), so the batch is
+        only split when they are under a quarter of it.  Returns a list of index arrays."""
         if self.num_graphs == 0:
             return [np.zeros(0, np.int64)]
         sizes = np.diff(self.graph_ptr).astype(np.int64)
@@ -111,7 +112,7 @@ class HostBatch:
         need = np.maximum(sizes, 64) * hidden * 4 * 2 + (nnz + 2 * sizes + 6) * 6 + sizes * 6 + 64
         small = np.flatnonzero(need <= lds_budget)
         big = np.flatnonzero(need > lds_budget)
-        if small.size == 0 or big.size == 0 or min(small.size, big.size) < 32:
+        if min(small.size, big.size) < 32 or big.size * 4 > self.num_graphs:
             return [np.arange(self.num_graphs)]
         return [small, big]
 

@@ -188,11 +188,18 @@ def test_evaluation_harness(engine, golden, tmp_path):
 
 
 def test_mixed_size_batch_is_bucketed(engine):
-    """A BA test2 mix is solved as two launches (small / large LDS images) with identical results."""
+    """A few large graphs among many small ones are solved as two launches (small / large LDS images) with
+    identical results."""
     from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
     from distgcn_amd.mwis_dqn_call import DQNAgent, solve_host_batch
     from oracle import ctwin
-    hb = datagen.ba_test2_batch(100)
+    rng = np.random.default_rng(4)
+    ps, cs, ws = [], [], []
+    for n in [60] * 160 + [300] * 40:
+        p, c = datagen.er_graph(n, 0.1, rng)
+        ps.append(p); cs.append(c); ws.append(rng.random(n))
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
     assert len(hb.size_buckets()) == 2
     agent = DQNAgent(1, flags=_flags())
     res = solve_host_batch(engine, agent.model, hb)

@@ -79,10 +79,20 @@ def test_host_utils_match_goldens(golden):
     assert np.array_equal(dense, golden.supports["g03_feat_rownorm"])
 
 
+def _few_big_many_small():
+    rng = np.random.default_rng(4)
+    ps, cs, ws = [], [], []
+    for n in [60] * 160 + [300] * 40:
+        p, c = datagen.er_graph(n, 0.1, rng)
+        ps.append(p); cs.append(c); ws.append(rng.random(n))
+    return HostBatch.from_csr_lists(ps, cs, ws)
+
+
 def test_size_buckets_and_select():
-    hb = datagen.ba_test2_batch(100)
+    assert len(datagen.ba_test2_batch(100).size_buckets()) == 1  # 44 % large graphs: one launch is faster
+    hb = _few_big_many_small()
     buckets = hb.size_buckets()
-    assert len(buckets) == 2 and sorted(np.concatenate(buckets).tolist()) == list(range(100))
+    assert len(buckets) == 2 and sorted(np.concatenate(buckets).tolist()) == list(range(200))
     sub = hb.select(buckets[1])
     assert sub.num_graphs == buckets[1].size
     g = int(buckets[1][3])
