@@ -536,11 +536,12 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
         const int total = e1 - e0;
-        for (int base = threadIdx.x; base < total; base += BLOCK * 4) {
-            int c[4];
-            float gv[4];
+        constexpr int kP0 = 8;  // column loads in flight per thread
+        for (int base = threadIdx.x; base < total; base += BLOCK * kP0) {
+            int c[kP0];
+            float gv[kP0];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kP0; ++i) {
                 const int j = base + i * BLOCK;
                 c[i] = 0;
                 gv[i] = 0.f;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kP0; ++i) {
                 const int j = base + i * BLOCK;
                 if (j >= total) continue;
                 int lo = 0, hi = ng;  // last row whose start is <= j
@@ -619,12 +620,25 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             const int v = threadIdx.x;
             float z0 = 0.f, z1 = 0.f;
             if (v < ng) {
-                for (int k = 0; k < L.cin; ++k) {
-                    float h;
-                    if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : xfill;
-                    else h = bufA[swz(v, k)];
-                    z0 = fmaf(h, L.W[k * 2 + 0], z0);
-                    z1 = fmaf(h, L.W[k * 2 + 1], z1);
+                if (l > 0 && L.cin == kHid) {  // the row as 8 swizzled 16-byte chunks, same k order
+#pragma unroll
+                    for (int c = 0; c < kHid / 4; ++c) {
+                        const float4 h = *reinterpret_cast<const float4*>(bufA + v * kHid + ((c ^ (v & 7)) << 2));
+                        const float hk[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            z0 = fmaf(hk[i], L.W[(4 * c + i) * 2 + 0], z0);
+                            z1 = fmaf(hk[i], L.W[(4 * c + i) * 2 + 1], z1);
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < L.cin; ++k) {
+                        float h;
+                        if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : xfill;
+                        else h = bufA[swz(v, k)];
+                        z0 = fmaf(h, L.W[k * 2 + 0], z0);
+                        z1 = fmaf(h, L.W[k * 2 + 1], z1);
+                    }
                 }
                 bufB[v] = z1;
             }
@@ -633,7 +647,17 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 const unsigned ri = rinfo[v];
                 const int rs = ri & 0xffff, re = rs + (ri >> 16);
                 float acc = 0.f;
-                for (int j = rs; j < re; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
+                int j = rs;
+                for (; j + 4 <= re; j += 4) {  // loads of four entries in flight, chain order unchanged
+                    const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
+                    const float y0 = bufB[words[j] >> 7], y1 = bufB[words[j + 1] >> 7];
+                    const float y2 = bufB[words[j + 2] >> 7], y3 = bufB[words[j + 3] >> 7];
+                    acc = fmaf(a0, y0, acc);
+                    acc = fmaf(a1, y1, acc);
+                    acc = fmaf(a2, y2, acc);
+                    acc = fmaf(a3, y3, acc);
+                }
+                for (; j < re; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
                 float o = z0 + acc;
                 if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
