@@ -818,8 +818,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         bad = (p != p);
         pr[threadIdx.x] = p;
     }
+    // (the flag words are next written by the first greedy round, behind the barrier that follows the ranks)
     const bool any_bad = block_or<BLOCK>(bad != 0, wflags);
-    __syncthreads();  // flag words are re-used by the greedy rounds
     if (any_bad) {
         if (threadIdx.x == 0) {
             atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
