@@ -10,8 +10,9 @@ os.makedirs(DST, exist_ok=True)
 
 
 def first(pattern):
+    """Newest match: gpurun MERGES each call's output into gpurun_out/, so older runs linger next to it."""
     hits = glob.glob(pattern, recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 for mode in ("fused", "layered"):
