@@ -29,6 +29,8 @@
 //
 // Shapes handled here: first layer any width -> 32 (VALU), hidden layers 32 -> 32 (MFMA), last layer
 // -> 1; or a single layer F -> 1.  Anything else returns DGCN_ERR_UNSUPPORTED and the caller uses mode 0.
+#include <atomic>
+
 #include "common.h"
 
 namespace dgcn {
@@ -1034,9 +1036,17 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
 template <bool MASKED, bool GVALS, int BLOCK>
 static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+        // raise the kernel's dynamic-LDS limit once per device and size (the attribute call is a driver round trip)
+        static std::atomic<size_t> reserved[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t>& have = reserved[dev & 63];
+        if (lds > have.load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+            if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+            have.store(kLdsLimit, std::memory_order_relaxed);
+        }
     }
     TimedLaunch t(family, s);
     DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
