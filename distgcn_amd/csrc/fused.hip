@@ -201,7 +201,8 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
                                                  const unsigned* rinfo, const unsigned short* perm,
-                                                 const float* vals, const unsigned short* words) {
+                                                 const float* vals, const unsigned short* words, unsigned wmask) {
+    // wmask: 0xffffffff, except in DGCN_DIAG experiments that redirect every gather to a few rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = lane >> 3, q = lane & 7;
     constexpr int kWaves = BLOCK / 64;
@@ -223,14 +224,21 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
             float2 a2[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#ifdef DGCN_DIAG
+                if (wmask == 0x3f0u) {  // experiment: no metadata reads (synthetic words / values from registers)
+                    w[i] = (unsigned)(((j + 2 * i) & 127) << 7) | (unsigned)(((j + 2 * i + 1) & 127) << 23);
+                    a2[i] = make_float2(0.01f, -0.01f);
+                    continue;
+                }
+#endif
                 w[i] = *reinterpret_cast<const unsigned*>(words + j + 2 * i);
                 a2[i] = *reinterpret_cast<const float2*>(vals + j + 2 * i);
             }
             float4 z[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                z[2 * i] = lds_chunk((w[i] & 0xffffu) ^ qx);
-                z[2 * i + 1] = lds_chunk((w[i] >> 16) ^ qx);
+                z[2 * i] = lds_chunk((w[i] & 0xffffu & wmask) ^ qx);
+                z[2 * i + 1] = lds_chunk(((w[i] >> 16) & wmask) ^ qx);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -243,8 +251,8 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
             const unsigned w1 = *reinterpret_cast<const unsigned*>(words + j + 2);
             const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
             const float2 a23 = *reinterpret_cast<const float2*>(vals + j + 2);
-            const float4 z0 = lds_chunk((w0 & 0xffffu) ^ qx), z1 = lds_chunk((w0 >> 16) ^ qx);
-            const float4 z2 = lds_chunk((w1 & 0xffffu) ^ qx), z3 = lds_chunk((w1 >> 16) ^ qx);
+            const float4 z0 = lds_chunk((w0 & 0xffffu & wmask) ^ qx), z1 = lds_chunk(((w0 >> 16) & wmask) ^ qx);
+            const float4 z2 = lds_chunk((w1 & 0xffffu & wmask) ^ qx), z3 = lds_chunk(((w1 >> 16) & wmask) ^ qx);
             acc = fma4(a01.x, z0, acc);
             acc = fma4(a01.y, z1, acc);
             acc = fma4(a23.x, z2, acc);
@@ -254,12 +262,12 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
         if (j + 2 <= re) {
             const unsigned w0 = *reinterpret_cast<const unsigned*>(words + j);
             const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float4 z0 = lds_chunk((w0 & 0xffffu) ^ qx), z1 = lds_chunk((w0 >> 16) ^ qx);
+            const float4 z0 = lds_chunk((w0 & 0xffffu & wmask) ^ qx), z1 = lds_chunk(((w0 >> 16) & wmask) ^ qx);
             acc = fma4(a01.x, z0, acc);
             acc = fma4(a01.y, z1, acc);
             j += 2;
         }
-        if (j < re) acc = fma4(vals[j], lds_chunk((unsigned)words[j] ^ qx), acc);
+        if (j < re) acc = fma4(vals[j], lds_chunk(((unsigned)words[j] & wmask) ^ qx), acc);
         float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
         const float4 z = *own;
         float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
@@ -609,7 +617,15 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words);
+            #ifdef DGCN_DIAG
+            // diag bits 8..10: 1 = all gathers hit row 0, 2 = rows 0/1 only (parity conflicts kept), 3 = rows 0..3,
+            // 4 = full 8-entry trips take synthetic metadata from registers (no metadata reads)
+            const unsigned wmask = ((a.diag >> 8) & 7) == 1 ? 0x70u : ((a.diag >> 8) & 7) == 2 ? 0xf0u
+                                   : ((a.diag >> 8) & 7) == 3 ? 0x1f0u : ((a.diag >> 8) & 7) == 4 ? 0x3f0u : 0xffffffffu;
+#else
+            constexpr unsigned wmask = 0xffffffffu;
+#endif
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask);
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
