@@ -610,8 +610,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, l == 0 ? 3 : 5, tclk);  // transform body (wave 0)
-            // fetch the next hidden layer's weights now; they land while this layer gathers
-            if (l >= 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
             STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
 #ifdef DGCN_DIAG
@@ -630,6 +628,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
+            // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
+            // their 32 registers are not live during the gather phase
+            if (l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
         } else {
