@@ -368,7 +368,8 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
 }
 
 template <bool MASKED, bool GVALS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
+// (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
