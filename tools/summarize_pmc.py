@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc/* (tools/collect_pmc.sh) -> profiles/<tag>_fused_pmc.txt: per-launch sums of each counter for k_fused."""
+import collections, csv, glob, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_fused" not in r["Kernel_Name"]:
+            continue
+        acc[r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[r["Counter_Name"]].add(r["Dispatch_Id"])
+lines = ["k_fused<false,false,512>, 500 ER graphs N=200, l=20: counter sums per launch (all XCDs / SEs / CUs)"]
+for k in sorted(acc):
+    lines.append("%-32s %16.0f" % (k, acc[k] / max(len(cnt[k]), 1)))
+open(os.path.join(ROOT, "profiles", "%s_fused_pmc.txt" % TAG), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
