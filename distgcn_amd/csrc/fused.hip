@@ -1075,7 +1075,16 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
 // (at 128 VGPRs both fit the register file exactly).  DGCN_FUSED_BLOCK=512|1024 overrides (tuning / tests).
 template <bool MASKED, bool GVALS>
 static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
-    bool big = lds > kLdsLimit / 2 && a.max_nodes >= 128;
+    // ... and so does every graph of a batch that has no more graphs than the device has CUs
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int ncu = cus[dev & 63].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
+        cus[dev & 63].store(ncu, std::memory_order_relaxed);
+    }
+    bool big = (lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128;
     if (const char* e = getenv("DGCN_FUSED_BLOCK")) big = atoi(e) == kFusedBlockBig && a.max_nodes >= 128;
     return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig>(a, B, lds, family, s)
                : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
