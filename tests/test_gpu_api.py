@@ -517,3 +517,58 @@ def test_wireless_simulation_matches_restatement(engine, algo):
         assert np.allclose(got[i]["total_wt"], want["total_wt"], rtol=1e-12)
         assert got[i]["queue"].max() > 0 and got[i]["depart"].sum() > 0
     assert set(wireless.summarize(got[0])) == {"avg_queue_len", "50p_queue_len", "95p_queue_len", "5p_queue_len"}
+
+
+def _example_inputs():
+    """The inputs examples/solve_batch.cpp builds (same 64-bit LCG stream)."""
+    from distgcn_amd.batch import HostBatch
+    state = [12345]
+
+    def nxt():
+        state[0] = (state[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return (state[0] >> 40) / 16777216.0
+
+    ps, cs, ws = [], [], []
+    for n, dens in ((40, 0.15), (25, 0.3)):
+        adj = [[] for _ in range(n)]
+        for i in range(n):
+            for j in range(i + 1, n):
+                if nxt() < dens:
+                    adj[i].append(j)
+                    adj[j].append(i)
+        ps.append(np.concatenate([[0], np.cumsum([len(a) for a in adj])]).astype(np.int64))
+        cs.append(np.array([j for a in adj for j in a], dtype=np.int64))
+        ws.append(np.array([0.05 + nxt() for _ in range(n)]))
+    dims = [1, 32, 32, 1]
+    layers = []
+    for l in range(3):
+        lim = np.sqrt(6.0 / (dims[l] + dims[l + 1]))
+        flat = np.array([np.float32((2.0 * nxt() - 1.0) * lim) for _ in range(dims[l] * 2 * dims[l + 1])], dtype=np.float32)
+        cat = flat.reshape(dims[l], 2 * dims[l + 1])
+        layers.append({"weights": [cat[:, :dims[l + 1]].copy(), cat[:, dims[l + 1]:].copy()], "bias": None,
+                       "act": "linear" if l == 2 else "leaky_relu"})
+    return HostBatch.from_csr_lists(ps, cs, ws), layers
+
+
+def test_native_cpp_caller_of_the_c_abi():
+    """examples/solve_batch (C++, HIP runtime + include/dgcn.h, no Python / torch in the process) against the twin."""
+    import subprocess
+    from oracle import ctwin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "solve_batch")
+    if not os.path.isfile(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    hb, layers = _example_inputs()
+    ref = ctwin.solve(hb, layers)
+    assert lines[0].split() == ["dgcn", "100"]
+    for g, (n0, n1) in enumerate(hb.graph_slices()):
+        tok = lines[1 + g].split()
+        assert tok[:2] == ["graph", str(g)] and int(tok[3]) == int(ref["rounds"][g])
+        assert float(tok[5]) == pytest.approx(ref["totals"][g], rel=1e-12)
+        assert [int(x) for x in tok[7:]] == np.flatnonzero(ref["state"][n0:n1] == 1).tolist()
+    scores = np.array([float(x) for x in lines[3].split()[1:]], dtype=np.float32)
+    assert np.array_equal(scores.view(np.uint32), ref["scores"][:, 0].view(np.uint32))
