@@ -22,18 +22,23 @@ def get_engine(device=None):
 
 
 def as_csr(adj):
-    a = sp.csr_matrix(adj)
+    """Canonical CSR (sorted rows, no duplicates) of any SciPy matrix / array.  A matrix that already is
+    canonical CSR is returned AS IS (callers never modify the result in place)."""
+    if sp.isspmatrix_csr(adj) and adj.has_canonical_format:
+        a = adj
+    else:
+        a = sp.csr_matrix(adj)
+        a.sum_duplicates()
+        a.sort_indices()
     if a.shape[0] != a.shape[1]:
         raise ValueError("adjacency must be square, got %s" % (a.shape,))
-    a.sum_duplicates()
-    a.sort_indices()
     return a
 
 
 def single_batch(adj, weights=None) -> HostBatch:
     a = as_csr(adj)
     w = None if weights is None else [np.asarray(weights, dtype=np.float64).ravel()]
-    return HostBatch.from_csr_lists([a.indptr.astype(np.int64)], [a.indices.astype(np.int64)], w)
+    return HostBatch.from_csr_lists([a.indptr], [a.indices], w)
 
 
 def tuple_to_dense(tup, dtype=np.float32):
@@ -75,7 +80,7 @@ def state_to_device(engine, state, input_dim):
     off.setdiag(0)
     off = sp.csr_matrix(off)
     off.eliminate_zeros()
-    db = engine.upload(HostBatch.from_csr_lists([off.indptr.astype(np.int64)], [off.indices.astype(np.int64)]))
+    db = engine.upload(HostBatch.from_csr_lists([off.indptr], [off.indices]))
     t = torch
     row_ptr = t.from_numpy(lap.indptr.astype(np.int32)).to(engine.device)
     col = t.from_numpy(lap.indices.astype(np.int32)).to(engine.device)

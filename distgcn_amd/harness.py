@@ -39,7 +39,7 @@ def greedy_utilities(adjs: Sequence, wts_list: Sequence) -> np.ndarray:
     import torch
     eng = get_engine()
     csrs = [as_csr(a) for a in adjs]
-    hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs], [c.indices.astype(np.int64) for c in csrs],
+    hb = HostBatch.from_csr_lists([c.indptr for c in csrs], [c.indices for c in csrs],
                                   [np.asarray(w, dtype=np.float64).ravel() for w in wts_list])
     db = eng.upload(hb)
     res = eng.lgs(db, prio=db.weights, sum_weights=db.weights)

@@ -107,8 +107,8 @@ class DQNAgent:
         """Solve many graphs in one launch.  Returns a list of ``(set, total_wt, 1.0)`` in input order."""
         eng = get_engine()
         pruned = [self._prune(a, w) for a, w in zip(adjs, wts_list)]
-        hb = HostBatch.from_csr_lists([p[0].indptr.astype(np.int64) for p in pruned],
-                                      [p[0].indices.astype(np.int64) for p in pruned], [p[1] for p in pruned])
+        hb = HostBatch.from_csr_lists([p[0].indptr for p in pruned],
+                                      [p[0].indices for p in pruned], [p[1] for p in pruned])
         res = solve_host_batch(eng, self.model, hb, self.flags.predict, mode)
         out = []
         for g, (n0, n1) in enumerate(hb.graph_slices()):

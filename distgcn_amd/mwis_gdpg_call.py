@@ -86,8 +86,8 @@ class MWISSolver(object):
 
     def solve_mwis_batch(self, adjs: Sequence, wts_list: Sequence, mode: str = "auto") -> List[tuple]:
         csrs = [as_csr(a) for a in adjs]
-        hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs],
-                                      [c.indices.astype(np.int64) for c in csrs],
+        hb = HostBatch.from_csr_lists([c.indptr for c in csrs],
+                                      [c.indices for c in csrs],
                                       [np.asarray(w, dtype=np.float64).reshape(-1, self.feature_size)[:, 0] for w in wts_list])
         res = solve_host_batch(get_engine(), self.model, hb, self.flags.predict, mode, X=self._features(hb))
         out = []
@@ -105,7 +105,7 @@ class MWISSolver(object):
     def _residual_scores(self, adj_nn, wts_nn):
         """(DeviceBatch, device scores [n,1]) of one residual graph: ``makestate`` + ``act``."""
         eng = get_engine()
-        hb = HostBatch.from_csr_lists([adj_nn.indptr.astype(np.int64)], [adj_nn.indices.astype(np.int64)],
+        hb = HostBatch.from_csr_lists([adj_nn.indptr], [adj_nn.indices],
                                       [np.asarray(wts_nn, dtype=np.float64)[:, 0]])
         db = eng.upload(hb)
         dm = self.model.device_model(eng)
@@ -138,8 +138,8 @@ class MWISSolver(object):
         the shapes are outside the fused kernel."""
         import torch
         csrs = [as_csr(a) for a in adjs]
-        hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs],
-                                      [c.indices.astype(np.int64) for c in csrs],
+        hb = HostBatch.from_csr_lists([c.indptr for c in csrs],
+                                      [c.indices for c in csrs],
                                       [np.asarray(w, dtype=np.float64).reshape(-1, self.feature_size)[:, 0] for w in wts_list])
         eng = get_engine()
         db = eng.upload(hb)
@@ -231,7 +231,7 @@ class MWISSolver(object):
                 eng, db, scores = self._residual_scores(adj_nn, wts_nn)
                 act_vals = scores.cpu().numpy().flatten()
             else:
-                hb = HostBatch.from_csr_lists([adj_nn.indptr.astype(np.int64)], [adj_nn.indices.astype(np.int64)],
+                hb = HostBatch.from_csr_lists([adj_nn.indptr], [adj_nn.indices],
                                               [wts_nn[:, 0]])
                 db = eng.upload(hb)
                 act_vals = full_scores.flatten()[rmap]

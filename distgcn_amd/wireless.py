@@ -79,7 +79,7 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
     for c, f, k, tr in zip(csrs, flows, chans, traffics):
         if c.shape[0] != f * k or tr["arrival_pkts"].shape[0] != T or tr["link_rates"].shape[:2] != (T, f):
             raise ValueError("conflict graph / traffic shapes disagree")
-    hb = HostBatch.from_csr_lists([c.indptr.astype(np.int64) for c in csrs], [c.indices.astype(np.int64) for c in csrs],
+    hb = HostBatch.from_csr_lists([c.indptr for c in csrs], [c.indices for c in csrs],
                                   [np.zeros(c.shape[0]) for c in csrs])
     db = eng.upload(hb)
     foff = np.concatenate([[0], np.cumsum(flows)])
