@@ -192,3 +192,25 @@ def test_twin_on_every_shipped_checkpoint(golden, all_models):
             bar = max(1e-5, 2.0 * np.abs(f32 - f64).max())
             assert np.abs(got - f64).max() <= bar, (name, gi)
     assert {1, 2, 3, 4, 8, 16, 32, 48, 64} <= seen_widths
+
+
+def test_known_answers_of_100_shipped_graphs(dataset100):
+    """greedy_utility stored by the reference in its .mat files (Data_Generation.py:149-153) and the imported
+    reference's local_greedy_search_count on the raw weights, for 50 ER + 50 BA test2 graphs: the NumPy oracle,
+    its vectorised form and the C twin all reproduce them."""
+    from oracle import ctwin
+    import scipy.sparse as sp
+    z = dataset100.z
+    hb = dataset100.host_batch()
+    tw = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, hb.weights, sum_weights=hb.weights, want_stats=False)
+    assert tw["fault"] == 0
+    assert np.allclose(tw["totals"], z["greedy_utility"], rtol=1e-9, atol=0)
+    assert np.allclose(tw["totals"], z["lgs_total"], rtol=1e-12, atol=0)
+    assert np.array_equal(tw["rounds"], z["lgs_rounds"])
+    for i in range(0, dataset100.n, 7):  # the pure-Python oracle is slow: a sample
+        p, c, w = dataset100.csr(i)
+        adj = sp.csr_matrix((np.ones(c.size), c, p), shape=(w.size, w.size))
+        _, total = orc.greedy_search(adj, w)
+        assert total == pytest.approx(z["greedy_utility"][i], rel=1e-9)
+        st, rounds = orc.lgs_vectorised(p, c, w)
+        assert rounds == z["lgs_rounds"][i] and np.sum(w[st == 1]) == pytest.approx(z["lgs_total"][i], rel=1e-12)
