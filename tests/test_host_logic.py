@@ -137,3 +137,33 @@ def test_wireless_traffic_follows_reference_draws():
     res = ref_wireless.simulate_one(adj, tr["arrival_pkts"], tr["link_rates"],
                                     lambda a, w: set(np.flatnonzero(w == w.max()).tolist()[:1]), "qr")
     assert np.isclose(tr["arrival_pkts"][1:].sum(), res["depart"].sum() + res["queue"][-1].sum())
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_matfile_reader_round_trip(tmp_path, compress):
+    """distgcn_amd.matfile against files written by scipy.io.savemat the way Data_Generation.py:218-219 does."""
+    import scipy.io as sio
+    from distgcn_amd import harness, matfile
+    rng = np.random.default_rng(2)
+    for i, n in enumerate((1, 7, 120)):
+        p, c = datagen.er_graph(n, 0.2, rng)
+        adj = sp.csr_matrix((np.ones(c.size), c, p), shape=(n, n))
+        w = rng.random((1, n))
+        sio.savemat(str(tmp_path / ("g%d.mat" % i)), {"adj": adj.tocsc(), "weights": w, "N": n, "p": 0.2,
+                                                      "greedy_utility": 1.5 + i, "mwis_utility": 2.5, "mwis_label": (w > 0.5) * 1,
+                                                      "tag": "abc"}, do_compression=compress)
+        m = matfile.loadmat(str(tmp_path / ("g%d.mat" % i)))
+        ref = sio.loadmat(str(tmp_path / ("g%d.mat" % i)))
+        ip, ix = matfile.symmetric_csr(m["adj"], strict=True)
+        assert np.array_equal(ip, adj.indptr) and np.array_equal(ix, adj.indices)
+        assert m["adj"].data is None or np.array_equal(m["adj"].data, np.ones(c.size))
+        for k in ("weights", "N", "p", "greedy_utility", "mwis_utility", "mwis_label"):
+            assert np.array_equal(np.asarray(m[k]), ref[k]) and np.asarray(m[k]).shape == ref[k].shape, k
+        assert m["tag"] == "abc"
+    data = harness.load_mat_folder(str(tmp_path))
+    assert data["names"] == ["g0.mat", "g1.mat", "g2.mat"] and data["greedy_utility"] == [1.5, 2.5, 3.5]
+    assert data["adjs"][2].shape == (120, 120) and (data["adjs"][2] != adj).nnz == 0
+    # an asymmetric matrix is refused by the fast path and read through SciPy instead
+    bad = sp.csr_matrix(np.triu(np.ones((4, 4)), 1))
+    with pytest.raises(ValueError):
+        matfile.symmetric_csr(matfile.SparseCSC((4, 4), bad.tocsc().indptr, bad.tocsc().indices, None))
