@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--p", type=float, default=0.1)
+    ap.add_argument("--family", choices=["er", "ba"], default="er",
+                    help="er: G(nodes, p) (C2 / C3); ba: the BA test2 mix of SURVEY 8d (C4: one GPU's share), ignores --nodes/--p")
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--mode", choices=["layered", "fused", "auto"], default="auto")
@@ -70,6 +72,14 @@ def spmm_algorithmic_bytes(hb, layers, with_y0):
         c = lyr["weights"][0].shape[1]
         per_launch.append(csr + (3 if with_y0 else 2) * 4 * c * n)
     return per_launch
+
+
+def workload_name(args):
+    """BASELINE.json's config this run corresponds to (C3 is the bench line; the others are reference runs)."""
+    if args.family == "ba":
+        return "C4 (one GPU's share)" if args.graphs == 500 else "custom"
+    key = (args.graphs, args.nodes, args.p, args.layers, args.hidden)
+    return {(500, 200, 0.1, 20, 32): "C3", (500, 100, 0.1, 1, 32): "C2"}.get(key, "custom")
 
 
 def cpu_baseline(hb, layers, budget_s):
@@ -143,7 +153,10 @@ def main():
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
 
-    hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
+    if args.family == "ba":
+        hb = datagen.ba_test2_batch(args.graphs, first_index=rank * args.graphs)
+    else:
+        hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
     layers, weights_note = load_layers(args)
     eng = Engine(dev)
     db = eng.upload(hb)
@@ -288,7 +301,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "graphs/sec (GCN fwd + greedy MWIS) on ER N=%d p=%g" % (args.nodes, args.p),
+            "metric": ("graphs/sec (GCN fwd + greedy MWIS) on ER N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
+                      else "graphs/sec (GCN fwd + greedy MWIS) on the BA test2 mix",
             "value": world * args.graphs * args.steps / dt,
             "unit": "graphs/s",
             "n_gpus": world,
@@ -299,9 +313,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic ER graphs (seeded), uniform(0,1) weights; " + weights_note,
-            "config": {"workload": "C3: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN forward + local greedy, "
-                                   "supports rebuilt every step" % (args.graphs, args.nodes, args.p, args.layers, args.hidden),
+            "data": "synthetic %s graphs (seeded), uniform(0,1) weights; " % ("ER" if args.family == "er" else "BA") + weights_note,
+            "config": {"workload": "%s: %d %s per GPU, l=%d c=%d GCN forward + local greedy, supports rebuilt every step"
+                                   % (workload_name(args), args.graphs,
+                                      ("ER graphs N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
+                                      else "BA test2-mix graphs (N 100..300)", args.layers, args.hidden),
                        "forward_mode": mode_name, "graphs_per_gpu": args.graphs, "parallelism": "graph-sharded x%d" % world},
             "roofline": roofline,
             "spmm_kernel_roofline": spmm_line,
@@ -309,7 +325,7 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(hb, layers, args.cpu_seconds)
-            if not args.no_cpu_pool:
+            if not args.no_cpu_pool and args.family == "er":
                 out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args, min(args.cpu_seconds, 6.0))
         else:
             out["cpu_baseline"] = None
