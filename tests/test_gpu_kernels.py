@@ -437,3 +437,31 @@ def test_random_graphs_with_ties_all_paths(engine, seed):
         assert np.array_equal(out["state"].cpu().numpy(), ref["state"])
         assert np.array_equal(out["rounds"].cpu().numpy(), ref["rounds"])
         assert np.allclose(out["totals"].cpu().numpy(), ref["totals"], rtol=1e-12, atol=0)
+
+
+def test_large_batch_is_the_small_batch_tiled(engine):
+    """Size-independent property at a batch far beyond BASELINE's: 10 000 graphs that are 20 copies of a
+    500-graph batch must give 20 copies of its results (global node ids, int32 offsets, grid sizes)."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    base = datagen.er_batch(500, 200, 0.1)
+    ps, cs, ws = [], [], []
+    for g, (n0, n1) in enumerate(base.graph_slices()):
+        e0, e1 = int(base.row_ptr[n0]), int(base.row_ptr[n1])
+        ps.append(base.row_ptr[n0:n1 + 1] - e0)
+        cs.append(base.col_idx[e0:e1] - n0)
+        ws.append(base.weights[n0:n1])
+    big = HostBatch.from_csr_lists(ps * 20, cs * 20, ws * 20)
+    assert big.num_graphs == 10000 and big.num_nodes == 20 * base.num_nodes
+    for mode, nl in ((1, 20), (0, 3)):
+        dm = DeviceModel(datagen.random_model(nl, 32, seed=2), engine.device)
+        small = engine.solve(engine.upload(base), dm, mode=mode)
+        large = engine.solve(engine.upload(big), dm, mode=mode)
+        engine.check_status(small["status"])
+        engine.check_status(large["status"])
+        for k in ("state", "rounds", "totals"):
+            s, l = small[k].cpu().numpy(), large[k].cpu().numpy()
+            assert np.array_equal(np.tile(s, 20), l), (mode, k)
+        assert np.array_equal(np.tile(small["scores"].cpu().numpy().ravel().view(np.uint32), 20),
+                              large["scores"].cpu().numpy().ravel().view(np.uint32))
