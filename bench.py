@@ -7,7 +7,15 @@ One "step" = one pass of the whole hot path over one batch already resident in H
 support construction (L = I - D^-1/2 A D^-1/2) -> 20-layer c32 GCN forward -> priority product ->
 local greedy search.  Workload at every N: BASELINE.json configs[2] (C3), 500 ER graphs
 G(200, 0.1) per GPU (weak scaling: each rank owns its own 500 graphs; no data-path collective; the
-one collective, the end-of-step all_gather of the membership bytes, is inside the timed step).
+one collective, the end-of-step all_gather of every rank's packed result buffer - membership bytes +
+float64 totals + int32 rounds + status word - is inside the timed step).
+``--scaling strong --family ba --graphs 4000`` is BASELINE.json configs[3] (C4): ONE 4 000-graph BA batch
+sharded over the ranks by ``distgcn_amd.parallel.shard_ranges``.
+
+Ranks: one process per GPU.  Under ``python -m torch.distributed.run`` the ranks already exist (RANK /
+WORLD_SIZE in the environment).  Run plainly with ``--gpus N`` (N > 1) this process only LAUNCHES N fresh
+rank processes - before anything here touches the GPU - and relays their exit code; a rank whose
+LOCAL_RANK has no device fails loudly.  The JSON line carries what RCCL itself saw (``dist``).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -26,24 +34,28 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU")
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default: ~0.25 s of timed region on C3)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU (weak scaling) or in the whole job (strong)")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--p", type=float, default=0.1)
     ap.add_argument("--family", choices=["er", "ba"], default="er",
-                    help="er: G(nodes, p) (C2 / C3); ba: the BA test2 mix of SURVEY 8d (C4: one GPU's share), ignores --nodes/--p")
+                    help="er: G(nodes, p) (C2 / C3); ba: the BA test2 mix of SURVEY 8d (C4), ignores --nodes/--p")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--mode", choices=["layered", "fused", "auto"], default="auto")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: CPU ranks (tests only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-pool", action="store_true", help="skip the all-cores CPU figure (forked workers)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step membership gather at N>1")
+    ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step result gather at N>1")
     ap.add_argument("--no-spmm-probe", action="store_true", help="skip the stand-alone SpMM kernel measurement")
-    return ap.parse_args()
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (ingest + solve + fetch) measurement")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
+    return ap.parse_args(argv)
 
 
 def load_layers(args):
@@ -52,7 +64,8 @@ def load_layers(args):
     from distgcn_amd import datagen
     from distgcn_amd.gcn.models import layers_from_params
     path = os.path.join(ROOT, "tests", "golden", "models.npz")
-    name = "result_IS4SAT_deep_ld1_c%d_l%d_cheb1_diver1_mwis_dqn" % (args.hidden, args.layers)
+    prefix = "DQNBA" if args.family == "ba" else "IS4SAT"
+    name = "result_%s_deep_ld1_c%d_l%d_cheb1_diver1_mwis_dqn" % (prefix, args.hidden, args.layers)
     if os.path.isfile(path):
         z = np.load(path)
         pre = name + "|"
@@ -77,6 +90,8 @@ def spmm_algorithmic_bytes(hb, layers, with_y0):
 def workload_name(args):
     """BASELINE.json's config this run corresponds to (C3 is the bench line; the others are reference runs)."""
     if args.family == "ba":
+        if args.scaling == "strong" and args.graphs == 4000:
+            return "C4"
         return "C4 (one GPU's share)" if args.graphs == 500 else "custom"
     key = (args.graphs, args.nodes, args.p, args.layers, args.hidden)
     return {(500, 200, 0.1, 20, 32): "C3", (500, 100, 0.1, 1, 32): "C2"}.get(key, "custom")
@@ -129,111 +144,108 @@ def cpu_baseline_all_cores(args, seconds):
         return {"value": None, "error": repr(e)[:200]}
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from distgcn_amd import datagen
-    from distgcn_amd.engine import Engine, DeviceModel, MODE_LAYERED, MODE_FUSED
+def build_host_batch(args, rank, world):
+    """-> (this rank's HostBatch, graphs in the whole job).  weak: every rank generates its own ``--graphs``
+    graphs (disjoint seeds); strong: every rank generates the SAME ``--graphs``-graph batch and keeps the
+    contiguous range ``parallel.shard_ranges`` gives it (balanced on sum(nnz + N): BA graphs vary 30x)."""
+    from distgcn_amd import datagen, parallel
+    def gen(count, first):
+        if args.family == "ba":
+            return datagen.ba_test2_batch(count, first_index=first)
+        return datagen.er_batch(count, args.nodes, args.p, first_index=first)
+    if args.scaling == "weak":
+        return gen(args.graphs, rank * args.graphs), world * args.graphs
+    full = gen(args.graphs, 0)
+    lo, hi = parallel.shard_ranges(full, world)[rank]
+    return full.subset(lo, hi), args.graphs
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank != 0:  # only rank 0 reports; keep other ranks' library banners out of the launcher's stdout
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    use_dist = world > 1 or os.environ.get("DGCN_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on 1 GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+class GpuWorkload:
+    """This rank's share of the job on its MI355X: batch resident in HBM, one fused launch per step, results
+    in a ring of packed buffers (``flat``: membership + totals + rounds + status) that the gather sends as is."""
+
+    def __init__(self, args, rank, world, local):
+        import torch
+        from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED, MODE_LAYERED
+        self.torch, self.args = torch, args
+        self.dev = "cuda:%d" % local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = "cuda:%d" % local
-    torch.cuda.set_device(local)
+        self.hb, self.job_graphs = build_host_batch(args, rank, world)
+        self.layers, self.weights_note = load_layers(args)
+        self.eng = Engine(self.dev)
+        self.db = self.eng.upload(self.hb)
+        self.model = DeviceModel(self.layers, self.dev)
+        mode_name = args.mode
+        if mode_name == "auto":
+            mode_name = os.environ.get("DGCN_BENCH_MODE", "fused")
+        self.mode_name = mode_name
+        self.mode = MODE_FUSED if mode_name == "fused" else MODE_LAYERED
+        self.ring = None
+        self.counter = 0
 
-    if args.family == "ba":
-        hb = datagen.ba_test2_batch(args.graphs, first_index=rank * args.graphs)
-    else:
-        hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
-    layers, weights_note = load_layers(args)
-    eng = Engine(dev)
-    db = eng.upload(hb)
-    model = DeviceModel(layers, dev)
-    mode_name = args.mode
-    if mode_name == "auto":
-        mode_name = os.environ.get("DGCN_BENCH_MODE", "fused")
-    mode = MODE_FUSED if mode_name == "fused" else MODE_LAYERED
+    def collective_device(self):
+        return self.dev
 
-    gather_buf = None
-    if use_dist and not args.no_gather:
-        gather_buf = torch.empty(world * hb.num_nodes, dtype=torch.uint8, device=dev)
+    def make_buffers(self, cap_nodes, cap_graphs):
+        from distgcn_amd.engine import MODE_FUSED
+        if self.mode == MODE_FUSED:
+            self.ring = [self.eng.solve_buffers(self.db, want_scores=False, cap_nodes=cap_nodes, cap_graphs=cap_graphs)
+                         for _ in range(4)]
+        elif (cap_nodes, cap_graphs) != (max(self.hb.num_nodes, 1), max(self.hb.num_graphs, 1)):
+            raise RuntimeError("the layer-by-layer mode gathers only equally sized shards")
 
-    pending = []  # (work handle, tensors it reads) of gathers still in flight
-    ring = [eng.solve_buffers(db, want_scores=False) for _ in range(4)] if mode == MODE_FUSED else None
-    counter = [0]
-
-    def step():
-        if ring is not None:
+    def step(self):
+        """-> result dict; ["flat"] is the packed byte tensor the gather sends."""
+        if self.ring is not None:
             # steady-state serving loop: output buffers are re-used (4-deep ring: a buffer is rewritten
             # only after the gather that reads it has been waited for)
-            counter[0] += 1
-            res = eng.solve_fused(db, model, want_scores=False, out=ring[counter[0] % 4])
-        else:
-            db.lap = None  # supports are part of the path: rebuild them every step
-            res = eng.solve(db, model, mode=mode)
-        if gather_buf is not None:
-            # the batch gather of SURVEY 8e (membership only; every rank has equal N).  Issued async: RCCL
-            # runs it on its own stream behind this step's kernel, so it overlaps the NEXT step's compute
-            # instead of stalling the compute stream for a latency-bound ~100 KB collective.
-            work = dist.all_gather_into_tensor(gather_buf, res["state"], async_op=True)
-            pending.append((work, res["state"]))
-            if len(pending) > 2:
-                pending.pop(0)[0].wait()
-        return res
+            self.counter += 1
+            out = self.ring[self.counter % 4]
+            res = self.eng.solve_fused(self.db, self.model, want_scores=False, out=out)
+            res["flat"], res["layout"] = out["flat"], out["layout"]
+            return res
+        self.db.lap = None  # supports are part of the path: rebuild them every step
+        return self.eng.solve(self.db, self.model, mode=self.mode)
 
-    def drain():
-        while pending:
-            pending.pop(0)[0].wait()
+    def sync(self):
+        self.torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    drain()
-    torch.cuda.synchronize()
-    eng.check_status(res["status"])
+    def check(self, res):
+        self.eng.check_status(res["status"])
 
-    eng.timing(True)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    drain()  # every gather of the timed steps has completed before the clock stops
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    eng.timing(False)
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timing(self, on):
+        self.eng.timing(on)
 
-    # ---- roofline of the dominant kernel, from HIP events recorded around its launches in the
-    # timed region (on the launch stream), against SURVEY 8d's algorithmic bytes
-    fam_ms = {}
-    for fam in ("supports", "transform", "spmm", "lgs", "fused_forward", "fused_solve"):
-        ms, n = eng.timing_read(fam)
-        if n:
-            fam_ms[fam] = (ms, n)
+    def kernel_times(self):
+        fam_ms = {}
+        for fam in ("supports", "transform", "spmm", "lgs", "fused_forward", "fused_solve"):
+            ms, n = self.eng.timing_read(fam)
+            if n:
+                fam_ms[fam] = (ms, n)
+        return fam_ms
+
+
+def decode_flat(flat_host, layout, num_nodes, num_graphs):
+    """One rank's packed result buffer (engine.Engine._packed layout) -> numpy views."""
+    NP = {"uint8": np.uint8, "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
+    out = {}
+    for name, (o, nb, dt) in layout.items():
+        out[name] = flat_host[o:o + nb].view(NP[dt])
+    return {"state": out["state"][:num_nodes], "totals": out["totals"][:num_graphs], "rounds": out["rounds"][:num_graphs],
+            "status": int(out["status"][0]) if "status" in out else 0}
+
+
+def roofline_objects(args, wl, fam_ms):
+    """roofline of the dominant kernel from the HIP events recorded around its launches in the timed region
+    (on the launch stream), against SURVEY 8d's algorithmic bytes."""
+    hb, layers = wl.hb, wl.layers
     roofline = None
     per_layer_bytes = spmm_algorithmic_bytes(hb, layers, with_y0=False)  # SURVEY 8d, layer by layer
     traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(tpath):
         traffic_db = json.load(open(tpath))
+    traffic_note = "PMC FETCH_SIZE/WRITE_SIZE passes of an earlier run of this command, read from profiles/hbm_traffic.json (not measured in this run)"
     if fam_ms:
         dom = max(fam_ms, key=lambda k: fam_ms[k][0])
         ms, n = fam_ms[dom]
@@ -247,7 +259,8 @@ def main():
             ach = avg_bytes / avg_s / 1e9
             roofline = {"kernel": "k_spmm_lds (all %d launches of a step)" % len(per), "bound": "hbm",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": traffic, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": avg_bytes,
+                        "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
+                        "algorithmic_bytes_per_launch": avg_bytes,
                         "formula": "SURVEY 8d B_spmm + 4*C*N for the fused '+Z0' read, averaged over the layers"}
         elif dom in ("fused_forward", "fused_solve"):
             # one launch = every layer of every graph: SURVEY 8d counts the forward layer by layer
@@ -262,7 +275,8 @@ def main():
                 flops += 2.0 * n_nodes * cin * 2 * cout + 2.0 * nnz_l * cout
             roofline = {"kernel": "k_fused (%s: whole path, one launch per step)" % dom, "bound": "hbm",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": traffic, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo,
+                        "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
+                        "algorithmic_bytes_per_launch": algo,
                         "formula": "SURVEY 8d: sum over layers of B_spmm (CSR + Z read + Y write), %d graphs" % hb.num_graphs,
                         "fp32_matrix_view": {"flops_per_launch": flops, "achieved_tflops": flops / avg_s / 1e12,
                                              "peak_tflops": F32_MATRIX_PEAK_TF,
@@ -271,60 +285,240 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
     kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
+    return roofline, kernel_us, traffic_db
 
-    # ---- the stand-alone batched SpMM kernel of the north star (not part of the fused step): one
-    # hidden-layer aggregation over the same batch, timed with the same event hooks, outside the timed region
-    spmm_line = None
-    if rank == 0 and not args.no_spmm_probe:
-        lap = eng.supports(db)
-        C = args.hidden
-        Zt = torch.randn(hb.num_nodes, 2 * C, device=dev)
-        Yt = torch.empty(hb.num_nodes, C, device=dev)
-        def one():
-            eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs,
-                     max_nodes=hb.max_nodes, Y0=Zt, ldy0=2 * C, act="leaky_relu", out=Yt)
-        for _ in range(5):
-            one()
+
+def spmm_probe(args, wl, traffic_db):
+    """The stand-alone batched SpMM kernel of the north star (not part of the fused step): one hidden-layer
+    aggregation with the GraphConvolution epilogue, timed with the same event hooks, outside the timed region.
+    Two working sets: (a) this batch replayed (55 MB at C3: it stays in the 256 MiB Infinity Cache, so this is
+    NOT an HBM measurement) and (b) ``--spmm-out-of-cache``: distinct batches visited round-robin so that
+    every launch's inputs were last touched > 256 MiB of traffic ago (MI355X_MICROARCH.md, Infinity Cache
+    residency rule) - the HBM figure."""
+    torch, eng, hb, db = wl.torch, wl.eng, wl.hb, wl.db
+    from distgcn_amd import datagen
+    C = args.hidden
+    dev = wl.dev
+
+    def bytes_of(h, with_y0):
+        return (h.num_edges + h.num_nodes) * 8 + (h.num_nodes + h.num_graphs) * 4 + (3 if with_y0 else 2) * 4 * C * h.num_nodes
+
+    def make_set(h, d):
+        lap = eng.supports(d)
+        Zt = torch.randn(h.num_nodes, 2 * C, device=dev)
+        Yt = torch.empty(h.num_nodes, C, device=dev)
+        return (h, d, lap, Zt, Yt)
+
+    def launch(st):
+        h, d, lap, Zt, Yt = st
+        eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=d.graph_ptr, num_graphs=h.num_graphs,
+                 max_nodes=h.max_nodes, Y0=Zt, ldy0=2 * C, act="leaky_relu", out=Yt)
+
+    def timed(sets, reps):
+        for st in sets:
+            launch(st)
         torch.cuda.synchronize()
         eng.timing(True)
-        for _ in range(50):
-            one()
+        for _ in range(reps):
+            for st in sets:
+                launch(st)
         torch.cuda.synchronize()
         eng.timing(False)
         ms, n = eng.timing_read("spmm")
-        nb = (hb.num_edges + hb.num_nodes) * 8 + (hb.num_nodes + hb.num_graphs) * 4 + 3 * 4 * C * hb.num_nodes
-        ach = nb / (ms / n * 1e-3) / 1e9
-        spmm_line = {"kernel": "k_spmm_lds C=%d with the GraphConvolution epilogue" % C, "bound": "hbm", "achieved": ach,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_us": ms / n * 1e3,
-                     "algorithmic_bytes_per_launch": nb,
-                     "traffic": traffic_db.get("spmm|%dx%d|C%d" % (args.graphs, args.nodes, C), {}).get("hbm_bytes_per_launch")}
+        return ms / n * 1e-3
+
+    first = make_set(hb, db)
+    avg_s = timed([first], 50)
+    nb, nb_plain = bytes_of(hb, True), bytes_of(hb, False)
+    tkey = "spmm|%dx%d|C%d" % (args.graphs, args.nodes, C)
+    line = {"kernel": "k_spmm_lds C=%d with the GraphConvolution epilogue" % C, "bound": "hbm",
+            "working_set": "one batch replayed: %.1f MB, resident in the 256 MiB Infinity Cache (not an HBM figure)" % (nb / 1e6),
+            "achieved": nb / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / avg_s / 1e9 / HBM_PEAK_GBS,
+            "frac_plain_B_spmm": nb_plain / avg_s / 1e9 / HBM_PEAK_GBS,
+            "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": nb, "plain_B_spmm_bytes_per_launch": nb_plain,
+            "traffic": traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")}
+    # (b) out of the Infinity Cache: as many distinct batches as it takes to put > 320 MiB between two uses of a line
+    per_set = nb  # bytes one launch touches
+    nsets = int(np.ceil(320 * 2 ** 20 / per_set)) + 1
+    if nsets <= 64 and args.family == "er":
+        sets = [first]
+        for i in range(1, nsets):
+            h = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=1_000_000 + i * args.graphs)
+            sets.append(make_set(h, eng.upload(h)))
+        avg2 = timed(sets, 4)
+        nb_avg = float(np.mean([bytes_of(s[0], True) for s in sets]))
+        nbp_avg = float(np.mean([bytes_of(s[0], False) for s in sets]))
+        line["out_of_cache"] = {
+            "working_set": "%d distinct batches visited round-robin: %.0f MB between two uses of a line (> 256 MiB Infinity Cache)"
+                           % (nsets, nsets * nb_avg / 1e6),
+            "avg_launch_us": avg2 * 1e6, "achieved": nb_avg / avg2 / 1e9, "frac": nb_avg / avg2 / 1e9 / HBM_PEAK_GBS,
+            "frac_plain_B_spmm": nbp_avg / avg2 / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "traffic": traffic_db.get(tkey + "|out_of_cache", {}).get("hbm_bytes_per_launch")}
+    return line
+
+
+def run_ranks_if_asked(args, argv):
+    """``--gpus N`` without a launcher: start N rank processes (this process has not touched the GPU and
+    never will) and exit with their code."""
+    from distgcn_amd import parallel
+    if args.gpus <= 1 or parallel.launched_by_a_launcher():
+        return
+    script = os.path.abspath(sys.argv[0])
+    rc = parallel.spawn_local_ranks(args.gpus, script, list(sys.argv[1:] if argv is None else argv))
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def main(argv=None, workload_factory=None):
+    """``workload_factory(args, rank, world, local)`` builds the per-rank compute (default: ``GpuWorkload``);
+    tests/_bench_gloo_driver.py passes a CPU stand-in so that the launcher, rendezvous, sharding, gather and
+    report code below - the very same code - runs on two gloo ranks without a GPU."""
+    args = parse(argv)
+    run_ranks_if_asked(args, argv)
+
+    import torch
+    import torch.distributed as dist
+    from distgcn_amd import parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if rank != 0:  # only rank 0 reports; keep other ranks' library banners out of the launcher's stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    use_dist = world > 1 or args.force_dist or os.environ.get("DGCN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        parallel.init_rank_group(args.backend)
+
+    wl = (workload_factory or GpuWorkload)(args, rank, world, local)
+    hb = wl.hb
+    cdev = wl.collective_device()
+
+    # one buffer layout for every rank: sizes of the largest shard
+    caps = torch.tensor([max(hb.num_nodes, 1), max(hb.num_graphs, 1)], dtype=torch.int64, device=cdev)
+    sizes_all = None
+    if use_dist:
+        mine = torch.tensor([hb.num_nodes, hb.num_graphs], dtype=torch.int64, device=cdev)
+        sizes_all = torch.empty(2 * world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(sizes_all, mine)
+        sizes_all = sizes_all.cpu().numpy().reshape(world, 2)
+        dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+    cap_nodes, cap_graphs = (int(x) for x in caps.cpu().numpy())
+    wl.make_buffers(cap_nodes, cap_graphs)
+
+    gather_buf = None
+    pending = []  # (work handle, tensor it reads) of gathers still in flight
+
+    def step():
+        res = wl.step()
+        nonlocal gather_buf
+        if use_dist and not args.no_gather:
+            flat = res["flat"]
+            if gather_buf is None:
+                gather_buf = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
+            # the batch gather of SURVEY 8e: membership + totals + rounds (+ status) of every rank, ONE collective.
+            # Issued async: RCCL runs it on its own stream behind this step's kernel, so it overlaps the NEXT
+            # step's compute instead of stalling the compute stream for a latency-bound ~100 KB collective.
+            work = dist.all_gather_into_tensor(gather_buf, flat, async_op=True)
+            pending.append((work, flat))
+            if len(pending) > 2:
+                pending.pop(0)[0].wait()
+        return res
+
+    def drain():
+        while pending:
+            pending.pop(0)[0].wait()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    drain()
+    wl.sync()
+    if res is not None:
+        wl.check(res)
+
+    wl.timing(True)
+    if use_dist:
+        dist.barrier()
+    wl.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    drain()  # every gather of the timed steps has completed before the clock stops
+    wl.sync()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    wl.timing(False)
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    wl.check(res)
+
+    # ---- what the collective library saw, and what the last gather delivered (decoded on rank 0)
+    dist_report = None
+    if use_dist:
+        dist_report = parallel.census(cdev)
+        if gather_buf is not None:
+            got = gather_buf.cpu().numpy().reshape(world, -1)
+            own = res["flat"].cpu().numpy()
+            graphs = members = 0
+            weight = 0.0
+            faults = 0
+            for r in range(world):
+                d = decode_flat(got[r], res["layout"], int(sizes_all[r, 0]), int(sizes_all[r, 1]))
+                graphs += int((d["rounds"] >= 0).sum())
+                members += int((d["state"] == 1).sum())
+                weight += float(d["totals"].sum())
+                faults |= d["status"]
+            dist_report["gathered_last_step"] = {
+                "bytes_per_rank": int(got.shape[1]), "graphs": graphs, "set_members": members, "total_weight": weight,
+                "status_bits": faults, "own_slot_matches_own_result": bool(np.array_equal(got[rank], own)),
+                "content": "state[uint8 per vertex] + totals[f64 per graph] + rounds[i32 per graph] + status[i32]"}
+
+    fam_ms = wl.kernel_times()
+    roofline, kernel_us, traffic_db = roofline_objects(args, wl, fam_ms)
+
+    spmm_line = None
+    if rank == 0 and not args.no_spmm_probe and isinstance(wl, GpuWorkload):
+        spmm_line = spmm_probe(args, wl, traffic_db)
 
     if rank == 0:
+        per_gpu = args.graphs if args.scaling == "weak" else None
         out = {
             "metric": ("graphs/sec (GCN fwd + greedy MWIS) on ER N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
                       else "graphs/sec (GCN fwd + greedy MWIS) on the BA test2 mix",
-            "value": world * args.graphs * args.steps / dt,
+            "value": wl.job_graphs * args.steps / dt,
             "unit": "graphs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic %s graphs (seeded), uniform(0,1) weights; " % ("ER" if args.family == "er" else "BA") + weights_note,
-            "config": {"workload": "%s: %d %s per GPU, l=%d c=%d GCN forward + local greedy, supports rebuilt every step"
+            "data": "synthetic %s graphs (seeded), uniform(0,1) weights; " % ("ER" if args.family == "er" else "BA") + wl.weights_note,
+            "config": {"workload": "%s: %d %s %s, l=%d c=%d GCN forward + local greedy, supports rebuilt every step"
                                    % (workload_name(args), args.graphs,
                                       ("ER graphs N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
-                                      else "BA test2-mix graphs (N 100..300)", args.layers, args.hidden),
-                       "forward_mode": mode_name, "graphs_per_gpu": args.graphs, "parallelism": "graph-sharded x%d" % world},
+                                      else "BA test2-mix graphs (N 100..300)",
+                                      "per GPU" if args.scaling == "weak" else "in the job, sharded by graph over the ranks",
+                                      args.layers, args.hidden),
+                       "forward_mode": getattr(wl, "mode_name", "?"), "graphs_per_gpu": per_gpu, "job_graphs": wl.job_graphs,
+                       "parallelism": "graph-sharded x%d" % world},
+            "dist": dist_report,
             "roofline": roofline,
             "spmm_kernel_roofline": spmm_line,
             "kernels": kernel_us,
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(hb, layers, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(hb, wl.layers, args.cpu_seconds)
             if not args.no_cpu_pool and args.family == "er":
                 out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args, min(args.cpu_seconds, 6.0))
         else:

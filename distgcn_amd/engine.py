@@ -30,6 +30,28 @@ def dinv_table(max_degree: int) -> np.ndarray:
     return t
 
 
+_NP = {"uint8": np.uint8, "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
+
+
+def packed_layout(specs):
+    """(total bytes, {name: (byte offset, bytes, dtype name)}) of arrays packed into one byte buffer, widest
+    element type first, every array 16-byte aligned.  specs: (name, element count, dtype name); count 0 = absent."""
+    off, lay = 0, {}
+    for name, count, dt in sorted(specs, key=lambda x: -np.dtype(_NP[x[2]]).itemsize):
+        if count <= 0:
+            continue
+        nb = count * np.dtype(_NP[dt]).itemsize
+        lay[name] = (off, nb, dt)
+        off = (off + nb + 15) & ~15
+    return max(off, 16), lay
+
+
+def solve_buffer_specs(num_nodes: int, num_graphs: int, want_scores: bool):
+    """The arrays of one rank's packed solve result (``Engine.solve_buffers``)."""
+    return [("totals", num_graphs, "float64"), ("scores", num_nodes if want_scores else 0, "float32"),
+            ("rounds", num_graphs, "int32"), ("status", 1, "int32"), ("state", num_nodes, "uint8")]
+
+
 class DeviceModel:
     """Layer stack on the device.  ``layers`` is a list of dicts
     {"weights": [W_0, W_1] (each [in, out] float32), "bias": None | [out], "act": str}."""
@@ -87,20 +109,14 @@ class Engine:
             self._ws = self.torch.empty(max(nbytes, 256), dtype=self.torch.uint8, device=self.device)
         return self._ws
 
-    _NP = {"uint8": np.uint8, "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
+    _NP = _NP
 
     def _packed(self, specs):
         """Device arrays as views into ONE byte tensor, so a caller can fetch them all with a single
         device-to-host copy (``fetch_packed``).  specs: (name, element count, dtype name); count 0 = absent."""
         t = self.torch
-        off, lay = 0, {}
-        for name, count, dt in sorted(specs, key=lambda x: -np.dtype(self._NP[x[2]]).itemsize):
-            if count <= 0:
-                continue
-            nb = count * np.dtype(self._NP[dt]).itemsize
-            lay[name] = (off, nb, dt)
-            off = (off + nb + 15) & ~15
-        flat = t.zeros(max(off, 16), dtype=t.uint8, device=self.device)
+        off, lay = packed_layout(specs)
+        flat = t.zeros(off, dtype=t.uint8, device=self.device)
         out = {"flat": flat, "layout": lay}
         for name, _, _ in specs:
             if name in lay:
@@ -276,14 +292,16 @@ class Engine:
     def solve_supported(self, b: DeviceBatch, model: DeviceModel) -> bool:
         return bool(self.lib.dgcn_solve_supported(C.byref(b.c), C.byref(model.c)))
 
-    def solve_buffers(self, b: DeviceBatch, want_scores: bool = True):
+    def solve_buffers(self, b: DeviceBatch, want_scores: bool = True, cap_nodes: int = 0, cap_graphs: int = 0):
         """Output buffers of ``solve_fused`` for a batch, for callers that re-use them across calls
         (a steady-state serving loop should not pay five allocations per batch).  All of them are views
         into ONE byte tensor, so everything comes back with a single device-to-host copy
-        (``fetch_solve_buffers``)."""
-        n, B = max(b.host.num_nodes, 1), max(b.host.num_graphs, 1)
-        out = self._packed([("totals", B, "float64"), ("scores", n if want_scores else 0, "float32"),
-                            ("rounds", B, "int32"), ("status", 1, "int32"), ("state", n, "uint8")])
+        (``fetch_solve_buffers``) - or goes out in a single collective (``out["flat"]`` is what bench.py
+        all-gathers: membership + totals + rounds + status of a rank in one buffer).  ``cap_nodes`` /
+        ``cap_graphs``: lay the buffer out for that many vertices / graphs (every rank of a sharded batch
+        uses the largest shard's sizes, so all ranks' buffers have one layout)."""
+        n, B = max(b.host.num_nodes, cap_nodes, 1), max(b.host.num_graphs, cap_graphs, 1)
+        out = self._packed(solve_buffer_specs(n, B, want_scores))
         if want_scores:
             out["scores"] = out["scores"].reshape(n, 1)
         return out

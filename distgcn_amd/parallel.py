@@ -9,7 +9,11 @@ which is why it is a single call per batch and never per graph.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -80,3 +84,94 @@ def solve_sharded(hb: HostBatch, solve_fn: Callable[[HostBatch], Dict[str, np.nd
         rounds[a:b] = allb[r, cap_graphs * 8:cap_graphs * 8 + g * 4].view(np.int32)
         state[n0:n1] = allb[r, cap_graphs * 12:cap_graphs * 12 + (n1 - n0)]
     return {"state": state, "totals": totals, "rounds": rounds}
+
+
+# ------------------------------------------------------------------------------------------------
+# Rank launcher and census.  One process per GPU; the launcher NEVER touches the GPU itself (a process that
+# has initialised HIP must not be replaced or forked into ranks), it only starts fresh children.
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launched_by_a_launcher() -> bool:
+    """True when RANK / WORLD_SIZE come from torchrun (or from ``spawn_local_ranks``)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def spawn_local_ranks(nproc: int, script: str, argv: Sequence[str], port: Optional[int] = None,
+                      extra_env: Optional[Dict[str, str]] = None, timeout: Optional[float] = None) -> int:
+    """Start ``nproc`` fresh interpreters running ``script argv`` with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set (what ``python -m torch.distributed.run --nnodes=1`` would set),
+    wait for them, and return the worst exit code.  If one rank fails the others are ended (by their exact
+    pids) so that nobody waits in a collective forever."""
+    port = port or free_port()
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    import time
+    t0 = time.monotonic()
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:  # a failed rank leaves the others stuck in the rendezvous / a collective
+                    q.terminate()
+        if timeout is not None and time.monotonic() - t0 > timeout:
+            for q in live:
+                q.kill()
+            worst = worst or 124
+        time.sleep(0.05)
+    return worst
+
+
+def init_rank_group(backend: str = "nccl"):
+    """Join the job the launcher described in the environment.  -> (rank, world, local_rank).
+    backend "nccl" is RCCL on ROCm (one device per rank, fails loudly when LOCAL_RANK has no device);
+    "gloo" runs the same collectives on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        have = torch.cuda.device_count()
+        if local >= have:
+            raise RuntimeError("rank %d of %d needs GPU %d but this node shows %d device(s): --gpus must not exceed "
+                               "the GPUs present (no rank shares or fakes a device)" % (rank, world, local, have))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return rank, world, local
+
+
+def census(device) -> Dict[str, object]:
+    """What the collective library itself saw: the group's world size, an all-reduced count of the ranks that
+    took part, and every rank's (rank, device index) pair from an all_gather."""
+    import torch
+    import torch.distributed as dist
+    one = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    dev_index = torch.device(device).index if torch.device(device).type == "cuda" else -1
+    mine = torch.tensor([dist.get_rank(), -1 if dev_index is None else dev_index], dtype=torch.int32, device=device)
+    everyone = torch.empty(2 * dist.get_world_size(), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(everyone, mine)
+    pairs = everyone.cpu().numpy().reshape(-1, 2)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_all_reduce": int(one.item()),
+            "rank_device_pairs": [[int(a), int(b)] for a, b in pairs]}
