@@ -24,8 +24,8 @@ FAULT_NAMES = {
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
-    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
-    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
+    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
+    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
 
@@ -83,6 +83,13 @@ def load():
     lib.dgcn_last_error.restype = C.c_char_p
     lib.dgcn_supports_batch.restype = C.c_int
     lib.dgcn_supports_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
+    lib.dgcn_supports2_count_batch.restype = C.c_int
+    lib.dgcn_supports2_count_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp]
+    lib.dgcn_supports2_fill_batch.restype = C.c_int
+    lib.dgcn_supports2_fill_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
+    lib.dgcn_gcn_forward_poly_batch.restype = C.c_int
+    lib.dgcn_gcn_forward_poly_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(C.POINTER(DgcnCsr)), C.POINTER(DgcnModel),
+                                                vp, f32, vp, vp, sz, vp]
     lib.dgcn_spmm_split.restype = C.c_int
     lib.dgcn_spmm_split.argtypes = [i32]
     lib.dgcn_spmm_batch.restype = C.c_int

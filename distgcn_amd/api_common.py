@@ -71,20 +71,30 @@ def state_to_device(engine, state, input_dim):
         db = engine.upload(single_batch(adj))
         return db, Xd, x_const
     sup = dict.__getitem__(state, "support") if isinstance(state, dict) else state["support"]
-    if len(sup) != 2:
-        raise _lib.DgcnError("only [I, L] supports (max_degree=1) are implemented; state has %d" % len(sup))
-    coords, values, shape = sup[1]
-    lap = sp.csr_matrix((np.asarray(values, dtype=np.float64), (coords[:, 0], coords[:, 1])), shape=shape)
-    lap.sort_indices()
+    if len(sup) not in (2, 3):
+        raise _lib.DgcnError("[I, L] (max_degree=1) and [I, L, L.L] (max_degree=2) supports are implemented; state has %d"
+                             % len(sup))
+
+    def csr_of(tup):
+        coords, values, shape = tup
+        m = sp.csr_matrix((np.asarray(values, dtype=np.float64), (coords[:, 0], coords[:, 1])), shape=shape)
+        m.sort_indices()
+        return m
+
+    def upload_csr(m):
+        row_ptr = torch.from_numpy(m.indptr.astype(np.int32)).to(engine.device)
+        col = torch.from_numpy(m.indices.astype(np.int32)).to(engine.device)
+        val = torch.from_numpy(m.data.astype(np.float32)).to(engine.device)  # TF's float64 -> float32 feed cast
+        csr = _lib.DgcnCsr(n, int(m.nnz), int(m.nnz), row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
+        return {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
+
+    lap = csr_of(sup[1])
     off = lap.copy().tolil()
     off.setdiag(0)
     off = sp.csr_matrix(off)
     off.eliminate_zeros()
     db = engine.upload(HostBatch.from_csr_lists([off.indptr], [off.indices]))
-    t = torch
-    row_ptr = t.from_numpy(lap.indptr.astype(np.int32)).to(engine.device)
-    col = t.from_numpy(lap.indices.astype(np.int32)).to(engine.device)
-    val = t.from_numpy(lap.data.astype(np.float32)).to(engine.device)  # TF's float64 -> float32 feed cast
-    csr = _lib.DgcnCsr(n, int(lap.nnz), int(lap.nnz), row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
-    db.lap = {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
+    db.lap = upload_csr(lap)
+    if len(sup) == 3:
+        db.lap2 = upload_csr(csr_of(sup[2]))
     return db, Xd, x_const

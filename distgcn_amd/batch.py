@@ -160,6 +160,7 @@ class DeviceBatch:
                                 host.max_graph_edges, self.graph_ptr.data_ptr(), self.row_ptr.data_ptr(),
                                 self.col_idx.data_ptr())
         self.lap = None  # filled by Engine.supports()
+        self.lap2 = None  # filled by Engine.supports2() (max_degree = 2)
 
     @property
     def num_graphs(self):

@@ -18,9 +18,9 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
 
 static int model_check(const DgcnModel* m, const char* who) {
     if (!m || !m->layers_host || m->num_layers <= 0) return fail(DGCN_ERR_ARG, "%s: bad model", who);
-    if (m->num_supports != 2)
-        return fail(DGCN_ERR_UNSUPPORTED, "%s: num_supports=%d; only [I, L] (max_degree=1) is implemented", who,
-                    m->num_supports);
+    if (m->num_supports != 2 && m->num_supports != 3)
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: num_supports=%d; [I, L] (max_degree=1) and [I, L, L.L] (max_degree=2) are implemented",
+                    who, m->num_supports);
     for (int l = 0; l < m->num_layers; ++l) {
         const DgcnLayer& L = m->layers_host[l];
         if (L.in_dim <= 0 || L.out_dim <= 0 || !L.weights) return fail(DGCN_ERR_ARG, "%s: layer %d malformed", who, l);
@@ -78,11 +78,55 @@ using namespace dgcn;
 
 extern "C" size_t dgcn_gcn_forward_workspace(const DgcnBatch* b, const DgcnModel* m, int32_t mode) {
     if (!b || model_check(m, "dgcn_gcn_forward_workspace") != DGCN_OK) return 0;
-    if (mode == 1) return fused_workspace(b, m);
+    if (mode == 1) return m->num_supports == 2 ? fused_workspace(b, m) : 0;
     int mo;
     layered_dims(m, &mo);
     const size_t n = (size_t)max(b->num_nodes, 1);
-    return align256(n * 2 * mo * sizeof(float)) + align256(n * mo * sizeof(float));
+    // Z = H.[W_0 | .. | W_k], the next layer's H, and (k = 2) the running sum of the first two supports
+    return align256(n * m->num_supports * mo * sizeof(float)) + align256(n * mo * sizeof(float)) +
+           (m->num_supports > 2 ? align256(n * mo * sizeof(float)) : 0);
+}
+
+// Layer-by-layer forward over the supports [I, T_1, .., T_k] (k = num_supports - 1 CSR matrices given).
+// Per layer: Z = H.[W_0 | .. | W_k]; out = Z_0 + T_1.Z_1 (+ T_2.Z_2 ...) in support order - tf.add_n sums
+// left to right (gcn/layers.py:208) - then bias, activation in the last aggregation's epilogue.
+static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const DgcnModel* m, const float* X,
+                           float x_const, float* scores, void* workspace, hipStream_t s) {
+    int mo;
+    layered_dims(m, &mo);
+    const int K = m->num_supports;
+    const size_t n = (size_t)b->num_nodes;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* Zbuf = reinterpret_cast<float*>(ws);
+    float* Hbuf = reinterpret_cast<float*>(ws + align256(n * K * mo * sizeof(float)));
+    float* Tbuf = reinterpret_cast<float*>(ws + align256(n * K * mo * sizeof(float)) + align256(n * mo * sizeof(float)));
+    const float* H = X;  // NULL -> constant features
+    int ldh = m->layers_host[0].in_dim;
+    for (int l = 0; l < m->num_layers; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        const int ctot = K * L.out_dim;
+        // K2/K3: Z[:, i*out:(i+1)*out] = H.W_i  (weights stored [support][in][out] -> the host shim passes
+        // them pre-concatenated as [in][K*out]; see distgcn_amd/gcn/models.py)
+        int rc = transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
+        if (rc) return rc;
+        const bool last = l == m->num_layers - 1;
+        float* out = last ? scores : Hbuf;
+        const float* run = Zbuf;  // running sum: S_0.Z_0 = Z_0
+        int ldrun = ctot;
+        for (int i = 1; i < K; ++i) {
+            const bool fin = i == K - 1;
+            float* dst = fin ? out : Tbuf;
+            // K4-K7: dst = run + T_i.Z_i, and on the last support: act(. + b)
+            rc = spmm_dispatch(sup[i - 1], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + i * L.out_dim, ctot, L.out_dim,
+                               run, ldrun, fin ? L.bias : nullptr, fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s);
+            if (rc) return rc;
+            run = dst;
+            ldrun = L.out_dim;
+        }
+        H = out;
+        ldh = L.out_dim;
+    }
+    return DGCN_OK;
 }
 
 extern "C" int dgcn_gcn_forward_batch(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X,
@@ -97,34 +141,33 @@ extern "C" int dgcn_gcn_forward_batch(const DgcnBatch* b, const DgcnCsr* lap, co
     const size_t need = dgcn_gcn_forward_workspace(b, m, mode);
     if (!workspace || workspace_bytes < need)
         return fail(DGCN_ERR_WORKSPACE, "dgcn_gcn_forward_batch: workspace %zu < %zu bytes", workspace_bytes, need);
-    if (mode == 1) return fused_forward(b, lap, m, X, x_const, scores, workspace, workspace_bytes, s);
+    if (mode == 1) {
+        if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_gcn_forward_batch(mode 1): only [I, L] supports");
+        return fused_forward(b, lap, m, X, x_const, scores, workspace, workspace_bytes, s);
+    }
     if (mode != 0) return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_batch: unknown mode %d", mode);
 
-    int mo;
-    layered_dims(m, &mo);
-    const size_t n = (size_t)b->num_nodes;
-    float* Zbuf = reinterpret_cast<float*>(workspace);
-    float* Hbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256(n * 2 * mo * sizeof(float)));
+    if (m->num_supports != 2)
+        return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_batch: the model has %d supports; pass them all to dgcn_gcn_forward_poly_batch",
+                    m->num_supports);
+    const DgcnCsr* sup[1] = {lap};
+    return layered_forward(b, sup, m, X, x_const, scores, workspace, s);
+}
 
-    const float* H = X;  // NULL -> constant features
-    int ldh = m->layers_host[0].in_dim;
-    for (int l = 0; l < m->num_layers; ++l) {
-        const DgcnLayer& L = m->layers_host[l];
-        const int ctot = 2 * L.out_dim;
-        // K2/K3: Z[:, 0:out] = H.W0, Z[:, out:2out] = H.W1  (weights stored [support][in][out] -> the
-        // host shim passes them pre-concatenated as [in][2*out]; see distgcn_amd/gcn/models.py)
-        rc = transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
-        if (rc) return rc;
-        const bool last = l == m->num_layers - 1;
-        float* out = last ? scores : Hbuf;
-        // K4-K7: out = act(Z0 + L.Z1 + b)
-        rc = spmm_dispatch(lap, b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + L.out_dim, ctot, L.out_dim, Zbuf,
-                           ctot, L.bias, L.act, out, L.out_dim, s);
-        if (rc) return rc;
-        H = out;
-        ldh = L.out_dim;
-    }
-    return DGCN_OK;
+extern "C" int dgcn_gcn_forward_poly_batch(const DgcnBatch* b, const DgcnCsr* const* supports_host, const DgcnModel* m,
+                                           const float* X, float x_const, float* scores, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (!b || !supports_host || !scores) return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_poly_batch: null argument");
+    int rc = model_check(m, "dgcn_gcn_forward_poly_batch");
+    if (rc) return rc;
+    if (b->num_nodes <= 0) return DGCN_OK;
+    for (int i = 0; i + 1 < m->num_supports; ++i)
+        if (!supports_host[i] || supports_host[i]->num_rows != b->num_nodes)
+            return fail(DGCN_ERR_ARG, "dgcn_gcn_forward_poly_batch: support %d missing or of the wrong size", i + 1);
+    const size_t need = dgcn_gcn_forward_workspace(b, m, 0);
+    if (!workspace || workspace_bytes < need)
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_gcn_forward_poly_batch: workspace %zu < %zu bytes", workspace_bytes, need);
+    return layered_forward(b, supports_host, m, X, x_const, scores, workspace, (hipStream_t)stream);
 }
 
 extern "C" int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr, int32_t num_graphs,

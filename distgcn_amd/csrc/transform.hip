@@ -123,15 +123,17 @@ int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin
     }
     DGCN_TF_CASE(32, 64)
     DGCN_TF_CASE(32, 32)
+    DGCN_TF_CASE(32, 96)
     DGCN_TF_CASE(16, 32)
     DGCN_TF_CASE(16, 64)
     DGCN_TF_CASE(64, 128)
     DGCN_TF_CASE(64, 64)
     DGCN_TF_CASE(8, 32)
 #undef DGCN_TF_CASE
-    if (H && ctot == 2) {
-        DGCN_LAUNCH(t, (k_transform_narrow<2>), dim3(min(ceil_div(rows, 256), 4096)), dim3(256), 0, s, H, ldh, rows,
-                           cin, W, Z, ldz);
+    if (H && (ctot == 2 || ctot == 3)) {
+        const dim3 grid(min(ceil_div(rows, 256), 4096));
+        if (ctot == 2) DGCN_LAUNCH(t, (k_transform_narrow<2>), grid, dim3(256), 0, s, H, ldh, rows, cin, W, Z, ldz);
+        else DGCN_LAUNCH(t, (k_transform_narrow<3>), grid, dim3(256), 0, s, H, ldh, rows, cin, W, Z, ldz);
         return check_launch("k_transform_narrow");
     }
     const long total = (long)rows * ctot;

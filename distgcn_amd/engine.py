@@ -169,6 +169,33 @@ class Engine:
         b.lap = {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
         return b.lap
 
+    def supports2(self, b: DeviceBatch, status=None):
+        """T_2 = L.L for the batch, formed explicitly like the reference's ``t_k[-1]*laplacian``
+        (gcn/utils.py:268-271); float32 values bit-identical to the reference's.  Cached on the batch.
+        One device-to-host read of the entry count between the two passes (the caller allocates)."""
+        t = self.torch
+        if getattr(b, "lap2", None) is not None:
+            return b.lap2
+        n = b.host.num_nodes
+        own = status is None
+        if own:
+            status = t.zeros(1, dtype=t.int32, device=self.device)
+        tab = self._dinv(b.host.max_degree)
+        row_ptr = t.zeros(n + 1, dtype=t.int32, device=self.device)
+        _lib.check(self.lib.dgcn_supports2_count_batch(C.byref(b.c), tab.data_ptr(), int(tab.numel()), row_ptr.data_ptr(),
+                                                       status.data_ptr(), self._stream()), "dgcn_supports2_count_batch")
+        nnz = int(row_ptr[n].item())
+        col = t.empty(max(nnz, 1), dtype=t.int32, device=self.device)
+        val = t.empty(max(nnz, 1), dtype=t.float32, device=self.device)
+        _lib.check(self.lib.dgcn_supports2_fill_batch(C.byref(b.c), tab.data_ptr(), int(tab.numel()), row_ptr.data_ptr(),
+                                                      col.data_ptr(), val.data_ptr(), status.data_ptr(), self._stream()),
+                   "dgcn_supports2_fill_batch")
+        if own:
+            self.check_status(status)
+        csr = _lib.DgcnCsr(n, nnz, 0, row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
+        b.lap2 = {"row_ptr": row_ptr, "col_idx": col, "values": val, "c": csr}
+        return b.lap2
+
     # ------------------------------------------------------------------ K4
     def spmm(self, csr: dict, Z, C_feat: int, ldz: Optional[int] = None, graph_ptr=None, num_graphs=0, max_nodes=0,
              Y0=None, ldy0=0, bias=None, act="linear", out=None):
@@ -207,6 +234,18 @@ class Engine:
             x_const = float(np.float32(1.0 / model.in_dim))  # row-normalised all-ones features
         if out is None:
             out = t.empty((b.host.num_nodes, model.out_dim), dtype=t.float32, device=self.device)
+        if model.num_supports == 3:  # [I, L, L.L]: layer by layer through the poly entry
+            if mode != MODE_LAYERED:
+                raise _lib.DgcnError("max_degree=2 models run layer by layer (mode=MODE_LAYERED)")
+            lap2 = self.supports2(b)
+            need = int(self.lib.dgcn_gcn_forward_workspace(C.byref(b.c), C.byref(model.c), 0))
+            ws = self._workspace(need)
+            sups = (C.POINTER(_lib.DgcnCsr) * 2)(C.pointer(lap["c"]), C.pointer(lap2["c"]))
+            _lib.check(self.lib.dgcn_gcn_forward_poly_batch(C.byref(b.c), sups, C.byref(model.c),
+                                                            X.data_ptr() if X is not None else None, x_const,
+                                                            out.data_ptr(), ws.data_ptr(), int(ws.numel()), self._stream()),
+                       "dgcn_gcn_forward_poly_batch")
+            return out
         need = int(self.lib.dgcn_gcn_forward_workspace(C.byref(b.c), C.byref(model.c), mode))
         if need == 0:
             _lib.check(-1, "dgcn_gcn_forward_workspace")

@@ -82,7 +82,7 @@ typedef struct DgcnLayer {
 /* GCN_DQN / GCN2_DQN layer stack (gcn/models.py:536-573, 670-708). */
 typedef struct DgcnModel {
     int32_t num_layers;
-    int32_t num_supports;          /* 1 + max_degree; this library implements 2 ([I, L]) */
+    int32_t num_supports;          /* 1 + max_degree: 2 ([I, L]) or 3 ([I, L, L.L]; layer-by-layer path only) */
     const DgcnLayer* layers_host;  /* HOST array of num_layers descriptors */
 } DgcnModel;
 
@@ -99,6 +99,24 @@ const char* dgcn_last_error(void);
 int dgcn_supports_batch(const DgcnBatch* batch, const double* dinv_table, int32_t table_len,
                         int32_t* lap_row_ptr, int32_t* lap_col, float* lap_val,
                         int32_t* status, void* stream);
+
+/* ---- A2 with k = 2: gcn/utils.py:268-271 "t_new = t_k[-1]*laplacian" (max_degree = 2: the shipped
+ * result_IS4SAT_deep_ld1_c1_l{1,2}_cheb2_* checkpoints) --------------------------------------------------
+ * T_2 = L.L formed explicitly, as SciPy's csr_matmat forms it on the float64 L with sorted columns: for
+ * output row i the products L[i,j]*L[j,k] are added in float64 in ascending order of j (multiply and add
+ * rounded separately), sums that are exactly 0 are dropped, the result is cast to float32 (TF's feed) -
+ * bit-identical to the reference's values (tests/golden/supports.npz *_lap2_*).  Rows come out with
+ * ascending columns (global ids).  Two calls because the CALLER allocates:
+ *   count: lap2_row_ptr[num_nodes+1] <- row starts (exclusive scan of the row lengths), [num_nodes] = nnz
+ *   (read lap2_row_ptr[num_nodes] back, allocate lap2_col / lap2_val)
+ *   fill:  writes the entries.
+ * The adjacency rows must have ascending columns for the bit-exact order (otherwise the values differ
+ * by float64 rounding only).  Graphs up to 9 600 vertices.  Faults as dgcn_supports_batch. */
+int dgcn_supports2_count_batch(const DgcnBatch* batch, const double* dinv_table, int32_t table_len,
+                               int32_t* lap2_row_ptr, int32_t* status, void* stream);
+int dgcn_supports2_fill_batch(const DgcnBatch* batch, const double* dinv_table, int32_t table_len,
+                              const int32_t* lap2_row_ptr, int32_t* lap2_col, float* lap2_val,
+                              int32_t* status, void* stream);
 
 /* ---- K4 (+K5-K7): gcn/layers.py:206 sparse_tensor_dense_matmul, :208 add_n, :211 bias, :216 act
  * Y[v, 0:C] = act( Y0[v, 0:C] + sum_j S.values[j] * Z[S.col_idx[j], 0:C] + bias[0:C] )
@@ -132,6 +150,14 @@ size_t dgcn_gcn_forward_workspace(const DgcnBatch* batch, const DgcnModel* model
 int dgcn_gcn_forward_batch(const DgcnBatch* batch, const DgcnCsr* lap, const DgcnModel* model,
                            const float* X, float x_const, float* scores,
                            void* workspace, size_t workspace_bytes, int32_t mode, void* stream);
+
+/* The same forward for models with more than two supports (gcn/layers.py:199-208 sums over ALL supports):
+ * supports_host is a HOST array of model->num_supports - 1 CSR matrices T_1 = L, T_2 = L.L (T_0 = I is
+ * implicit).  Per layer Z = H.[W_0 | W_1 | W_2], out = act(((Z_0 + T_1.Z_1) + T_2.Z_2) + b): tf.add_n adds
+ * left to right.  Layer by layer only (workspace: dgcn_gcn_forward_workspace(batch, model, 0)). */
+int dgcn_gcn_forward_poly_batch(const DgcnBatch* batch, const DgcnCsr* const* supports_host, const DgcnModel* model,
+                                const float* X, float x_const, float* scores,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- models.py:526/660  pred = argmax(outputs, axis 0), per graph, first maximum wins ---------*/
 int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr, int32_t num_graphs,

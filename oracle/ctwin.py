@@ -60,6 +60,24 @@ def supports(graph_ptr, row_ptr, col_idx):
     return lrp, lc, lv, fault
 
 
+def supports2(graph_ptr, row_ptr, col_idx):
+    """T_2 = L.L (explicit, SciPy csr_matmat order; see dgcn_oracle.c) -> (row_ptr2, col2, val2 float32, fault)."""
+    graph_ptr = np.ascontiguousarray(graph_ptr, np.int32)
+    row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+    col_idx = np.ascontiguousarray(col_idx, np.int32)
+    n = int(graph_ptr[-1])
+    deg = np.diff(row_ptr)
+    tab = dinv_table(int(deg.max()) if deg.size else 0)
+    rp2 = np.zeros(n + 1, np.int32)
+    args = (n, _p(graph_ptr), int(graph_ptr.size - 1), _p(row_ptr), _p(col_idx), _p(tab), int(tab.size), _p(rp2))
+    lib().orc_supports2(*args, None, None)
+    nnz = int(rp2[n])
+    c2 = np.empty(max(nnz, 1), np.int32)
+    v2 = np.empty(max(nnz, 1), np.float32)
+    fault = lib().orc_supports2(*args, _p(c2), _p(v2))
+    return rp2, c2[:nnz], v2[:nnz], fault
+
+
 def spmm_split(C_feat):
     return int(lib().orc_spmm_split(int(C_feat)))
 
@@ -93,8 +111,12 @@ ACTS = {"linear": 0, "identity": 0, None: 0, "leaky_relu": 1, "relu": 2}
 
 
 def forward(lap, layers, num_nodes, X=None, x_const=None):
-    """layers: list of {"weights": [W0, W1], "bias", "act"}.  Returns scores[num_nodes, out]."""
-    lrp, lc, lv = lap
+    """layers: list of {"weights": [W0, W1(, W2)], "bias", "act"}; ``lap`` = (row_ptr, col, val) of L, or a list
+    of such triples [T_1, T_2] for a model with three supports.  Returns scores[num_nodes, out]."""
+    sups = [lap] if isinstance(lap, tuple) else list(lap)
+    K = len(layers[0]["weights"])
+    if len(sups) != K - 1:
+        raise ValueError("model has %d supports, %d matrices given" % (K, len(sups)))
     L = len(layers)
     dims = np.array([layers[0]["weights"][0].shape[0]] + [l["weights"][0].shape[1] for l in layers], np.int32)
     cats = [np.ascontiguousarray(np.concatenate([np.asarray(w, np.float32) for w in l["weights"]], axis=1)) for l in layers]
@@ -107,8 +129,12 @@ def forward(lap, layers, num_nodes, X=None, x_const=None):
     if X is not None:
         X = np.ascontiguousarray(X, np.float32)
     scores = np.empty((num_nodes, int(dims[-1])), np.float32)
-    rc = lib().orc_forward(num_nodes, _p(lrp), _p(lc), _p(lv), L, _p(dims), wptr, bptr, _p(acts), _p(X),
-                           C.c_float(x_const), _p(scores))
+    keep = [[np.ascontiguousarray(a) for a in s] for s in sups]
+    rp = (C.c_void_p * (K - 1))(*[s[0].ctypes.data for s in keep])
+    cl = (C.c_void_p * (K - 1))(*[s[1].ctypes.data for s in keep])
+    vl = (C.c_void_p * (K - 1))(*[s[2].ctypes.data for s in keep])
+    rc = lib().orc_forward_poly(num_nodes, K, rp, cl, vl, L, _p(dims), wptr, bptr, _p(acts), _p(X),
+                                C.c_float(x_const), _p(scores))
     if rc:
         raise MemoryError("orc_forward")
     return scores
@@ -138,7 +164,12 @@ def solve(host_batch, layers, predict="mwis"):
     """Whole path on the CPU twin: supports -> forward -> priority -> lgs."""
     hb = host_batch
     lrp, lc, lv, fault = supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)
-    scores = forward((lrp, lc, lv), layers, hb.num_nodes)
+    sups = [(lrp, lc, lv)]
+    if len(layers[0]["weights"]) == 3:
+        r2, c2, v2, f2 = supports2(hb.graph_ptr, hb.row_ptr, hb.col_idx)
+        sups.append((r2, c2, v2))
+        fault |= f2
+    scores = forward(sups, layers, hb.num_nodes)
     s = scores[:, 0]
     prio = s.astype(np.float64) * hb.weights if predict == "mwis" else s.astype(np.float64)
     out = lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, prio, sum_weights=hb.weights, want_stats=False)

@@ -65,6 +65,63 @@ int orc_supports(int num_nodes, const int32_t* graph_ptr, int num_graphs, const 
     return fault;
 }
 
+/* T_2 = L.L as SciPy's csr_matmat forms it for gcn/utils.py:268-271 (float64 L with ascending columns):
+ * row i: sums[k] += L[i,j] * L[j,k] for j ascending (multiply, then add; this file is built with
+ * -ffp-contract=off), exact zeros dropped, ascending output columns, value cast to float32 (TF feed).
+ * Pass col2 = NULL to count only.  row_ptr2[num_nodes+1] is written in both modes.  Adjacency rows must be
+ * sorted.  Returns the fault mask. */
+int orc_supports2(int num_nodes, const int32_t* graph_ptr, int num_graphs, const int32_t* row_ptr, const int32_t* col_idx,
+                  const double* dinv_table, int table_len, int32_t* row_ptr2, int32_t* col2, float* val2) {
+    int fault = 0, maxn = 0;
+    for (int g = 0; g < num_graphs; ++g) if (graph_ptr[g + 1] - graph_ptr[g] > maxn) maxn = graph_ptr[g + 1] - graph_ptr[g];
+    double* acc = (double*)malloc(((size_t)maxn + 1) * sizeof(double));
+    double* dv = (double*)malloc(((size_t)maxn + 1) * sizeof(double));
+    int out = 0;
+    for (int g = 0; g < num_graphs; ++g) {
+        const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1], ng = n1 - n0;
+        for (int k = 0; k < ng; ++k) {
+            const int deg = row_ptr[n0 + k + 1] - row_ptr[n0 + k];
+            dv[k] = 0.0;
+            if (deg < table_len) dv[k] = dinv_table[deg]; else fault |= 4;
+        }
+        for (int i = 0; i < ng; ++i) {
+            for (int k = 0; k < ng; ++k) acc[k] = 0.0;
+            const int rs = row_ptr[n0 + i], re = row_ptr[n0 + i + 1];
+            int p = rs, diag_done = 0;
+            while (p < re || !diag_done) {
+                const int cj = p < re ? col_idx[p] - n0 : 0x7fffffff;
+                int j;
+                double lij;
+                if (!diag_done && cj > i) { j = i; lij = 1.0; diag_done = 1; }
+                else {
+                    ++p;
+                    if (cj < 0 || cj >= ng) { fault |= 8; continue; }
+                    if (cj == i) { fault |= 1; continue; }
+                    j = cj;
+                    lij = -(dv[j] * dv[i]);
+                }
+                for (int q = row_ptr[n0 + j]; q < row_ptr[n0 + j + 1]; ++q) {
+                    const int k = col_idx[q] - n0;
+                    if (k < 0 || k >= ng || k == j) continue;
+                    const double ljk = -(dv[j] * dv[k]);
+                    acc[k] = acc[k] + lij * ljk;
+                }
+                acc[j] = acc[j] + lij * 1.0;
+            }
+            row_ptr2[n0 + i] = out;
+            for (int k = 0; k < ng; ++k)
+                if (acc[k] != 0.0) {
+                    if (col2) { col2[out] = n0 + k; val2[out] = (float)acc[k]; }
+                    ++out;
+                }
+        }
+    }
+    row_ptr2[num_nodes] = out;
+    free(acc);
+    free(dv);
+    return fault;
+}
+
 void orc_transform(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                    int ldz) {
     for (int r = 0; r < rows; ++r)
@@ -108,29 +165,51 @@ void orc_spmm(int num_rows, const int32_t* row_ptr, const int32_t* col_idx, cons
         }
 }
 
-/* Whole forward, layer by layer.  dims[l], dims[l+1] = in/out of layer l; weights[l] is
- * [in][2*out] (W0 | W1); biases[l] may be NULL; acts[l] activation code. */
-int orc_forward(int num_nodes, const int32_t* lap_row_ptr, const int32_t* lap_col, const float* lap_val,
-                int num_layers, const int32_t* dims, const float* const* weights, const float* const* biases,
-                const int32_t* acts, const float* X, float x_const, float* scores) {
+/* Whole forward, layer by layer, over the supports [I, T_1, .., T_k] (num_supports = k + 1; sup_* arrays hold
+ * T_1..T_k).  dims[l], dims[l+1] = in/out of layer l; weights[l] is [in][num_supports*out] (W0 | W1 | ..);
+ * biases[l] may be NULL; acts[l] activation code.  out = ((Z_0 + T_1.Z_1) + T_2.Z_2 ..) + b, activation. */
+int orc_forward_poly(int num_nodes, int num_supports, const int32_t* const* sup_row_ptr, const int32_t* const* sup_col,
+                     const float* const* sup_val, int num_layers, const int32_t* dims, const float* const* weights,
+                     const float* const* biases, const int32_t* acts, const float* X, float x_const, float* scores) {
     int maxd = 0;
+    const int K = num_supports;
     for (int l = 0; l <= num_layers; ++l) if (dims[l] > maxd) maxd = dims[l];
-    float* Z = (float*)malloc((size_t)num_nodes * 2 * maxd * sizeof(float) + 16);
+    float* Z = (float*)malloc((size_t)num_nodes * K * maxd * sizeof(float) + 16);
     float* Hb = (float*)malloc((size_t)num_nodes * maxd * sizeof(float) + 16);
-    if (!Z || !Hb) { free(Z); free(Hb); return -1; }
+    float* Tb = (float*)malloc((size_t)num_nodes * maxd * sizeof(float) + 16);
+    if (!Z || !Hb || !Tb) { free(Z); free(Hb); free(Tb); return -1; }
     const float* H = X;
     int ldh = dims[0];
     for (int l = 0; l < num_layers; ++l) {
-        const int cin = dims[l], cout = dims[l + 1], ctot = 2 * cout;
+        const int cin = dims[l], cout = dims[l + 1], ctot = K * cout;
         orc_transform(H, ldh, x_const, num_nodes, cin, weights[l], ctot, Z, ctot);
         float* out = (l == num_layers - 1) ? scores : Hb;
-        orc_spmm(num_nodes, lap_row_ptr, lap_col, lap_val, Z + cout, ctot, cout, Z, ctot, biases[l], acts[l], out, cout, 0);
+        const float* run = Z;
+        int ldrun = ctot;
+        for (int i = 1; i < K; ++i) {
+            const int fin = i == K - 1;
+            float* dst = fin ? out : Tb;
+            orc_spmm(num_nodes, sup_row_ptr[i - 1], sup_col[i - 1], sup_val[i - 1], Z + i * cout, ctot, cout, run, ldrun,
+                     fin ? biases[l] : NULL, fin ? acts[l] : 0, dst, cout, 0);
+            run = dst;
+            ldrun = cout;
+        }
         H = out;
         ldh = cout;
     }
     free(Z);
     free(Hb);
+    free(Tb);
     return 0;
+}
+
+int orc_forward(int num_nodes, const int32_t* lap_row_ptr, const int32_t* lap_col, const float* lap_val,
+                int num_layers, const int32_t* dims, const float* const* weights, const float* const* biases,
+                const int32_t* acts, const float* X, float x_const, float* scores) {
+    const int32_t* rp[1] = {lap_row_ptr};
+    const int32_t* cl[1] = {lap_col};
+    const float* vl[1] = {lap_val};
+    return orc_forward_poly(num_nodes, 2, rp, cl, vl, num_layers, dims, weights, biases, acts, X, x_const, scores);
 }
 
 void orc_priority(int n, const float* scores, const double* weights, double* prio) {

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/all_models.npz: EVERY shipped cheb1 checkpoint of the reference (``model/result_*``)
+"""Generate tests/golden/all_models.npz: EVERY shipped checkpoint of the reference (``model/result_*``: 44 with
+max_degree = 1, "cheb1", and the two "cheb2" ones with supports [I, L, L.L])
 as float32 weights, with oracle scores on two fixture graphs.  TEST INFRASTRUCTURE; run only in the build
 container (needs /root/reference):
 
     python oracle/make_golden_models.py
 
 Contents (data only): ``names``; ``<model>|<variable>`` float32 tensors read from the TF V2 bundles (A11);
-``<model>|meta`` = [feature_size, hidden, num_layer]; per graph g in GRAPHS: ``g%02d|<model>|f32`` / ``|f64``
+``<model>|meta`` = [feature_size, hidden, num_layer, max_degree]; per graph g in GRAPHS: ``g%02d|<model>|f32`` / ``|f64``
 scores of the oracle restatement (oracle/ref_numpy.py - NOT reference output: TensorFlow cannot run here) and
 ``|set`` / ``|rounds`` of the reference's own ``local_greedy_search_count`` on the f32 priorities.
-The two ``cheb2`` checkpoints (max_degree = 2) are listed in ``skipped``: [I, L, L^2] supports are outside
-the hot-path scope (max_degree = 1).
+For the ``cheb2`` checkpoints the state holds the imported-reference-equivalent ``simple_polynomials(adj, 2)``
+(oracle/ref_numpy.py, itself pinned against the imported reference by tests/golden/supports.npz ``*_lap2_*``).
 """
 import os
 import re
@@ -40,19 +41,22 @@ def main():
         mm = NAME_RE.match(m)
         if not mm:
             continue
-        if int(mm.group("k")) != 1:
+        md = int(mm.group("k"))
+        if md not in (1, 2):
             skipped.append(m)
             continue
         tensors = load_bundle(os.path.join(REF, "model", m))
         params = {k: v for k, v in tensors.items() if "Adam" not in k and not k.endswith("_power")}
-        layers = orc.gcn_layer_specs(params)
+        layers = orc.gcn_layer_specs(params, num_supports=md + 1)
+        assert "gcn_dqn/graphconvolution_1_vars/weights_%d" % (md + 1) not in params, m
         F = layers[0]["weights"][0].shape[0]
-        assert F == int(mm.group("ld")), (m, F)
+        # the directory name is not authoritative: result_IS4SAT_deep_ld1_c1_l1_cheb2_* holds [32, 1] weights
+        assert F == int(mm.group("ld")) or md == 2, (m, F)
         assert len(layers) == int(mm.group("l")), (m, len(layers))
         names.append(m)
         for k, v in params.items():
             out["%s|%s" % (m, k)] = np.asarray(v, dtype=np.float32)
-        out["%s|meta" % m] = np.array([F, int(mm.group("c")), len(layers)], dtype=np.int32)
+        out["%s|meta" % m] = np.array([F, int(mm.group("c")), len(layers), md], dtype=np.int32)
         predict = mm.group("p")
         for gi in GRAPHS:
             key = "g%02d" % gi
@@ -60,7 +64,7 @@ def main():
             n = w.size
             adj = sp.csr_matrix((np.ones(graphs[key + "_indices"].size), graphs[key + "_indices"],
                                  graphs[key + "_indptr"]), shape=(n, n))
-            state = orc.makestate(adj, w.reshape(n, 1), F, 1, "dqn_call")  # rows of 1/F (weights are > 0)
+            state = orc.makestate(adj, w.reshape(n, 1), F, md, "dqn_call")  # rows of 1/F (weights are > 0)
             s32, _ = orc.gcn_forward(layers, state, np.float32)
             s64, _ = orc.gcn_forward(layers, state, np.float64)
             out["%s|%s|f32" % (key, m)] = s32.ravel()

@@ -85,6 +85,37 @@ def test_dqn_agent_solve_mwis(engine, golden, mname):
         agent.solve_mwis(golden.scipy(0), golden.csr(0)[2], train=True)
 
 
+@pytest.mark.parametrize("mname", ["result_IS4SAT_deep_ld1_c1_l1_cheb2_diver1_mwis_dqn",
+                                   "result_IS4SAT_deep_ld1_c1_l2_cheb2_diver1_mwis_dqn"])
+def test_dqn_agent_chebyshev_order_2(engine, golden, all_models, mname):
+    """The two shipped max_degree = 2 checkpoints ([I, L, L.L] supports, three weights per layer,
+    gcn/utils.py:268-271 + gcn/layers.py:199-208) through DQNAgent: makestate / predict / solve_mwis."""
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ref_numpy as orc
+    meta = all_models.meta(mname)
+    assert meta["max_degree"] == 2
+    F = meta["feature_size"]
+    agent = DQNAgent(F, flags=_flags(feature_size=F, hidden1=meta["hidden"], num_layer=meta["num_layer"], max_degree=2))
+    agent.model.set_params(all_models.params(mname))
+    layers = all_models.layers(mname)
+    assert len(layers[0]["weights"]) == 3
+    for i in (0, 2, 9):
+        adj, w = golden.scipy(i), golden.csr(i)[2].copy()
+        got, tot, _ = agent.solve_mwis(adj, w)
+        want, wtot, _ = orc.solve_mwis_dqn(layers, adj, w, feature_size=F, max_degree=2)
+        assert got == set(int(x) for x in want) and tot == pytest.approx(float(wtot), rel=1e-12)
+    adj, w = golden.scipy(0), golden.csr(0)[2]
+    state = agent.makestate(adj, w.reshape(-1, 1))
+    act_values, action = agent.predict(state)
+    assert np.abs(act_values[:, 0] - all_models.expect(0, mname, "f32")).max() <= 1e-5
+    assert len(state["support"]) == 3
+    foreign = orc.makestate(adj, w.reshape(-1, 1), F, 2, "dqn_call")  # supports built on the host, as the reference does
+    fv, fa = agent.predict(foreign)
+    assert np.abs(fv - act_values).max() <= 1e-5 and fa[0] == action[0]
+    with pytest.raises(ValueError, match="supports"):
+        DQNAgent(F, flags=_flags(feature_size=F, hidden1=meta["hidden"], num_layer=meta["num_layer"])).model.set_params(all_models.params(mname))
+
+
 def test_predict_state_api(engine, golden):
     """makestate/predict: act_values float32 [N,1], action int64 [1]; a foreign state (supports built
     by the oracle's SciPy code, as the reference would) gives the same scores within 1e-5."""

@@ -172,26 +172,64 @@ def test_reference_import_agrees_when_available(golden):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-def test_twin_on_every_shipped_checkpoint(golden, all_models):
-    """The C twin (kernel operation order) against the NumPy restatement on all 44 shipped cheb1 models:
-    hidden widths 1..64, input widths 1/2/16/32, 1..20 layers, two with a bias."""
+def _twin_supports(hb, num_supports):
     from oracle import ctwin
-    from distgcn_amd.batch import HostBatch
-    assert len(all_models.names) == 44
+    sups = [ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]]
+    if num_supports == 3:
+        sups.append(ctwin.supports2(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3])
+    return sups
+
+
+def test_twin_on_every_shipped_checkpoint(golden, all_models):
+    """The C twin (kernel operation order) against the NumPy restatement on all 46 shipped models: hidden widths
+    1..64, input widths 1/2/16/32, 1..20 layers, two with a bias, two with max_degree = 2 ([I, L, L.L]).
+    Bars: within 1e-5 of the float32 restatement (the closest available proxy of TF's float32 path) and
+    within max(1e-5, 2 |f32 - f64|) of the float64 restatement."""
+    from oracle import ctwin
+    assert len(all_models.names) == 46
+    assert sum(all_models.meta(n)["max_degree"] == 2 for n in all_models.names) == 2
     seen_widths = set()
     for gi in all_models.graph_ids:
         hb = golden.host_batch([gi])
-        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        sups = {k: _twin_supports(hb, k) for k in (2, 3)}
         for name in all_models.names:
             layers = all_models.layers(name)
             meta = all_models.meta(name)
             assert layers[0]["weights"][0].shape[0] == meta["feature_size"] and len(layers) == meta["num_layer"]
+            assert len(layers[0]["weights"]) == meta["max_degree"] + 1
             seen_widths.add(meta["hidden"])
-            got = ctwin.forward(lap, layers, hb.num_nodes)[:, 0]
+            got = ctwin.forward(sups[meta["max_degree"] + 1], layers, hb.num_nodes)[:, 0]
             f64, f32 = all_models.expect(gi, name, "f64"), all_models.expect(gi, name, "f32")
             bar = max(1e-5, 2.0 * np.abs(f32 - f64).max())
             assert np.abs(got - f64).max() <= bar, (name, gi)
+            assert np.abs(got - f32).max() <= 1e-5, (name, gi, float(np.abs(got - f32).max()))
     assert {1, 2, 3, 4, 8, 16, 32, 48, 64} <= seen_widths
+
+
+def test_second_order_support_matches_the_imported_reference(golden):
+    """T_2 = L.L of the twin (dgcn_oracle.c: SciPy csr_matmat order in float64, cast to float32) against the
+    imported reference's simple_polynomials(adj, 2)[2] (tests/golden/supports.npz *_lap2_*), bit for bit, and the
+    restatement's float64 values exactly."""
+    from oracle import ctwin
+    import scipy.sparse as sp
+    seen = 0
+    for i in range(golden.num_graphs):
+        key = "g%02d_lap2_indptr" % i
+        if key not in golden.supports.files:
+            continue
+        seen += 1
+        hb = golden.host_batch([i])
+        r2, c2, v2, fault = ctwin.supports2(hb.graph_ptr, hb.row_ptr, hb.col_idx)
+        assert fault == 0
+        assert np.array_equal(r2, golden.supports[key])
+        assert np.array_equal(c2, golden.supports["g%02d_lap2_indices" % i])
+        want = golden.supports["g%02d_lap2_data" % i]
+        assert np.array_equal(v2.view(np.uint32), want.astype(np.float32).view(np.uint32))
+        t2 = orc.simple_polynomials(golden.scipy(i), 2)[2]
+        m = sp.csr_matrix((t2[1], (t2[0][:, 0], t2[0][:, 1])), shape=t2[2])
+        m.sort_indices()
+        assert np.array_equal(m.indices, golden.supports["g%02d_lap2_indices" % i]) and np.array_equal(m.data, want)
+    assert seen >= 3
 
 
 def test_known_answers_of_100_shipped_graphs(dataset100):
