@@ -24,8 +24,8 @@ FAULT_NAMES = {
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
-    "dgcn_version", "dgcn_last_error", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
-    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
+    "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
+    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
 
@@ -60,6 +60,12 @@ class DgcnModel(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("num_supports", C.c_int32), ("layers_host", C.POINTER(DgcnLayer))]
 
 
+class DgcnPackInfo(C.Structure):
+    _fields_ = [("num_graphs", C.c_int32), ("num_nodes", C.c_int32), ("num_edges", C.c_int32), ("max_nodes", C.c_int32),
+                ("max_graph_edges", C.c_int32), ("max_degree", C.c_int32), ("off_graph_ptr", C.c_int64),
+                ("off_row_ptr", C.c_int64), ("off_col_idx", C.c_int64), ("off_weights", C.c_int64), ("total_bytes", C.c_int64)]
+
+
 _lib = None
 
 
@@ -81,6 +87,10 @@ def load():
     vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
     lib.dgcn_version.restype = C.c_int
     lib.dgcn_last_error.restype = C.c_char_p
+    lib.dgcn_pack_measure.restype = C.c_int
+    lib.dgcn_pack_measure.argtypes = [vp, vp, i32, i32, i32, C.POINTER(DgcnPackInfo), vp]
+    lib.dgcn_pack_batch.restype = C.c_int
+    lib.dgcn_pack_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, sz, C.POINTER(DgcnPackInfo), i32]
     lib.dgcn_supports_batch.restype = C.c_int
     lib.dgcn_supports_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
     lib.dgcn_supports2_count_batch.restype = C.c_int
@@ -105,6 +115,8 @@ def load():
     lib.dgcn_argmax_batch.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.dgcn_lgs_batch.restype = C.c_int
     lib.dgcn_lgs_batch.argtypes = [C.POINTER(DgcnBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dgcn_margin_risk_batch.restype = C.c_int
+    lib.dgcn_margin_risk_batch.argtypes = [C.POINTER(DgcnBatch), vp, vp, vp, vp, C.c_double, vp, vp]
     lib.dgcn_lgs_masked_batch.restype = C.c_int
     lib.dgcn_lgs_masked_batch.argtypes = [C.POINTER(DgcnBatch), vp, C.c_int64, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.dgcn_solve_supported.restype = C.c_int

@@ -1101,7 +1101,7 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 1;
-    a.lane_map = getenv("DGCN_FUSED_LANEMAP") ? atoi(getenv("DGCN_FUSED_LANEMAP")) : 0;
+    a.lane_map = getenv("DGCN_FUSED_LANEMAP") ? atoi(getenv("DGCN_FUSED_LANEMAP")) : 1;  // measured: 224.7 -> 218.8 us on C3
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
 #endif

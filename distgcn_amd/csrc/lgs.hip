@@ -283,9 +283,68 @@ static int launch_lgs(const LgsArgs& a, int B, size_t lds, hipStream_t s) {
     return check_launch("k_lgs");
 }
 
+// ---------------------------------------------------------------------------------------------
+// which selected sets could a score error flip?
+// The local greedy search returns the lexicographically-first maximal independent set S under the total order
+// (priority desc, index asc), and S is THE set with: S independent, and every vertex outside S has a neighbour
+// in S that precedes it.  So S survives any perturbation of the priorities that keeps, for every excluded
+// vertex v, at least one member neighbour u ahead of it.  With every score off by at most `delta`, priorities
+// p = score * w move by at most delta * |w|, hence v is SAFE iff some member neighbour u has
+//     p_u - p_v > delta * (|w_u| + |w_v|)
+// (a tie or a thinner margin is not safe).  risky[g] = number of excluded vertices of graph g that are not safe;
+// risky[g] == 0 proves that graph's set is the same for every score vector within delta of the given one.
+// 8 lanes per vertex, one pass over the adjacency; runs after the search, outside the solver launch.
+__global__ __launch_bounds__(256) void k_margin_risk(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ col_idx, const double* __restrict__ prio,
+                                                     const float* __restrict__ scores, const double* __restrict__ weights,
+                                                     const uint8_t* __restrict__ state, double delta,
+                                                     int32_t* __restrict__ risky) {
+    const int g = blockIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    const int sub = threadIdx.x & 7;
+    auto pri = [&](int v) -> double {
+        if (prio) return prio[v];
+        return weights ? (double)scores[v] * weights[v] : (double)scores[v];
+    };
+    auto wabs = [&](int v) -> double { return (weights && !prio) ? fabs(weights[v]) : 1.0; };
+    int count = 0;
+    for (int v0 = n0 + (threadIdx.x >> 3); v0 - (int)(threadIdx.x >> 3) < n1; v0 += 32) {
+        const int v = v0;
+        bool need = v < n1 && state[v] == 2, safe = false;
+        if (need) {
+            const double pv = pri(v), wv = wabs(v);
+            for (int j = row_ptr[v] + sub; j < row_ptr[v + 1]; j += 8) {
+                const int u = col_idx[j];
+                if (state[u] == 1) safe |= (pri(u) - pv) > delta * (wabs(u) + wv);
+            }
+        }
+        safe |= __shfl_xor((int)safe, 1) != 0;
+        safe |= __shfl_xor((int)safe, 2) != 0;
+        safe |= __shfl_xor((int)safe, 4) != 0;
+        count += (need && !safe && sub == 0);
+    }
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    if (count) atomicAdd(&total, count);
+    __syncthreads();
+    if (threadIdx.x == 0) risky[g] = total;
+}
+
 }  // namespace dgcn
 
 using namespace dgcn;
+
+extern "C" int dgcn_margin_risk_batch(const DgcnBatch* b, const double* prio, const float* scores, const double* weights,
+                                      const uint8_t* state, double delta, int32_t* risky, void* stream) {
+    if (!b || !state || !risky || (!prio && !scores)) return fail(DGCN_ERR_ARG, "dgcn_margin_risk_batch: null argument");
+    if (!(delta >= 0.0)) return fail(DGCN_ERR_ARG, "dgcn_margin_risk_batch: delta must be >= 0");
+    if (b->num_graphs <= 0) return DGCN_OK;
+    TimedLaunch t("margin_risk", (hipStream_t)stream);
+    DGCN_LAUNCH(t, k_margin_risk, dim3(b->num_graphs), dim3(256), 0, (hipStream_t)stream, b->graph_ptr, b->row_ptr, b->col_idx,
+                prio, scores, weights, state, delta, risky);
+    return check_launch("k_margin_risk");
+}
 
 static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
                              const double* weights, const uint8_t* init_state, int32_t num_instances,

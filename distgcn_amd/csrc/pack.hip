@@ -1,0 +1,252 @@
+// Host-side batch ingestion: many per-graph CSR adjacencies -> ONE block-diagonal batch (include/dgcn.h
+// "A batch of graphs is ONE block-diagonal CSR") written straight into the caller's (pinned) staging buffer,
+// ready for a single host-to-device copy.
+//
+// The reference parses one .mat file and calls the solver per graph (mwis_dqn_test.py:304-321); the batched
+// path needs the graphs side by side.  Doing that with NumPy concatenations costs ~5 ms per 500 graphs - 20x the
+// fused kernel's launch time - so it is native: one pass over the inputs, a few worker threads, no
+// intermediate copies, structural validation on the way (anything that could make a kernel read out of
+// bounds; self-loops / NaNs are data faults the kernels report through the status word).
+//
+// No device code in this file: it is plain host C++ inside libdgcn.so (built by hipcc like the rest).
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace dgcn {
+
+// ---- a small persistent worker pool (thread creation costs more than packing a C3 batch)
+class Pool {
+public:
+    static Pool& get() {
+        static Pool p;
+        return p;
+    }
+    // run fn(part) for part in [0, parts) on up to `parts` threads (the caller takes part 0)
+    void run(int parts, const std::function<void(int)>& fn) {
+        if (parts <= 1) { fn(0); return; }
+        std::unique_lock<std::mutex> call_lock(call_mu_);  // one parallel region at a time
+        ensure(parts - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            parts_ = parts;
+            next_ = 1;
+            pending_ = parts - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    Pool() = default;
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void ensure(int n) {
+        while ((int)workers_.size() < n) workers_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            int part = -1;
+            const std::function<void(int)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && next_ < parts_); });
+                if (stop_) return;
+                part = next_++;
+                fn = fn_;
+                if (next_ >= parts_) seen = epoch_;
+            }
+            (*fn)(part);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int parts_ = 0, next_ = 0, pending_ = 0;
+    unsigned long epoch_ = 0;
+    bool stop_ = false;
+};
+
+static inline int64_t align16(int64_t x) { return (x + 15) & ~(int64_t)15; }
+
+template <typename I>
+static int measure_t(const void* const* indptr, const int32_t* num_nodes, int B, int with_weights, DgcnPackInfo* info,
+                     int64_t* nnz_out) {
+    int64_t n = 0, e = 0;
+    int max_n = 0;
+    int64_t max_e = 0;
+    for (int g = 0; g < B; ++g) {
+        const int ng = num_nodes[g];
+        if (ng < 0 || !indptr[g]) return fail(DGCN_ERR_ARG, "dgcn_pack: graph %d has no indptr / a negative size", g);
+        const I* p = static_cast<const I*>(indptr[g]);
+        const int64_t eg = (int64_t)p[ng];
+        if (p[0] != 0 || eg < 0) return fail(DGCN_ERR_ARG, "dgcn_pack: graph %d: indptr must start at 0 and end >= 0", g);
+        if (nnz_out) nnz_out[g] = eg;
+        n += ng;
+        e += eg;
+        if (ng > max_n) max_n = ng;
+        if (eg > max_e) max_e = eg;
+    }
+    if (n >= (int64_t)1 << 31 || e >= ((int64_t)1 << 31) - n)
+        return fail(DGCN_ERR_ARG, "dgcn_pack: batch too large for int32 indices (%lld vertices, %lld entries)", (long long)n, (long long)e);
+    info->num_graphs = B;
+    info->num_nodes = (int32_t)n;
+    info->num_edges = (int32_t)e;
+    info->max_nodes = max_n;
+    info->max_graph_edges = (int32_t)max_e;
+    info->max_degree = 0;
+    int64_t off = 0;
+    info->off_graph_ptr = off; off = align16(off + (int64_t)(B + 1) * 4);
+    info->off_row_ptr = off;   off = align16(off + (n + 1) * 4);
+    info->off_col_idx = off;   off = align16(off + (e > 0 ? e : 1) * 4);
+    info->off_weights = with_weights ? off : -1;
+    if (with_weights) off = align16(off + (n > 0 ? n : 1) * 8);
+    info->total_bytes = off > 16 ? off : 16;
+    return DGCN_OK;
+}
+
+template <typename I>
+static int pack_t(const void* const* indptr, const void* const* indices, const double* const* weights,
+                  const int32_t* num_nodes, int B, char* dst, DgcnPackInfo* info, int threads) {
+    int32_t* graph_ptr = reinterpret_cast<int32_t*>(dst + info->off_graph_ptr);
+    int32_t* row_ptr = reinterpret_cast<int32_t*>(dst + info->off_row_ptr);
+    int32_t* col_idx = reinterpret_cast<int32_t*>(dst + info->off_col_idx);
+    double* wts = info->off_weights >= 0 ? reinterpret_cast<double*>(dst + info->off_weights) : nullptr;
+    // offsets of every graph (sequential: B adds), kept in graph_ptr and a scratch edge-offset array
+    std::vector<int32_t> edge_off((size_t)B + 1);
+    int64_t n = 0, e = 0;
+    for (int g = 0; g < B; ++g) {
+        graph_ptr[g] = (int32_t)n;
+        edge_off[g] = (int32_t)e;
+        n += num_nodes[g];
+        e += (int64_t) static_cast<const I*>(indptr[g])[num_nodes[g]];
+    }
+    graph_ptr[B] = (int32_t)n;
+    edge_off[B] = (int32_t)e;
+    if (n != info->num_nodes || e != info->num_edges) return fail(DGCN_ERR_ARG, "dgcn_pack_batch: inputs changed since dgcn_pack_measure");
+    row_ptr[n] = (int32_t)e;
+    if (e == 0) col_idx[0] = 0;
+    if (wts && n == 0) wts[0] = 0.0;
+    // contiguous graph ranges per worker, balanced on entries + vertices
+    threads = std::max(1, std::min(threads, std::min(B, 64)));
+    if (e + n < 200000) threads = std::min(threads, 2);  // not worth waking more workers
+    std::vector<int> cut((size_t)threads + 1, B);
+    cut[0] = 0;
+    {
+        const int64_t total = e + n;
+        int g = 0;
+        for (int t = 1; t < threads; ++t) {
+            const int64_t target = total * t / threads;
+            while (g < B && (int64_t)edge_off[g] + graph_ptr[g] < target) ++g;
+            cut[t] = g;
+        }
+    }
+    std::atomic<int> bad_graph{-1};
+    std::atomic<int> bad_kind{0};
+    std::vector<int> maxdeg((size_t)threads, 0);
+    auto work = [&](int part) {
+        int md = 0;
+        for (int g = cut[part]; g < cut[part + 1]; ++g) {
+            const int ng = num_nodes[g];
+            const I* p = static_cast<const I*>(indptr[g]);
+            const I* c = static_cast<const I*>(indices[g]);
+            const int32_t n0 = graph_ptr[g], e0 = edge_off[g];
+            const int64_t eg = (int64_t)p[ng];
+            if (eg > 0 && !c) { bad_graph = g; bad_kind = 3; continue; }
+            int32_t* rp = row_ptr + n0;
+            int64_t prev = 0;
+            bool ok = true;
+            for (int v = 0; v < ng; ++v) {
+                const int64_t cur = (int64_t)p[v];
+                ok &= cur >= prev;
+                const int64_t nxt = (int64_t)p[v + 1];
+                const int64_t d = nxt - cur;
+                if (d > md) md = (int)std::min<int64_t>(d, 0x7fffffff);
+                rp[v] = (int32_t)(e0 + cur);
+                prev = cur;
+            }
+            ok &= eg >= prev;
+            if (!ok) { bad_graph = g; bad_kind = 1; continue; }
+            int32_t* cc = col_idx + e0;
+            unsigned range_bad = 0;
+            for (int64_t j = 0; j < eg; ++j) {
+                const int64_t u = (int64_t)c[j];
+                range_bad |= (unsigned)(u < 0) | (unsigned)(u >= ng);
+                cc[j] = (int32_t)(u + n0);
+            }
+            if (range_bad) { bad_graph = g; bad_kind = 2; continue; }
+            if (wts) {
+                if (!weights || !weights[g]) { if (ng) { bad_graph = g; bad_kind = 4; } continue; }
+                std::memcpy(wts + n0, weights[g], (size_t)ng * sizeof(double));
+            }
+        }
+        maxdeg[part] = md;
+    };
+    Pool::get().run(threads, work);
+    if (bad_graph.load() >= 0) {
+        static const char* what[] = {"", "indptr is not non-decreasing", "a column index is outside [0, n)", "indices missing",
+                                     "weights missing"};
+        return fail(DGCN_ERR_ARG, "dgcn_pack_batch: graph %d: %s", bad_graph.load(), what[bad_kind.load()]);
+    }
+    int md = 0;
+    for (int t = 0; t < threads; ++t) md = std::max(md, maxdeg[t]);
+    info->max_degree = md;
+    return DGCN_OK;
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_pack_measure(const void* const* indptr_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                                 int32_t index_bytes, int32_t with_weights, DgcnPackInfo* info, int64_t* nnz_out_host) {
+    if (!info || num_graphs < 0 || (num_graphs > 0 && (!indptr_host || !num_nodes_host)))
+        return fail(DGCN_ERR_ARG, "dgcn_pack_measure: null argument");
+    if (index_bytes == 4) return measure_t<int32_t>(indptr_host, num_nodes_host, num_graphs, with_weights, info, nnz_out_host);
+    if (index_bytes == 8) return measure_t<int64_t>(indptr_host, num_nodes_host, num_graphs, with_weights, info, nnz_out_host);
+    return fail(DGCN_ERR_ARG, "dgcn_pack_measure: index_bytes must be 4 or 8");
+}
+
+extern "C" int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_host,
+                               const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                               int32_t index_bytes, void* staging_host, size_t staging_bytes, DgcnPackInfo* info,
+                               int32_t num_threads) {
+    if (!info || !staging_host || num_graphs < 0 || (num_graphs > 0 && (!indptr_host || !indices_host || !num_nodes_host)))
+        return fail(DGCN_ERR_ARG, "dgcn_pack_batch: null argument");
+    if ((int64_t)staging_bytes < info->total_bytes)
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_pack_batch: staging buffer %zu < %lld bytes", staging_bytes, (long long)info->total_bytes);
+    if (info->num_graphs != num_graphs) return fail(DGCN_ERR_ARG, "dgcn_pack_batch: info is for %d graphs", info->num_graphs);
+    if (num_threads <= 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        num_threads = (int)std::min(8u, hc ? hc : 1u);
+    }
+    char* dst = static_cast<char*>(staging_host);
+    if (index_bytes == 4)
+        return pack_t<int32_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads);
+    if (index_bytes == 8)
+        return pack_t<int64_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads);
+    return fail(DGCN_ERR_ARG, "dgcn_pack_batch: index_bytes must be 4 or 8");
+}

@@ -241,7 +241,10 @@ template <int VEC, int LPR, int G>
 static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
                        const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s) {
     constexpr size_t kLdsMax = 150 * 1024;    // one workgroup may own (almost) the whole 160 KB LDS
-    const int pad = env_int("DGCN_SPMM_PAD", VEC);  // default: pad one vector, staggers rows across LDS banks
+    // LDS row stride of the staged Z slice = C + pad floats.  Measured on working sets beyond the Infinity Cache
+    // (tools/tune_spmm_hbm.py, 4 000 ER graphs per launch): no padding 103.3 us, one vector 107.9 us, two 107.4 us -
+    // the denser slice (25.6 instead of 28.8 KB per graph) is worth more than the staggered banks.
+    const int pad = env_int("DGCN_SPMM_PAD", 0);
     const int zs = (C == 1) ? 1 : C + (pad / VEC) * VEC;
     const size_t zbytes = (size_t)((max_nodes * zs + 3) & ~3) * sizeof(float);
     const int force_global = env_int("DGCN_SPMM_GLOBAL", 0);

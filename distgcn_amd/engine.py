@@ -285,6 +285,17 @@ class Engine:
         return {"state": state[:n], "rounds": rounds[:B], "stats": stats, "overhead": overhead,
                 "totals": totals, "status": status, "flat": pk["flat"], "layout": pk["layout"]}
 
+    def margin_risk(self, b: DeviceBatch, state, delta: float, prio=None, scores=None, weights=None):
+        """per graph, the number of excluded vertices whose exclusion a score error of ``delta`` could
+        overturn (``dgcn_margin_risk_batch``); 0 proves the graph's set is the same for every score vector within
+        ``delta`` of this one.  -> int32 device tensor [num_graphs]."""
+        t = self.torch
+        out = t.zeros(max(b.host.num_graphs, 1), dtype=t.int32, device=self.device)
+        p = lambda x: x.data_ptr() if x is not None else None
+        _lib.check(self.lib.dgcn_margin_risk_batch(C.byref(b.c), p(prio), p(scores), p(weights), state.data_ptr(),
+                                                   float(delta), out.data_ptr(), self._stream()), "dgcn_margin_risk_batch")
+        return out[:b.host.num_graphs]
+
     def lgs_masked(self, b: DeviceBatch, prio, init_state, num_instances: int, sum_weights=None, max_rounds: int = 0,
                    prio_stride: int = 0):
         """Greedy search on ``num_instances`` residuals of the same batch (``dgcn_lgs_masked_batch``).

@@ -89,6 +89,29 @@ typedef struct DgcnModel {
 int dgcn_version(void);
 const char* dgcn_last_error(void);
 
+/* ---- batch ingestion (host side): what mwis_dqn_test.py:304-321 does one .mat file at a time ------------
+ * Packs num_graphs per-graph CSR adjacencies (SciPy's indptr / indices arrays as they are, int32 or int64:
+ * index_bytes = 4 / 8; optional float64 vertex weights) into ONE block-diagonal batch laid out in the
+ * caller's HOST staging buffer (pinned memory, so that a single hipMemcpyAsync moves the batch):
+ *   [graph_ptr int32[B+1] | row_ptr int32[N+1] | col_idx int32[E] (global ids) | weights float64[N]]
+ * each section 16-byte aligned at the byte offsets returned in DgcnPackInfo; the same offsets hold on the
+ * device copy.  dgcn_pack_measure reads only the sizes (fills everything but max_degree) so the caller can
+ * size the buffer; dgcn_pack_batch writes it with num_threads workers (0 = up to 8) and fills max_degree.
+ * Structural validation only (what could make a kernel read out of bounds: indptr monotone from 0, column
+ * ids inside [0, n)); self-loops and NaNs are reported later by the kernels' status word.
+ * All pointers here are HOST pointers.  Thread-safe; keeps no pointer after returning. */
+typedef struct DgcnPackInfo {
+    int32_t num_graphs, num_nodes, num_edges, max_nodes, max_graph_edges, max_degree;
+    int64_t off_graph_ptr, off_row_ptr, off_col_idx, off_weights; /* byte offsets; off_weights = -1 without weights */
+    int64_t total_bytes;
+} DgcnPackInfo;
+int dgcn_pack_measure(const void* const* indptr_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                      int32_t index_bytes, int32_t with_weights, DgcnPackInfo* info,
+                      int64_t* nnz_out_host /* [num_graphs] entries per graph, or NULL: lets the caller check its indices arrays' lengths */);
+int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
+                    const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes,
+                    void* staging_host, size_t staging_bytes, DgcnPackInfo* info, int32_t num_threads);
+
 /* ---- A1/A2: gcn/utils.py:120-127 normalize_adj + :258-274 simple_polynomials (k = 1) ----------
  * Builds L = I - D^-1/2 A D^-1/2 for the whole batch.  dinv_table[d] must hold the float64 value
  * numpy.power(d, -0.5) with inf -> 0 (table built once by the host so the float64 bits equal the
@@ -178,6 +201,18 @@ int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr,
 int dgcn_lgs_batch(const DgcnBatch* batch, const double* prio, const float* scores, const double* weights,
                    int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
                    const double* sum_weights, double* totals, int32_t* status, void* stream);
+
+/* ---- how fragile is a selected set against score error? ---------------------------------
+ * (mwis_gdpg_call.py:211-216 feeds float32 scores x float64 weights into heuristics.py:103-111's compares.)
+ * The search returns the lexicographically-first maximal independent set S under (priority desc, index asc),
+ * which is the unique independent set in which every excluded vertex has a member neighbour ahead of it.
+ * risky[g] = number of excluded vertices v (state 2) of graph g WITHOUT a member neighbour u (state 1) with
+ *     p_u - p_v > delta * (|w_u| + |w_v|)        (p = prio, or (double)score * weight; |w| = 1 when prio is given
+ *                                                 or weights is NULL)
+ * risky[g] == 0 proves graph g's set is identical for EVERY score vector within delta (per score) of this one -
+ * e.g. TensorFlow's float32 result if it is within delta of these scores.  `state` must be a finished search. */
+int dgcn_margin_risk_batch(const DgcnBatch* batch, const double* prio, const float* scores, const double* weights,
+                           const uint8_t* state, double delta, int32_t* risky, void* stream);
 
 /* ---- greedy search on many residuals of the same batch: the rollout of mwis_gdpg_call.py:629-645 ----
  * Instance k (0 <= k < num_instances) runs the local greedy search on the batch with the vertices

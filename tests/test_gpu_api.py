@@ -437,6 +437,37 @@ def test_c5_rollout_n500(engine, family):
     assert np.all((adj @ sel.astype(np.float64) > 0) | sel)
 
 
+def test_c5_rollout_full_size_trained_l20(engine, golden):
+    """BASELINE config 5 at full size: 64 ER G(500, 0.02) conflict graphs, the trained IS4SAT l=20 c=32 weights,
+    rollout search b=16, all 64 graphs advanced together on the device (one launch per step).  The Python oracle
+    needs minutes per graph at l=20, so the check is: independence + maximality on all 64, and - for three of
+    them - the same set as the host-re-slicing path (the reference's own control flow: SciPy re-slicing per step,
+    mwis_gdpg_call.py:596-659, with every forward pass and greedy completion on the device)."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.gcn.models import GCN_DQN
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=20), seed=1)
+    agent.model = GCN_DQN(None, input_dim=1, flags=_flags(num_layer=20))
+    agent.model.set_params(golden.params(M20))
+    adjs, wts = [], []
+    for g in range(64):
+        rng = np.random.default_rng(20230700 + g)
+        indptr, indices = datagen.er_graph(500, 0.02, rng)
+        adjs.append(sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(500, 500)))
+        wts.append(rng.random(500))
+    got = agent.solve_iterative_batch(adjs, wts, "rollout", b=16)
+    assert got is not None and len(got) == 64
+    for (sel, total), adj, w in zip(got, adjs, wts):
+        m = np.zeros(500, bool); m[list(sel)] = True
+        assert not (adj[m][:, m]).nnz and np.all((adj @ m.astype(np.float64) > 0) | m)
+        assert float(np.asarray(total).ravel()[0]) == pytest.approx(float(w[m].sum()), rel=1e-12)
+    agent.device_iterative = False
+    for g in (0, 31, 63):
+        sel, total = agent.solve_mwis_rollout(adjs[g], wts[g], b=16)
+        assert sel == got[g][0], g
+
+
 def test_large_graph_takes_layered_path(engine):
     """Graphs beyond the fused kernel's 512 vertices / 160 KB image run layer by layer, same results."""
     from distgcn_amd import datagen
@@ -633,3 +664,42 @@ def _solve(engine, db, dm):
     out = engine.solve_buffers(db, False)
     engine.solve_fused(db, dm, want_scores=False, out=out)
     return out
+
+
+def test_serving_pipeline_host_to_host(engine, golden):
+    """distgcn_amd.serving.SolvePipeline: per-graph CSR arrays in host memory -> native packing into pinned memory ->
+    one copy in, one fused launch, one copy out; several batches in flight, results in submission order and equal to
+    the twin's; a slot must be read before it is re-used; faults surface at result()."""
+    from distgcn_amd import datagen
+    from distgcn_amd._lib import DgcnError
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.serving import SolvePipeline
+    from oracle import ctwin
+    layers = golden.layers(M20)
+    dm = DeviceModel(layers, engine.device)
+    pipe = SolvePipeline(engine, dm, depth=3)
+    batches, refs = [], []
+    for k, (count, n) in enumerate([(40, 200), (7, 60), (64, 120), (1, 300), (33, 200)]):
+        hb = datagen.er_batch(count, n, 0.1, first_index=1000 * k)
+        ps, cs, ws = [], [], []
+        for n0, n1 in hb.graph_slices():
+            e0, e1 = int(hb.row_ptr[n0]), int(hb.row_ptr[n1])
+            ps.append(np.ascontiguousarray(hb.row_ptr[n0:n1 + 1] - e0)); cs.append(np.ascontiguousarray(hb.col_idx[e0:e1] - n0))
+            ws.append(np.ascontiguousarray(hb.weights[n0:n1]))
+        batches.append((ps, cs, ws))
+        refs.append(ctwin.solve(hb, layers))
+    got = list(pipe.solve_many(batches))
+    assert len(got) == len(refs)
+    for g, r in zip(got, refs):
+        assert np.array_equal(g["state"], r["state"]) and np.array_equal(g["rounds"], r["rounds"])
+        assert np.allclose(g["totals"], r["totals"], rtol=1e-12, atol=0)
+    slots = [pipe.submit(*batches[0]) for _ in range(3)]
+    with pytest.raises(RuntimeError, match="unread result"):
+        pipe.submit(*batches[0])
+    for s_ in slots:
+        assert np.array_equal(pipe.result(s_)["state"], refs[0]["state"])
+    bad = (batches[1][0], batches[1][1], [w.copy() for w in batches[1][2]])
+    bad[2][3][0] = np.nan
+    with pytest.raises(DgcnError, match="NaN"):
+        pipe.result(pipe.submit(*bad))
+    assert np.array_equal(pipe.result(pipe.submit(*batches[1]))["state"], refs[1]["state"])  # the pipeline recovers

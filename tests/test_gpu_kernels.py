@@ -323,19 +323,20 @@ def _independent_and_maximal(hb, state):
 
 @pytest.mark.parametrize("config", ["C2", "C3", "BA"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_solve_full_size_vs_twin(engine, config, mode):
-    """BASELINE.json full sizes: 500 ER graphs (C2: N=100 l=1; C3: N=200 l=20 c32) and a 500-graph BA
-    test2 mix.  Scores bit-exact vs the CPU twin, hence selected sets bit-identical; plus the
-    size-independent properties (independence, maximality)."""
+def test_solve_full_size_vs_twin(engine, golden, config, mode):
+    """BASELINE.json full sizes with the TRAINED weights the benchmark runs (fixture copies of the shipped
+    checkpoints): 500 ER graphs (C2: N=100, IS4SAT l=1; C3: N=200, IS4SAT l=20 c32) and a 500-graph BA test2 mix
+    (C4's per-GPU share, DQNBA l=20).  Scores bit-exact vs the CPU twin, hence selected sets bit-identical; plus
+    the size-independent properties (independence, maximality)."""
     from distgcn_amd import datagen
     from distgcn_amd.engine import DeviceModel
     from oracle import ctwin
     if config == "C2":
-        hb, layers = datagen.er_batch(500, 100, 0.1), datagen.random_model(1, 32)
+        hb, layers = datagen.er_batch(500, 100, 0.1), golden.layers("result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn")
     elif config == "C3":
-        hb, layers = datagen.er_batch(500, 200, 0.1), datagen.random_model(20, 32)
+        hb, layers = datagen.er_batch(500, 200, 0.1), golden.layers("result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn")
     else:
-        hb, layers = datagen.ba_test2_batch(500), datagen.random_model(20, 32, seed=11)
+        hb, layers = datagen.ba_test2_batch(500), golden.layers("result_DQNBA_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn")
     db = engine.upload(hb)
     res = engine.solve(db, DeviceModel(layers, engine.device), mode=mode)
     engine.check_status(res["status"])
@@ -520,3 +521,40 @@ def test_large_batch_is_the_small_batch_tiled(engine):
             assert np.array_equal(np.tile(s, 20), l), (mode, k)
         assert np.array_equal(np.tile(small["scores"].cpu().numpy().ravel().view(np.uint32), 20),
                               large["scores"].cpu().numpy().ravel().view(np.uint32))
+
+
+def test_margin_risk_counts_and_guarantee(engine, golden):
+    """dgcn_margin_risk_batch: counts equal the NumPy checker's on the fixture graphs for several
+    deltas, and the guarantee holds - perturb every score by up to delta at random, solve again: every graph the kernel
+    reported as risk-free keeps exactly its set."""
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ref_numpy as orc
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    dm = DeviceModel(golden.layers("result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn"), engine.device)
+    res = engine.solve(db, dm, mode=1)
+    engine.check_status(res["status"])
+    scores = res["scores"].reshape(-1)
+    state = res["state"].cpu().numpy()
+    s_host = scores.cpu().numpy().astype(np.float64)
+    prio = s_host * hb.weights
+    rng = np.random.default_rng(5)
+    some_risk = False
+    for delta in (0.0, 2e-6, 2e-5, 1e-3, 1e-2):
+        got = engine.margin_risk(db, res["state"], delta, scores=scores, weights=db.weights).cpu().numpy()
+        for g, (n0, n1) in enumerate(hb.graph_slices()):
+            p, c, _ = golden.csr(g)
+            assert got[g] == orc.margin_risk(p, c, prio[n0:n1], state[n0:n1], delta, hb.weights[n0:n1]), (delta, g)
+        some_risk |= bool(got.sum())
+        for trial in range(3):
+            pert = (s_host + rng.uniform(-delta, delta, size=s_host.size)) * hb.weights
+            again = engine.lgs(db, prio=_dev(engine, pert), sum_weights=db.weights)["state"].cpu().numpy()
+            for g, (n0, n1) in enumerate(hb.graph_slices()):
+                if got[g] == 0:
+                    assert np.array_equal(again[n0:n1] == 1, state[n0:n1] == 1), (delta, g, trial)
+    assert some_risk  # the large deltas do flag graphs
+    # prio given directly (|w| = 1) and an unweighted score run
+    got = engine.margin_risk(db, res["state"], 1e-4, prio=_dev(engine, prio)).cpu().numpy()
+    for g, (n0, n1) in enumerate(hb.graph_slices()):
+        p, c, _ = golden.csr(g)
+        assert got[g] == orc.margin_risk(p, c, prio[n0:n1], state[n0:n1], 1e-4)

@@ -167,3 +167,70 @@ def test_matfile_reader_round_trip(tmp_path, compress):
     bad = sp.csr_matrix(np.triu(np.ones((4, 4)), 1))
     with pytest.raises(ValueError):
         matfile.symmetric_csr(matfile.SparseCSC((4, 4), bad.tocsc().indptr, bad.tocsc().indices, None))
+
+
+def _random_csr_lists(rng, count, dtype):
+    from distgcn_amd import datagen
+    ps, cs, ws = [], [], []
+    for _ in range(count):
+        n = int(rng.integers(0, 40))
+        ip, ix = datagen.er_graph(n, float(rng.choice([0.0, 0.1, 0.5])), rng) if n else (np.zeros(1, np.int64), np.zeros(0, np.int64))
+        ps.append(ip.astype(dtype)); cs.append(ix.astype(dtype)); ws.append(rng.random(n))
+    return ps, cs, ws
+
+
+def _numpy_pack(ps, cs, ws):
+    """The block-diagonal layout written out in NumPy (what dgcn_pack_batch must produce)."""
+    sizes = np.array([p.size - 1 for p in ps], dtype=np.int64)
+    nnz = np.array([p[-1] for p in ps], dtype=np.int64)
+    gp = np.concatenate([[0], np.cumsum(sizes)])
+    ep = np.concatenate([[0], np.cumsum(nnz)])
+    rp = np.concatenate([p[:-1].astype(np.int64) + ep[g] for g, p in enumerate(ps)] + [[ep[-1]]]) if ps else np.zeros(1)
+    ci = np.concatenate([c.astype(np.int64) + gp[g] for g, c in enumerate(cs)]) if ps else np.zeros(0)
+    return gp.astype(np.int32), rp.astype(np.int32), ci.astype(np.int32), (np.concatenate(ws) if ps else np.zeros(0))
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_native_pack_matches_numpy(dtype):
+    """dgcn_pack_batch (host C++ in libdgcn.so, bound through the C ABI) against the layout written out in NumPy:
+    ragged batch with empty and edgeless graphs, both index widths, with and without weights, 1..8 threads."""
+    from distgcn_amd.batch import HostBatch, pack_csr_lists
+    rng = np.random.default_rng(3)
+    ps, cs, ws = _random_csr_lists(rng, 57, dtype)
+    gp, rp, ci, w = _numpy_pack(ps, cs, ws)
+    for threads in (1, 3, 8):
+        hb = HostBatch.from_packed(*pack_csr_lists(ps, cs, ws, threads=threads))
+        assert np.array_equal(hb.graph_ptr, gp) and np.array_equal(hb.row_ptr, rp) and np.array_equal(hb.col_idx, ci)
+        assert np.array_equal(hb.weights, w)
+        assert hb.max_nodes == max(p.size - 1 for p in ps) and hb.max_graph_edges == max(int(p[-1]) for p in ps)
+        assert hb.max_degree == max(int(np.diff(p).max()) if p.size > 1 else 0 for p in ps)
+    hb = HostBatch.from_csr_lists(ps, cs)  # no weights
+    assert hb.weights is None and np.array_equal(hb.col_idx, ci)
+    # mixed index widths fall back to the NumPy path and give the same batch
+    mixed = HostBatch.from_csr_lists([p.astype(np.int64) for p in ps], [c.astype(np.int32) for c in cs], ws)
+    assert np.array_equal(mixed.row_ptr, rp) and np.array_equal(mixed.col_idx, ci) and mixed.max_degree == hb.max_degree
+    # a larger batch takes several worker threads
+    ps, cs, ws = _random_csr_lists(np.random.default_rng(4), 900, dtype)
+    gp, rp, ci, w = _numpy_pack(ps, cs, ws)
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
+    assert np.array_equal(hb.graph_ptr, gp) and np.array_equal(hb.row_ptr, rp) and np.array_equal(hb.col_idx, ci)
+
+
+def test_native_pack_rejects_malformed_input():
+    from distgcn_amd._lib import DgcnError
+    from distgcn_amd.batch import HostBatch, pack_csr_lists
+    i32 = lambda *a: np.array(a, dtype=np.int32)
+    with pytest.raises(DgcnError, match="non-decreasing"):
+        HostBatch.from_csr_lists([i32(0, 2, 1, 3)], [i32(1, 2, 0)])
+    with pytest.raises(DgcnError, match="outside"):
+        HostBatch.from_csr_lists([i32(0, 1, 2)], [i32(1, 7)])
+    with pytest.raises(DgcnError, match="start at 0"):
+        HostBatch.from_csr_lists([i32(1, 1, 2)], [i32(1, 0)])
+    with pytest.raises(ValueError, match="does not match its indptr"):
+        HostBatch.from_csr_lists([i32(0, 1, 2)], [i32(1)])
+    with pytest.raises(ValueError, match="vertex count"):
+        HostBatch.from_csr_lists([i32(0, 1, 2)], [i32(1, 0)], [np.ones(3)])
+    with pytest.raises(ValueError, match="too small"):
+        pack_csr_lists([i32(0, 1, 2)], [i32(1, 0)], [np.ones(2)], staging=np.empty(8, np.uint8))
+    empty = HostBatch.from_csr_lists([], [], [])
+    assert empty.num_graphs == 0 and empty.num_nodes == 0 and empty.graph_ptr.tolist() == [0]

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""A/B of k_fused launch options in ONE process, interleaved rounds (cdna guide rule 24):
+   python tools/ab_fused.py "K=V,K=V" "K=V" ...   (each argument is one variant; "" = defaults)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from distgcn_amd import datagen
+from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
+
+variants = [dict(kv.split("=") for kv in a.split(",") if kv) for a in (sys.argv[1:] or [""])]
+keys = sorted({k for v in variants for k in v})
+hb = datagen.er_batch(500, 200, 0.1)
+eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(20, 32), "cuda:0")
+out = eng.solve_buffers(db, True)
+ref = None
+res = {i: [] for i in range(len(variants))}
+for _ in range(300):
+    eng.solve_fused(db, model, out=out)
+torch.cuda.synchronize()
+for rnd in range(7):
+    for i, v in enumerate(variants):
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(v)
+        for _ in range(20):
+            eng.solve_fused(db, model, out=out)
+        torch.cuda.synchronize()
+        eng.timing(True)
+        for _ in range(100):
+            eng.solve_fused(db, model, out=out)
+        torch.cuda.synchronize(); eng.timing(False)
+        ms, n = eng.timing_read("fused_solve")
+        res[i].append(ms / n * 1e3)
+        sc = out["scores"].cpu().numpy().copy(); st = out["state"].cpu().numpy().copy()
+        if ref is None:
+            ref = (sc, st)
+        assert np.array_equal(sc.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(st, ref[1]), "variant %s changes the results" % v
+for i, v in enumerate(variants):
+    print("%-60s median %7.2f us  min %7.2f us" % (v, float(np.median(res[i])), min(res[i])))
