@@ -360,6 +360,19 @@ def spmm_probe(args, wl, traffic_db):
         avg2 = timed(sets, 4)
         nb_avg = float(np.mean([bytes_of(s[0], True) for s in sets]))
         nbp_avg = float(np.mean([bytes_of(s[0], False) for s in sets]))
+        # (c) the same working set as ONE launch: a 4 000-graph batch (8 x this one), steady state instead of the
+        # fill / drain of a 500-workgroup launch
+        bigh = datagen.er_batch(8 * args.graphs, args.nodes, args.p, first_index=3_000_000)
+        big = make_set(bigh, eng.upload(bigh))
+        avg3 = timed([big], 6)
+        line["out_of_cache_one_launch"] = {
+            "working_set": "one launch over %d graphs: %.0f MB algorithmic per launch (> 256 MiB Infinity Cache)"
+                           % (bigh.num_graphs, bytes_of(bigh, True) / 1e6),
+            "avg_launch_us": avg3 * 1e6, "achieved": bytes_of(bigh, True) / avg3 / 1e9,
+            "frac": bytes_of(bigh, True) / avg3 / 1e9 / HBM_PEAK_GBS,
+            "frac_plain_B_spmm": bytes_of(bigh, False) / avg3 / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "traffic": traffic_db.get(tkey + "|one4000", {}).get("hbm_bytes_per_launch")}
+        del big
         line["out_of_cache"] = {
             "working_set": "%d distinct batches visited round-robin: %.0f MB between two uses of a line (> 256 MiB Infinity Cache)"
                            % (nsets, nsets * nb_avg / 1e6),

@@ -72,9 +72,74 @@ __global__ __launch_bounds__(256) void k_argmax(const float* __restrict__ scores
     if (threadIdx.x == 0) out[g] = (sa[0] == 0x7fffffff) ? 0 : sa[0];
 }
 
+// ---- output heads of the model classes (gcn/models.py) -----------------------------------------------------
+// GCN2_DQN(is_dual=True), models.py:651-653: outputs = mean_v(act[v][0]) + (act[v][1:] - mean_v(act[v][1:])), per graph.
+// One workgroup per graph; column means are float32 sums in a fixed order (strided partials, then a binary tree).
+__global__ __launch_bounds__(256) void k_head_dual(const float* __restrict__ act, int D, const int32_t* __restrict__ graph_ptr,
+                                                   float* __restrict__ out) {
+    __shared__ float red[256];
+    __shared__ float mean[64];
+    const int g = blockIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    if (n1 <= n0) return;
+    for (int j = 0; j < D; ++j) {
+        float part = 0.f;
+        for (int v = n0 + threadIdx.x; v < n1; v += 256) part += act[(size_t)v * D + j];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) mean[j] = red[0] / (float)(n1 - n0);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < (n1 - n0) * (D - 1); i += 256) {
+        const int v = n0 + i / (D - 1), j = 1 + i % (D - 1);
+        out[(size_t)v * (D - 1) + (j - 1)] = mean[0] + (act[(size_t)v * D + j] - mean[j]);
+    }
+}
+
+// GCN_DQN(skip=True), models.py:505-521: outputs = dense(concat([dense_input, activations[-1]], axis 1)) with
+// tf.layers.dense's kernel [F + D][D] and bias [D]: a k-ordered fmaf chain over the F input features then the D
+// activations, then + bias.  X == NULL: every input feature equals x_const.
+__global__ __launch_bounds__(256) void k_head_skip(const float* __restrict__ X, float x_const, int F, const float* __restrict__ act,
+                                                   int D, const float* __restrict__ kernel, const float* __restrict__ bias,
+                                                   int rows, float* __restrict__ out) {
+    const long total = (long)rows * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i / D), c = (int)(i % D);
+        float acc = 0.f;
+        for (int k = 0; k < F; ++k) acc = fmaf(X ? X[(size_t)v * F + k] : x_const, kernel[k * D + c], acc);
+        for (int j = 0; j < D; ++j) acc = fmaf(act[(size_t)v * D + j], kernel[(F + j) * D + c], acc);
+        out[i] = bias ? acc + bias[c] : acc;
+    }
+}
+
 }  // namespace dgcn
 
 using namespace dgcn;
+
+extern "C" int dgcn_head_dual_batch(const float* act, int32_t out_dim, const int32_t* graph_ptr, int32_t num_graphs,
+                                    float* out, void* stream) {
+    if (!act || !graph_ptr || !out) return fail(DGCN_ERR_ARG, "dgcn_head_dual_batch: null argument");
+    if (out_dim < 2 || out_dim > 64) return fail(DGCN_ERR_ARG, "dgcn_head_dual_batch: 2 <= out_dim <= 64 (got %d)", out_dim);
+    if (num_graphs <= 0) return DGCN_OK;
+    TimedLaunch t("head", (hipStream_t)stream);
+    DGCN_LAUNCH(t, k_head_dual, dim3(num_graphs), dim3(256), 0, (hipStream_t)stream, act, out_dim, graph_ptr, out);
+    return check_launch("k_head_dual");
+}
+
+extern "C" int dgcn_head_skip_batch(const float* X, float x_const, int32_t in_dim, const float* act, int32_t out_dim,
+                                    const float* kernel, const float* bias, int32_t rows, float* out, void* stream) {
+    if (!act || !kernel || !out || in_dim <= 0 || out_dim <= 0) return fail(DGCN_ERR_ARG, "dgcn_head_skip_batch: bad argument");
+    if (rows <= 0) return DGCN_OK;
+    TimedLaunch t("head", (hipStream_t)stream);
+    const long total = (long)rows * out_dim;
+    DGCN_LAUNCH(t, k_head_skip, dim3((unsigned)min((total + 255) / 256, (long)4096)), dim3(256), 0, (hipStream_t)stream, X, x_const,
+                in_dim, act, out_dim, kernel, bias, rows, out);
+    return check_launch("k_head_skip");
+}
 
 extern "C" size_t dgcn_gcn_forward_workspace(const DgcnBatch* b, const DgcnModel* m, int32_t mode) {
     if (!b || model_check(m, "dgcn_gcn_forward_workspace") != DGCN_OK) return 0;

@@ -72,6 +72,8 @@ struct FusedArgs {
     int32_t max_nodes;
     int32_t meta_cap;
     int32_t prio_second;
+    int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
+                          // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
     int32_t lane_map;   // gather phase: 1 = lanes rotated by 4 inside each 16-lane row (two whole rows per ds_read_b128 bank group)
     int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS
     // residual-graph variant (k_fused<true>): `state` is in/out, vertices with state != 0 are not part of the graph
@@ -147,6 +149,10 @@ __device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4]) {
         for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
 }
 
+// (Tried and dropped: sending the 1..8 rows a vertex count leaves over - ER N = 200: 12 full tiles + 8 rows, which puts a
+// 4th tile on one SIMD - through the VALU of the last wave instead of a 13th MFMA tile (lane = output column, 32-term
+// fmaf chain per row).  Same bits, but 252 us instead of 219 us per C3 launch: the wave's 32 column weights spill at
+// the 128-VGPR budget and its serial rows become the phase's critical path.)
 template <int BLOCK>
 __device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -607,8 +613,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const bool scores_given = MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN);
     if (scores_given && (int)threadIdx.x < ng) score = a.scores[n0 + threadIdx.x];
     float bfrag[8][4];
-    if (a.num_layers > 2 && !scores_given) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
-    for (int l = 0; l < (scores_given ? 0 : a.num_layers); ++l) {
+    const int P = a.wide_passes > 1 ? a.wide_passes : 1;  // first-layer column blocks (1 = the ordinary case)
+    int l_first = 0;
+    if (P > 1 && !scores_given) {
+        // Wide two-layer stack F -> c -> 1: block p of the first layer's columns goes through the 32-wide transform +
+        // aggregation; its 32 features of H then feed terms 32p .. 32p+31 of the last layer's two chains (the k order
+        // of the one-pass product), after which bufA is free for the next block.  The finished chains wait in
+        // bufA[v] / bufB[v] for the last-layer code below.  (Kept apart from the deep-stack loop: nothing here is
+        // live while that loop holds its MFMA operands.)
+        const FusedLayer& LL = a.layers[P];
+        const int v = threadIdx.x;
+        float zc0 = 0.f, zc1 = 0.f;
+        for (int p = 0; p < P; ++p) {
+            first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
+            __syncthreads();
+            hidden_aggregate<BLOCK>(a.layers[p], ng, bufA, bufB, rinfo, perm, vals, words, 0xffffffffu, a.lane_map);
+            __syncthreads();
+            if (v < ng) {
+#pragma unroll
+                for (int c = 0; c < kHid / 4; ++c) {
+                    const float4 h = *reinterpret_cast<const float4*>(bufA + v * kHid + ((c ^ (v & 7)) << 2));
+                    const float hk[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        zc0 = fmaf(hk[i], LL.W[(kHid * p + 4 * c + i) * 2 + 0], zc0);
+                        zc1 = fmaf(hk[i], LL.W[(kHid * p + 4 * c + i) * 2 + 1], zc1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (v < ng) { bufA[v] = zc0; bufB[v] = zc1; }
+        l_first = P;
+    }
+    if (a.num_layers > 2 && P == 1 && !scores_given) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
+    for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
         if (L.cout == kHid) {
 #ifdef DGCN_DIAG
@@ -640,7 +679,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
             // their 32 registers are not live during the gather phase
-            if (l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
+            if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
             __syncthreads();
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
         } else {
@@ -649,7 +688,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             const int v = threadIdx.x;
             float z0 = 0.f, z1 = 0.f;
             if (v < ng) {
-                if (l > 0 && L.cin == kHid) {  // the row as 8 swizzled 16-byte chunks, same k order
+                if (P > 1) {  // chains already run block by block above
+                    z0 = bufA[v];
+                    z1 = bufB[v];
+                } else if (l > 0 && L.cin == kHid) {  // the row as 8 swizzled 16-byte chunks, same k order
 #pragma unroll
                     for (int c = 0; c < kHid / 4; ++c) {
                         const float4 h = *reinterpret_cast<const float4*>(bufA + v * kHid + ((c ^ (v & 7)) << 2));
@@ -947,9 +989,20 @@ static int fused_variant(int max_nodes, int meta_cap) {
     return -1;
 }
 
+constexpr int kMaxWidePasses = 4;
+
+// F -> c -> 1 with 32 < c <= 128: the first layer runs as ceil(c / 32) column blocks through the 32-wide machinery
+static int fused_wide_passes(const DgcnModel* m) {
+    if (m->num_layers != 2) return 1;
+    const int c = m->layers_host[0].out_dim;
+    if (c <= kHid || c > kHid * kMaxWidePasses || m->layers_host[1].out_dim != 1) return 1;
+    return (c + kHid - 1) / kHid;
+}
+
 static int fused_shape_ok(const DgcnModel* m) {
     if (m->num_layers > kMaxFusedLayers) return 0;
     const int Lc = m->num_layers;
+    if (fused_wide_passes(m) > 1) return m->layers_host[0].in_dim <= 64 && m->layers_host[1].in_dim == m->layers_host[0].out_dim;
     for (int l = 0; l < Lc; ++l) {
         const DgcnLayer& L = m->layers_host[l];
         const bool last = l == Lc - 1;
@@ -961,32 +1014,36 @@ static int fused_shape_ok(const DgcnModel* m) {
     return 1;
 }
 
-// ---- hidden widths below 32 --------------------------------------------------------------------
+// ---- hidden widths other than 32 ----------------------------------------------------------------
 // k_fused is written for 32-wide hidden states.  A narrower stack runs as a 32-wide one whose extra weight
 // rows / columns (and biases) are zero: the extra features are exactly 0 in every layer and the extra chain
-// terms are fmaf(0, 0, acc) = acc, so the real features keep their bits.  k_pad_model writes the padded
-// copies into the caller's workspace (one tiny launch per call; nothing is cached between calls).
-constexpr size_t kPadLayerFloats = 64 * 64 + 64;  // [in <= 64][2 * 32] weights + 32 bias (+ slack), per layer
+// terms are fmaf(0, 0, acc) = acc, so the real features keep their bits.  A two-layer stack F -> c -> 1 with
+// 32 < c <= 128 (the shipped c48 / c64 l=2 checkpoints) runs its first layer as ceil(c / 32) independent
+// 32-column blocks - the columns of a GraphConvolution do not interact - while the last layer's two chains
+// continue from block to block in the same k order as the one-pass product.  k_pad_model writes the padded /
+// re-blocked copies into the caller's workspace (one tiny launch per call; nothing is cached between calls).
+constexpr size_t kPadLayerFloats = 64 * 64 + 64;  // [in <= 64][2 * 32] (or [in <= 128][2]) weights + 32 bias (+ slack), per layer
 
 struct PadArgs {
-    int32_t num_layers;
-    float* out;  // [num_layers][kPadLayerFloats]
-    struct { const float* W; const float* bias; int32_t in, out; } src[kMaxFusedLayers];
+    int32_t num_layers;  // kernel-side ("virtual") layers
+    float* out;          // [num_layers][kPadLayerFloats]
+    // virtual layer = columns [c0, c0 + out_p) of source layer (W [in][2*out], bias [out]), written as [in_p][2*out_p]
+    struct { const float* W; const float* bias; int32_t in, out, c0, in_p, out_p; } src[kMaxFusedLayers];
 };
 
 __global__ void k_pad_model(PadArgs a) {
     const int l = blockIdx.x;
-    const bool last = l == a.num_layers - 1;
-    const int in = a.src[l].in, out = a.src[l].out;
-    const int in_p = l == 0 ? in : kHid, out_p = last ? 1 : kHid;
+    const int in = a.src[l].in, out = a.src[l].out, c0 = a.src[l].c0;
+    const int in_p = a.src[l].in_p, out_p = a.src[l].out_p;
     float* W = a.out + (size_t)l * kPadLayerFloats;
     float* bias = W + 64 * 64;
     for (int i = threadIdx.x; i < in_p * 2 * out_p; i += blockDim.x) {
         const int k = i / (2 * out_p), j = i % (2 * out_p);
-        const int half = j / out_p, c = j % out_p;
+        const int half = j / out_p, c = c0 + j % out_p;
         W[i] = (k < in && c < out) ? a.src[l].W[k * 2 * out + half * out + c] : 0.f;
     }
-    for (int c = threadIdx.x; c < kHid; c += blockDim.x) bias[c] = (a.src[l].bias && c < out) ? a.src[l].bias[c] : 0.f;
+    for (int c = threadIdx.x; c < kHid; c += blockDim.x)
+        bias[c] = (a.src[l].bias && c < out_p && c0 + c < out) ? a.src[l].bias[c0 + c] : 0.f;
 }
 
 static bool fused_needs_padding(const DgcnModel* m) {
@@ -995,49 +1052,59 @@ static bool fused_needs_padding(const DgcnModel* m) {
     return false;
 }
 
+static int fused_virtual_layers(const DgcnModel* m) { return m->num_layers - 1 + fused_wide_passes(m); }
+
 static size_t fused_pad_bytes(const DgcnModel* m) {
-    return fused_needs_padding(m) ? (size_t)m->num_layers * kPadLayerFloats * sizeof(float) : 0;
+    return fused_needs_padding(m) ? (size_t)fused_virtual_layers(m) * kPadLayerFloats * sizeof(float) : 0;
 }
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
                          void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream) {
     if (!fused_shape_ok(m))
-        return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 only", who);
+        return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 "
+                    "(and two-layer stacks F->c->1 with c <= 128) only", who);
     if (b->max_nodes > kFusedMaxNodes)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: graphs of %d vertices exceed the fused kernel's %d", who, b->max_nodes,
                     kFusedMaxNodes);
     a->graph_ptr = b->graph_ptr;
     a->max_nodes = max(b->max_nodes, 64);  // >= 64 rows: the greedy phase re-uses bufB for priorities + reduction
-    a->num_layers = m->num_layers;
+    const int P = fused_wide_passes(m);
+    const int VL = fused_virtual_layers(m);
+    a->num_layers = VL;
+    a->wide_passes = P;
     const size_t pad_bytes = fused_pad_bytes(m);
     if (pad_bytes && (!workspace || workspace_bytes < pad_bytes))
         return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (zero-padded weights), got %zu", who, pad_bytes,
                     workspace ? workspace_bytes : (size_t)0);
     float* padded = static_cast<float*>(workspace);  // the padded model sits first in the workspace
-    for (int l = 0; l < m->num_layers; ++l) {
-        const DgcnLayer& L = m->layers_host[l];
-        const bool last = l == m->num_layers - 1;
-        a->layers[l].W = pad_bytes ? padded + (size_t)l * kPadLayerFloats : L.weights;
-        a->layers[l].bias = pad_bytes ? (L.bias ? padded + (size_t)l * kPadLayerFloats + 64 * 64 : nullptr) : L.bias;
-        a->layers[l].cin = (pad_bytes && l > 0) ? kHid : L.in_dim;
-        a->layers[l].cout = (pad_bytes && !last) ? kHid : L.out_dim;
-        a->layers[l].act = L.act;
-        a->layers[l].pad = 0;
+    PadArgs pa = {};
+    pa.num_layers = VL;
+    pa.out = padded;
+    for (int vl = 0; vl < VL; ++vl) {
+        // virtual layer vl <- source layer sl, column block c0
+        const int sl = vl < P ? 0 : vl - P + 1;
+        const DgcnLayer& L = m->layers_host[sl];
+        const bool last = sl == m->num_layers - 1;
+        const int c0 = vl < P ? vl * kHid : 0;
+        const int in_p = sl == 0 ? L.in_dim : (P > 1 ? kHid * P : kHid), out_p = last ? 1 : kHid;
+        a->layers[vl].W = pad_bytes ? padded + (size_t)vl * kPadLayerFloats : L.weights;
+        a->layers[vl].bias = pad_bytes ? (L.bias ? padded + (size_t)vl * kPadLayerFloats + 64 * 64 : nullptr) : L.bias;
+        a->layers[vl].cin = pad_bytes ? in_p : L.in_dim;
+        a->layers[vl].cout = pad_bytes ? out_p : L.out_dim;
+        a->layers[vl].act = L.act;
+        a->layers[vl].pad = 0;
+        pa.src[vl].W = L.weights;
+        pa.src[vl].bias = L.bias;
+        pa.src[vl].in = L.in_dim;
+        pa.src[vl].out = L.out_dim;
+        pa.src[vl].c0 = c0;
+        pa.src[vl].in_p = in_p;
+        pa.src[vl].out_p = out_p;
     }
     if (pad_bytes) {
-        PadArgs pa = {};
-        pa.num_layers = m->num_layers;
-        pa.out = padded;
-        for (int l = 0; l < m->num_layers; ++l) {
-            const DgcnLayer& L = m->layers_host[l];
-            pa.src[l].W = L.weights;
-            pa.src[l].bias = L.bias;
-            pa.src[l].in = L.in_dim;
-            pa.src[l].out = L.out_dim;
-        }
         TimedLaunch t("fused_pad", stream);
-        DGCN_LAUNCH(t, k_pad_model, dim3(m->num_layers), dim3(256), 0, stream, pa);
+        DGCN_LAUNCH(t, k_pad_model, dim3(VL), dim3(256), 0, stream, pa);
         int rc = check_launch("k_pad_model");
         if (rc) return rc;
         workspace = static_cast<char*>(workspace) + pad_bytes;

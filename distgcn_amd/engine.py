@@ -256,6 +256,24 @@ class Engine:
                    "dgcn_gcn_forward_batch")
         return out
 
+    def head_dual(self, b: DeviceBatch, act):
+        """GCN2_DQN(is_dual=True) output head (gcn/models.py:651-653): [num_nodes, D] -> [num_nodes, D - 1]."""
+        t = self.torch
+        D = int(act.shape[1])
+        out = t.empty((b.host.num_nodes, D - 1), dtype=t.float32, device=self.device)
+        _lib.check(self.lib.dgcn_head_dual_batch(act.data_ptr(), D, b.graph_ptr.data_ptr(), b.host.num_graphs, out.data_ptr(),
+                                                 self._stream()), "dgcn_head_dual_batch")
+        return out
+
+    def head_skip(self, act, kernel, bias, X=None, x_const: float = 1.0, in_dim: int = 1):
+        """GCN_DQN(skip=True) output head (gcn/models.py:505-521): dense(concat([X, act])) -> [num_nodes, D]."""
+        t = self.torch
+        out = t.empty_like(act)
+        _lib.check(self.lib.dgcn_head_skip_batch(X.data_ptr() if X is not None else None, x_const, in_dim, act.data_ptr(),
+                                                 int(act.shape[1]), kernel.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 int(act.shape[0]), out.data_ptr(), self._stream()), "dgcn_head_skip_batch")
+        return out
+
     def argmax(self, b: DeviceBatch, scores):
         t = self.torch
         out = t.empty(b.host.num_graphs, dtype=t.int32, device=self.device)

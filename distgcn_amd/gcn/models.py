@@ -114,7 +114,17 @@ class _GCNBase:
                 self.vars[base + "/bias"] = s["bias"].copy()
             elif base + "/bias" in self.vars:
                 raise ValueError("layer %d: model has a bias, checkpoint does not" % k)
+        if getattr(self, "skip", False):  # tf.layers.dense head of models.py:505-521
+            for leaf in ("dense/kernel", "dense/bias"):
+                hits = [k for k in params if k.endswith(leaf) and "Adam" not in k]
+                if not hits:
+                    raise ValueError("skip=True model: checkpoint lacks %s" % leaf)
+                arr = np.asarray(params[hits[0]], dtype=np.float32)
+                if arr.shape != self.vars[self.scope + "/" + leaf].shape:
+                    raise ValueError("%s: checkpoint shape %s, model shape %s" % (leaf, arr.shape, self.vars[self.scope + "/" + leaf].shape))
+                self.vars[self.scope + "/" + leaf] = arr.copy()
         self._device_model = None
+        self._head_dev = None
 
     def load(self, name: str):
         """Restore from a model directory or bundle prefix (``mwis_dqn_call.py:188-192``).
@@ -133,11 +143,25 @@ class _GCNBase:
             self._device_model = DeviceModel(self.layers, engine.device)
         return self._device_model
 
+    @property
+    def has_head(self) -> bool:
+        """True when ``outputs`` is not simply the last layer's activation (is_dual, models.py:651-653; skip, :505-521)."""
+        return bool(self.is_dual or getattr(self, "skip", False))
+
     def forward_batch(self, engine, device_batch, X=None, x_const=None, mode: int = 0):
-        """scores[num_nodes, out] for a whole batch, on the device (no host round trip)."""
+        """``model.outputs`` [num_nodes, out] for a whole batch, on the device (no host round trip)."""
+        act = engine.forward(device_batch, self.device_model(engine), X=X, x_const=x_const, mode=mode)
         if self.is_dual:
-            raise NotImplementedError("GCN2_DQN(is_dual=True) (models.py:651-653) is not implemented")
-        return engine.forward(device_batch, self.device_model(engine), X=X, x_const=x_const, mode=mode)
+            return engine.head_dual(device_batch, act)
+        if getattr(self, "skip", False):
+            import torch
+            if getattr(self, "_head_dev", None) is None or self._head_dev[0].device != engine.device:
+                self._head_dev = (torch.from_numpy(np.ascontiguousarray(self.vars[self.scope + "/dense/kernel"])).to(engine.device),
+                                  torch.from_numpy(np.ascontiguousarray(self.vars[self.scope + "/dense/bias"])).to(engine.device))
+            if x_const is None:
+                x_const = float(np.float32(1.0 / self.input_dim))
+            return engine.head_skip(act, self._head_dev[0], self._head_dev[1], X=X, x_const=x_const, in_dim=self.input_dim)
+        return act
 
     def predict(self, state, engine=None):
         """``sess.run([outputs_softmax, pred])`` for ONE graph given the reference's ``state`` dict
@@ -146,7 +170,7 @@ class _GCNBase:
         engine = engine or get_engine()
         db, X, x_const = state_to_device(engine, state, self.input_dim)
         dm = self.device_model(engine)
-        mode = 1 if (engine.solve_supported(db, dm) and not self.is_dual) else 0
+        mode = 1 if engine.solve_supported(db, dm) else 0
         scores_d = self.forward_batch(engine, db, X=X, x_const=x_const, mode=mode)
         if scores_d.shape[1] == 1:
             action = engine.argmax(db, scores_d).cpu().numpy().astype(np.int64)  # models.py:526 pred
@@ -173,11 +197,24 @@ class GCN_DQN(_GCNBase):
         self.num_layer = int(fl.num_layer)
         self.act_name = "leaky_relu"
         self.is_dual = False
-        if getattr(fl, "skip", False):
-            raise NotImplementedError("skip=True (models.py:505-521) is not used by any shipped script")
+        self.skip = bool(getattr(fl, "skip", False))
         hidden = int(fl.hidden1)
         dims = [self.input_dim] + [hidden] * (self.num_layer - 1) + [self.output_dim]
         self._init_params(dims, 1 + int(fl.max_degree), False, fl.wts_init, seed)
+        if self.skip:
+            # tf.compat.v1.layers.dense over concat([dense_input, activations[-1]]) (models.py:505-521): variables
+            # <scope>/dense/kernel [F + D, D] and <scope>/dense/bias [D]; glorot-uniform kernel, or the reference's
+            # +-identity pattern when wts_init == 'zeros' (:511-520)
+            F, D = self.input_dim, self.output_dim
+            if fl.wts_init == "zeros":
+                k = np.zeros((F + D, D), dtype=np.float32)
+                half = int(D / 2)
+                k[0:half, list(range(0, D - 1, 2))] = -np.identity(half, dtype=np.float32)
+                k[0:half, list(range(1, D, 2))] = np.identity(half, dtype=np.float32)
+            else:
+                k = _glorot(np.random.default_rng(seed + 1), (F + D, D))
+            self.vars[self.scope + "/dense/kernel"] = k
+            self.vars[self.scope + "/dense/bias"] = np.zeros(D, dtype=np.float32)
 
 
 class GCN2_DQN(_GCNBase):

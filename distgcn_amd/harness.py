@@ -62,11 +62,52 @@ def greedy_utilities(adjs: Sequence, wts_list: Sequence) -> np.ndarray:
     return res["totals"].cpu().numpy()
 
 
+def _solve_with_exploration(agent, adjs, wts_list, epsilon: float, rng):
+    """The ``test=False`` branch of the reference's loop (``mwis_dqn_test.py:244-256``): with probability ``epsilon`` a
+    graph's GCN scores are replaced by ``uniform(0, 1)`` draws before the priority product and the greedy search.
+    ``rng`` supplies ``rand()`` / ``uniform(size=)`` (``numpy.random`` itself, seeded by the caller, replays the
+    reference's draws graph by graph: one ``rand()``, then ``uniform(size=n)`` when it fires).  Batched: one forward
+    pass and one greedy launch; only the score rows of the graphs that fire are rewritten on the host."""
+    import torch
+    eng = get_engine()
+    csrs = [as_csr(a) for a in adjs]
+    wl = [np.asarray(w, dtype=np.float64).ravel() for w in wts_list]
+    hb = HostBatch.from_csr_lists([c.indptr for c in csrs], [c.indices for c in csrs], wl)
+    db = eng.upload(hb)
+    dm = agent.model.device_model(eng)
+    # mwis_dqn_test.py:162-169: features ones * w row-normalised -> 1/F on positive-weight rows, 0 on zero-weight rows
+    F = agent.model.input_dim
+    X = None
+    if hb.num_nodes and np.any(hb.weights <= 0):
+        X = torch.from_numpy(np.where(hb.weights[:, None] > 0, np.float32(1.0 / F), np.float32(0.0)).astype(np.float32)
+                             .repeat(F, axis=1)).to(eng.device)
+    mode = 1 if eng.solve_supported(db, dm) else 0
+    scores = agent.model.forward_batch(eng, db, X=X, mode=mode)
+    host = None
+    for n0, n1 in hb.graph_slices():
+        if rng.rand() <= epsilon:
+            if host is None:
+                host = scores.cpu().numpy().copy()
+            host[n0:n1, 0] = rng.uniform(size=n1 - n0)
+    if host is not None:
+        scores = torch.from_numpy(host).to(eng.device)
+    predict = getattr(agent.flags, "predict", "mwis")
+    res = eng.lgs(db, scores=scores, weights=db.weights if predict == "mwis" else None, sum_weights=db.weights)
+    eng.check_status(res["status"])
+    st, tot = res["state"].cpu().numpy(), res["totals"].cpu().numpy()
+    return [(set(int(i) for i in np.flatnonzero(st[n0:n1] == 1)), np.float64(tot[g]))
+            for g, (n0, n1) in enumerate(hb.graph_slices())]
+
+
 def evaluate(agent, adjs: Sequence, wts_list: Sequence, greedy_utility: Optional[Sequence[float]] = None,
-             names: Optional[Sequence[str]] = None) -> List[dict]:
+             names: Optional[Sequence[str]] = None, epsilon: float = 0.0, rng=None) -> List[dict]:
     """Solve every graph with ``agent.solve_mwis_batch`` and return one record per graph:
-    ``{"data", "p", "total", "size"}`` - ``p`` is the reference's ratio column."""
-    res = agent.solve_mwis_batch(adjs, wts_list)
+    ``{"data", "p", "total", "size"}`` - ``p`` is the reference's ratio column.  ``epsilon > 0`` takes the
+    reference's exploring branch (the scripts run ``solve_mwis(test=False)`` with ``--epsilon=.0002``)."""
+    if epsilon > 0.0:
+        res = _solve_with_exploration(agent, adjs, wts_list, epsilon, rng if rng is not None else np.random)
+    else:
+        res = agent.solve_mwis_batch(adjs, wts_list)
     if greedy_utility is None or any(g is None for g in greedy_utility):
         greedy_utility = greedy_utilities(adjs, wts_list)
     rows = []

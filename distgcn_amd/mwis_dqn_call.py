@@ -139,8 +139,17 @@ def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str
         return out
     db = eng.upload(hb)
     dm = model.device_model(eng)
-    if model.is_dual:
-        raise NotImplementedError("is_dual models are not implemented")
+    if getattr(model, "has_head", False):
+        # is_dual / skip: model.outputs is a function of the last activation - forward (+ head), then the greedy kernel
+        from .engine import MODE_FUSED, MODE_LAYERED
+        fwd_mode = MODE_FUSED if (eng.solve_supported(db, dm) and mode != "layered") else MODE_LAYERED
+        scores = model.forward_batch(eng, db, X=X, mode=fwd_mode)
+        if scores.shape[1] != 1:
+            raise _lib.DgcnError("solve needs one output per vertex; this model yields %d" % scores.shape[1])
+        res = eng.lgs(db, scores=scores, weights=db.weights if predict == "mwis" else None, sum_weights=db.weights)
+        eng.check_status(res["status"])
+        return {"state": res["state"].cpu().numpy(), "totals": res["totals"].cpu().numpy(),
+                "rounds": res["rounds"].cpu().numpy(), "scores": scores.cpu().numpy()}
     fused_ok = eng.solve_supported(db, dm)
     if mode == "fused" and not fused_ok:
         raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")

@@ -182,6 +182,16 @@ int dgcn_gcn_forward_poly_batch(const DgcnBatch* batch, const DgcnCsr* const* su
                                 const float* X, float x_const, float* scores,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- output heads of the model classes ---------------------------------------------------------------------
+ * dual: GCN2_DQN(is_dual=True), gcn/models.py:651-653 - per graph,
+ *       out[v][j-1] = mean_v(act[v][0]) + (act[v][j] - mean_v(act[v][j])), j = 1..out_dim-1; out is [num_nodes][out_dim-1].
+ * skip: GCN_DQN with FLAGS.skip, gcn/models.py:505-521 - out = concat([X, act], axis 1) . kernel + bias
+ *       (tf.layers.dense: kernel [in_dim + out_dim][out_dim], bias [out_dim] or NULL); X NULL = constant features. */
+int dgcn_head_dual_batch(const float* act, int32_t out_dim, const int32_t* graph_ptr, int32_t num_graphs,
+                         float* out, void* stream);
+int dgcn_head_skip_batch(const float* X, float x_const, int32_t in_dim, const float* act, int32_t out_dim,
+                         const float* kernel, const float* bias, int32_t rows, float* out, void* stream);
+
 /* ---- models.py:526/660  pred = argmax(outputs, axis 0), per graph, first maximum wins ---------*/
 int dgcn_argmax_batch(const float* scores, int32_t ld, const int32_t* graph_ptr, int32_t num_graphs,
                       int32_t* arg_out, void* stream);

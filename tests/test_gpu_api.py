@@ -218,6 +218,88 @@ def test_evaluation_harness(engine, golden, tmp_path):
     assert (tmp_path / "out" / "model.csv").read_text().splitlines()[0] == ",data,p"
 
 
+def test_evaluation_harness_exploring_branch(engine, golden):
+    """mwis_dqn_test.py:244-256 with test=False: with probability epsilon a graph's scores are uniform(0,1) draws.
+    The same seeded numpy.random stream replayed on the host (one rand() per graph, uniform(size=n) when it fires) and
+    the oracle's greedy search give the expected sets; epsilon = 0 leaves the deterministic path untouched."""
+    from distgcn_amd import harness
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(1, flags=_flags())
+    agent.model.set_params(golden.params(M20))
+    ids = [0, 1, 2, 8, 9, 12]
+    adjs = [golden.scipy(i) for i in ids]
+    wts = [golden.csr(i)[2] for i in ids]
+    gu = [float(golden.graphs["g%02d_greedy_utility" % i]) for i in ids]
+    base = harness.evaluate(agent, adjs, wts, gu)
+    rs = np.random.RandomState(12)
+    rows = harness.evaluate(agent, adjs, wts, gu, epsilon=0.5, rng=rs)
+    replay = np.random.RandomState(12)
+    fired = 0
+    for k, i in enumerate(ids):
+        if replay.rand() <= 0.5:
+            fired += 1
+            act = replay.uniform(size=wts[k].size)
+            want, _ = orc.local_greedy_search(adjs[k], act * wts[k])
+            assert rows[k]["total"] == pytest.approx(float(wts[k][sorted(want)].sum()), rel=1e-12)
+        else:
+            assert rows[k]["p"] == pytest.approx(base[k]["p"], rel=1e-12)
+    assert 0 < fired < len(ids)
+    tiny = harness.evaluate(agent, adjs, wts, gu, epsilon=1e-12, rng=np.random.RandomState(1))
+    assert [r["p"] for r in tiny] == pytest.approx([r["p"] for r in base], rel=1e-12)
+
+
+def test_output_heads_dual_and_skip(engine, golden):
+    """GCN2_DQN(is_dual=True) (gcn/models.py:651-653) and GCN_DQN with FLAGS.skip (:505-521): model.outputs against
+    the NumPy restatement, through forward_batch, predict and - for the one-output skip model - solve_mwis."""
+    from distgcn_amd.gcn.models import GCN2_DQN
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    from oracle import ref_numpy as orc
+    hb = golden.host_batch([0, 9, 2])
+    db = engine.upload(hb)
+    # ---- duelling head: 3 outputs -> 2
+    m = GCN2_DQN(None, hidden_dim=32, num_layer=3, bias=True, input_dim=1, output_dim=3, is_dual=True, seed=3)
+    out = m.forward_batch(engine, db).cpu().numpy()
+    assert out.shape == (hb.num_nodes, 2)
+    for gi, (n0, n1) in zip([0, 9, 2], hb.graph_slices()):
+        adj, w = golden.scipy(gi), golden.csr(gi)[2]
+        state = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "gdpg")
+        want, _ = orc.gcn_forward(m.layers, state, np.float32, is_dual=True)
+        assert np.abs(out[n0:n1] - want).max() <= 1e-5
+    agent_state = {"features": state["features"], "support": state["support"]}
+    vals, action = m.predict(agent_state, engine)
+    assert vals.shape == (w.size, 2) and action.shape == (2,) and np.array_equal(action, np.argmax(vals, axis=0))
+    # ---- skip head: dense over concat([X, last activation])
+    agent = DQNAgent(1, flags=_flags(num_layer=3, skip=True), seed=4)
+    model = agent.model
+    k, b = model.vars["gcn_dqn/dense/kernel"], model.vars["gcn_dqn/dense/bias"]
+    assert k.shape == (2, 1) and b.shape == (1,)
+    model.vars["gcn_dqn/dense/bias"] = np.array([0.05], np.float32)
+    out = model.forward_batch(engine, db).cpu().numpy()
+    for gi, (n0, n1) in zip([0, 9, 2], hb.graph_slices()):
+        adj, w = golden.scipy(gi), golden.csr(gi)[2]
+        state = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "dqn_call")
+        last, _ = orc.gcn_forward(model.layers, state, np.float32)
+        x = np.full((w.size, 1), 1.0, np.float32)
+        want = np.concatenate([x, last], axis=1).astype(np.float32) @ k + np.float32(0.05)
+        assert np.abs(out[n0:n1] - want).max() <= 1e-5
+    adj, w = golden.scipy(9), golden.csr(9)[2]
+    got, tot, _ = agent.solve_mwis(adj, w)
+    state = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "dqn_call")
+    last, _ = orc.gcn_forward(model.layers, state, np.float32)
+    sc = (np.concatenate([np.ones((w.size, 1), np.float32), last], axis=1) @ k + np.float32(0.05))[:, 0]
+    want, _ = orc.local_greedy_search(adj, sc.astype(np.float64) * w)
+    assert got == set(int(v) for v in want)
+    # checkpoint round trip keeps the head
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        model.save(d)
+        again = DQNAgent(1, flags=_flags(num_layer=3, skip=True), seed=9)
+        again.model.load(d)
+        assert np.array_equal(again.model.vars["gcn_dqn/dense/bias"], model.vars["gcn_dqn/dense/bias"])
+        assert np.array_equal(again.model.vars["gcn_dqn/dense/kernel"], k)
+
+
 def test_mixed_size_batch_is_bucketed(engine):
     """A few large graphs among many small ones are solved as two launches (small / large LDS images) with
     identical results."""

@@ -174,20 +174,62 @@ def test_forward_golden_models(engine, golden, mode):
     assert ran == len(golden.model_names)
 
 
-def test_fused_rejects_wide_hidden_loudly(engine, golden, all_models):
-    """The fused kernel covers hidden widths <= 32 (narrower ones run zero-padded); 48 / 64 must say so."""
+def test_fused_shape_coverage(engine, golden, all_models):
+    """Which shipped stacks the fused kernel takes: every [I, L] stack with hidden width <= 32 (narrower ones run
+    zero-padded) and the two-layer stacks F -> c -> 1 with c = 48 / 64 (first layer in 32-column blocks); the two
+    max_degree = 2 models run layer by layer and say so.  A deep stack with a 48-wide hidden layer is refused loudly."""
+    from distgcn_amd import datagen
     from distgcn_amd._lib import DgcnError
     from distgcn_amd.engine import DeviceModel
     db = engine.upload(golden.host_batch([0]))
+    wide = 0
     for name in all_models.names:
         layers = all_models.layers(name)
         dm = DeviceModel(layers, engine.device)
+        widths = [lyr["weights"][0].shape[1] for lyr in layers[:-1]]
         # (the checkpoint named ld32_c32_l2 really holds a 48-wide hidden layer)
-        ok = all(lyr["weights"][0].shape[1] <= 32 for lyr in layers[:-1]) and len(layers[0]["weights"]) == 2
+        ok = len(layers[0]["weights"]) == 2 and (all(w <= 32 for w in widths) or (len(layers) == 2 and widths[0] <= 128))
+        wide += ok and any(w > 32 for w in widths)
         assert engine.solve_supported(db, dm) == ok, name
         if not ok:
             with pytest.raises(DgcnError, match="fused kernel handles|run layer by layer"):
                 engine.forward(db, dm, mode=1)
+    assert wide == 5  # c48 x 2 (one of them named c32), c64 x 3
+    deep = DeviceModel(datagen.random_model(4, 48), engine.device)
+    assert not engine.solve_supported(db, deep)
+    with pytest.raises(DgcnError, match="fused kernel handles"):
+        engine.forward(db, deep, mode=1)
+
+
+@pytest.mark.parametrize("hidden", [33, 48, 64, 100, 128])
+def test_fused_wide_two_layer_stacks(engine, golden, hidden):
+    """F -> c -> 1 with 32 < c <= 128 in the fused kernel (first layer as 32-column blocks, the last layer's chains
+    continued from block to block): scores bit-equal to the layer-by-layer path and to the twin, with a bias, with
+    explicit features, on the residual-graph variant's plain launch too."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = golden.host_batch()
+    db = engine.upload(hb)
+    for fs, bias in ((1, False), (16, True)):
+        layers = datagen.random_model(2, hidden, feature_size=fs, bias=bias, seed=hidden + fs)
+        dm = DeviceModel(layers, engine.device)
+        assert engine.solve_supported(db, dm)
+        X = None
+        if fs > 1:
+            X = np.random.default_rng(1).random((hb.num_nodes, fs)).astype(np.float32)
+        Xd = None if X is None else _dev(engine, X)
+        fused = engine.forward(db, dm, X=Xd, mode=1).cpu().numpy()
+        layered = engine.forward(db, dm, X=Xd, mode=0).cpu().numpy()
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        twin = ctwin.forward(lap, layers, hb.num_nodes, X=X)
+        assert np.array_equal(fused.view(np.uint32), layered.view(np.uint32))
+        assert np.array_equal(fused.view(np.uint32), twin.view(np.uint32))
+        if fs == 1:
+            res = engine.solve(db, dm, mode=1)
+            ref = ctwin.solve(hb, layers)
+            assert np.array_equal(res["state"].cpu().numpy(), ref["state"])
+            assert np.array_equal(res["scores"].cpu().numpy().view(np.uint32), ref["scores"].view(np.uint32))
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -444,7 +486,7 @@ def test_every_shipped_checkpoint(engine, golden, all_models):
             total += 1
             same_as_reference += set(np.flatnonzero(state[n0:n1] == 1)) == set(all_models.expect(gi, name, "set").tolist())
         table.append("%-62s %5s %12.3e %12.3e %12.3e" % (name, "fused" if mode else "layer", e32, e64, e3264))
-    assert fused >= 37  # every [I, L] stack whose hidden width is <= 32 takes the fused kernel
+    assert fused == 44  # every [I, L] stack: hidden width <= 32, or two layers with a wide first one (c48 / c64)
     assert same_as_reference >= total - 2, (same_as_reference, total)
     table.append("sets equal to the reference's local_greedy_search on the restatement's priorities: %d of %d" % (same_as_reference, total))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
