@@ -230,7 +230,7 @@ class GpuWorkload:
 
     def kernel_times(self):
         fam_ms = {}
-        for fam in ("supports", "transform", "spmm", "lgs", "fused_forward", "fused_solve"):
+        for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve"):
             ms, n = self.eng.timing_read(fam)
             if n:
                 fam_ms[fam] = (ms, n)
@@ -265,11 +265,13 @@ def roofline_objects(args, wl, fam_ms):
         tkey = ("spmm|%dx%d|C%d" % (args.graphs, args.nodes, args.hidden)) if dom == "spmm" else \
             "%s|%dx%d|l%d" % (dom, args.graphs, args.nodes, args.layers)
         traffic = traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")
-        if dom == "spmm":
+        if dom in ("spmm", "layer"):
             per = spmm_algorithmic_bytes(hb, layers, with_y0=True)
             avg_bytes = sum(per) / len(per)
             ach = avg_bytes / avg_s / 1e9
-            roofline = {"kernel": "k_spmm_lds (all %d launches of a step)" % len(per), "bound": "hbm",
+            roofline = {"kernel": ("k_spmm_lds (all %d launches of a step)" % len(per)) if dom == "spmm" else
+                                  "k_layer32 (aggregation + next layer's transform, %d launches of a step)" % int(round(n / args.steps)),
+                        "bound": "hbm",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": avg_bytes,

@@ -12,6 +12,8 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
                   const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s);
 int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                        int ldz, hipStream_t s);
+int layer32_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, const float* bias, int act,
+                     const float* Wn, int ctot_next, float* Zn, hipStream_t s);
 size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m);
 int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
                   float* scores, void* ws, size_t ws_bytes, hipStream_t s);
@@ -147,8 +149,9 @@ extern "C" size_t dgcn_gcn_forward_workspace(const DgcnBatch* b, const DgcnModel
     int mo;
     layered_dims(m, &mo);
     const size_t n = (size_t)max(b->num_nodes, 1);
-    // Z = H.[W_0 | .. | W_k], the next layer's H, and (k = 2) the running sum of the first two supports
-    return align256(n * m->num_supports * mo * sizeof(float)) + align256(n * mo * sizeof(float)) +
+    // Z = H.[W_0 | .. | W_k] twice (a layer fused with the next transform writes the other one), the next layer's H,
+    // and (k = 2) the running sum of the first two supports
+    return 2 * align256(n * m->num_supports * mo * sizeof(float)) + align256(n * mo * sizeof(float)) +
            (m->num_supports > 2 ? align256(n * mo * sizeof(float)) : 0);
 }
 
@@ -162,19 +165,35 @@ static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const 
     const int K = m->num_supports;
     const size_t n = (size_t)b->num_nodes;
     char* ws = reinterpret_cast<char*>(workspace);
+    const size_t zsz = align256(n * K * mo * sizeof(float));
     float* Zbuf = reinterpret_cast<float*>(ws);
-    float* Hbuf = reinterpret_cast<float*>(ws + align256(n * K * mo * sizeof(float)));
-    float* Tbuf = reinterpret_cast<float*>(ws + align256(n * K * mo * sizeof(float)) + align256(n * mo * sizeof(float)));
+    float* Zalt = reinterpret_cast<float*>(ws + zsz);
+    float* Hbuf = reinterpret_cast<float*>(ws + 2 * zsz);
+    float* Tbuf = reinterpret_cast<float*>(ws + 2 * zsz + align256(n * mo * sizeof(float)));
     const float* H = X;  // NULL -> constant features
     int ldh = m->layers_host[0].in_dim;
+    bool z_ready = false;  // Zbuf already holds this layer's Z: the previous layer's launch produced it
     for (int l = 0; l < m->num_layers; ++l) {
         const DgcnLayer& L = m->layers_host[l];
         const int ctot = K * L.out_dim;
         // K2/K3: Z[:, i*out:(i+1)*out] = H.W_i  (weights stored [support][in][out] -> the host shim passes
         // them pre-concatenated as [in][K*out]; see distgcn_amd/gcn/models.py)
-        int rc = transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
+        int rc = z_ready ? DGCN_OK : transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
         if (rc) return rc;
+        z_ready = false;
         const bool last = l == m->num_layers - 1;
+        if (K == 2 && !last && L.out_dim == 32) {
+            // layer l's aggregation + layer l+1's transform in one launch (layer.hip): H' never leaves the LDS
+            const DgcnLayer& N = m->layers_host[l + 1];
+            rc = layer32_dispatch(sup[0], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf, L.bias, L.act, N.weights, K * N.out_dim,
+                                  Zalt, s);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                float* tmp = Zbuf; Zbuf = Zalt; Zalt = tmp;
+                z_ready = true;
+                continue;
+            }
+        }
         float* out = last ? scores : Hbuf;
         const float* run = Zbuf;  // running sum: S_0.Z_0 = Z_0
         int ldrun = ctot;

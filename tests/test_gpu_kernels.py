@@ -600,3 +600,47 @@ def test_margin_risk_counts_and_guarantee(engine, golden):
     for g, (n0, n1) in enumerate(hb.graph_slices()):
         p, c, _ = golden.csr(g)
         assert got[g] == orc.margin_risk(p, c, prio[n0:n1], state[n0:n1], 1e-4)
+
+
+def test_layer_fused_with_next_transform(engine, golden):
+    """Layer-by-layer path at hidden width 32: the aggregation of layer l and the transform of layer l + 1 run as one
+    launch (csrc/layer.hip).  Same bits as the two separate kernels (DGCN_LAYER_FUSE=0) and as the twin, for deep stacks
+    with and without bias, explicit features, the BA mix, and a batch whose largest graph (700 vertices) sends it back
+    to the separate kernels."""
+    import os
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    big = sp.random(700, 700, density=0.01, random_state=5, format="csr")
+    big = ((big + big.T) > 0).astype(float); big.setdiag(0); big.eliminate_zeros()
+    cases = [(golden.host_batch(), datagen.random_model(5, 32, seed=1), None),
+             (datagen.ba_test2_batch(50), datagen.random_model(4, 32, bias=True, last_act="leaky_relu", seed=2), None),
+             (golden.host_batch([0, 3]), datagen.random_model(3, 32, feature_size=8, seed=3), 8),
+             (HostBatch.from_scipy([sp.csr_matrix(big), golden.scipy(0)]), datagen.random_model(4, 32, seed=4), None)]
+    for hb, layers, fs in cases:
+        db = engine.upload(hb)
+        dm = DeviceModel(layers, engine.device)
+        X = None if fs is None else np.random.default_rng(0).random((hb.num_nodes, fs)).astype(np.float32)
+        Xd = None if X is None else _dev(engine, X)
+        got = engine.forward(db, dm, X=Xd, mode=0).cpu().numpy()
+        os.environ["DGCN_LAYER_FUSE"] = "0"
+        try:
+            plain = engine.forward(db, dm, X=Xd, mode=0).cpu().numpy()
+        finally:
+            del os.environ["DGCN_LAYER_FUSE"]
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        twin = ctwin.forward(lap, layers, hb.num_nodes, X=X)
+        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+        assert np.array_equal(got.view(np.uint32), twin.view(np.uint32))
+    # the launches really are fused: one "layer" launch per hidden layer boundary, no separate transform after the first
+    hb, layers, _ = cases[0]
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    engine.supports(db)
+    engine.timing(True)
+    engine.forward(db, dm, mode=0)
+    engine.torch.cuda.synchronize()
+    engine.timing(False)
+    assert engine.timing_read("layer")[1] == 4 and engine.timing_read("transform")[1] == 1 and engine.timing_read("spmm")[1] == 1

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run the batched SpMM kernel alone (for rocprofv3 --pmc passes): python tools/run_spmm.py [er|ba] [iters] [sets]
 sets > 1: that many DISTINCT 500-graph batches visited round-robin, so that > 256 MiB of other traffic lies
-between two uses of a line (out of the Infinity Cache: the HBM measurement)."""
+between two uses of a line (out of the Infinity Cache: the HBM measurement).  sets < 0: ONE batch of |sets| * 500
+graphs per launch (-8 = 4 000 graphs, 444 MB per launch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +13,11 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nsets = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 eng = Engine("cuda:0")
 sets = []
+count = 500
+if nsets < 0:
+    count, nsets = -nsets * 500, 1
 for i in range(nsets):
-    hb = datagen.er_batch(500, 200, 0.1, first_index=i * 500) if kind == "er" else datagen.ba_test2_batch(500, first_index=i * 500)
+    hb = datagen.er_batch(count, 200, 0.1, first_index=i * count) if kind == "er" else datagen.ba_test2_batch(count, first_index=i * count)
     db = eng.upload(hb)
     sets.append((hb, db, eng.supports(db), torch.randn(hb.num_nodes, 64, device="cuda"), torch.empty(hb.num_nodes, 32, device="cuda")))
 for _ in range(iters):

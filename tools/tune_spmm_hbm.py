@@ -32,7 +32,7 @@ def main():
     big = make(eng, datagen.er_batch(4000, 200, 0.1, first_index=50_000))
     rot = [make(eng, datagen.er_batch(500, 200, 0.1, first_index=i * 500)) for i in range(8)]
     variants = [dict()]
-    for rows, block in itertools.product([200, 100, 64], [256, 512, 1024]):
+    for rows, block in (itertools.product([200, 100, 64], [256, 512, 1024]) if os.environ.get("DGCN_TUNE_FULL") else []):
         variants.append(dict(DGCN_SPMM_ROWS=str(rows), DGCN_SPMM_BLOCK=str(block)))
     variants.append(dict(DGCN_SPMM_GLOBAL="1"))
     variants.append(dict(DGCN_SPMM_CSRCAP="0"))
