@@ -107,15 +107,55 @@ class DQNAgent:
         """Solve many graphs in one launch.  Returns a list of ``(set, total_wt, 1.0)`` in input order."""
         eng = get_engine()
         pruned = [self._prune(a, w) for a, w in zip(adjs, wts_list)]
-        hb = HostBatch.from_csr_lists([p[0].indptr for p in pruned],
-                                      [p[0].indices for p in pruned], [p[1] for p in pruned])
-        res = solve_host_batch(eng, self.model, hb, self.flags.predict, mode)
+        res, gp = solve_csr_lists(eng, self.model, [p[0].indptr for p in pruned], [p[0].indices for p in pruned],
+                                  [p[1] for p in pruned], self.flags.predict, mode)
         out = []
-        for g, (n0, n1) in enumerate(hb.graph_slices()):
+        for g in range(len(pruned)):
             keep = pruned[g][2]
-            sel = np.flatnonzero(res["state"][n0:n1] == 1)
-            out.append((set(int(i) for i in keep[sel]), np.float64(res["totals"][g]), 1.0))
+            sel = np.flatnonzero(res["state"][gp[g]:gp[g + 1]] == 1)
+            out.append((set(keep[sel].tolist()), np.float64(res["totals"][g]), 1.0))
         return out
+
+
+_pipes = {}
+
+
+def _pipeline(eng, model, predict):
+    """Process-wide one-slot SolvePipeline per (engine, device model, predict): the API calls re-use its pinned staging,
+    device buffers and stream instead of allocating per call."""
+    from .serving import SolvePipeline
+    dm = model.device_model(eng)
+    key = (id(eng), predict)
+    hit = _pipes.get(key)
+    if hit is None or hit[0] is not dm:
+        hit = (dm, SolvePipeline(eng, dm, depth=1, predict=predict, want_scores=True))
+        _pipes[key] = hit
+    return hit[1]
+
+
+def solve_csr_lists(eng, model, indptrs, indices, weights, predict: str = "mwis", mode: str = "auto", X=None):
+    """Per-graph CSR arrays -> (result dict of NumPy arrays, graph_ptr).  The common case - a shape the fused kernel
+    takes, no explicit features, one size class - is one native pack into pinned memory, one copy in, ONE launch, one
+    copy out through the cached pipeline; everything else goes through ``solve_host_batch``."""
+    w64 = [np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights]
+    if mode != "layered" and X is None and not getattr(model, "has_head", False) and len(indptrs):
+        pipe = _pipeline(eng, model, predict)
+        slot = pipe._next_slot()
+        try:
+            info = pipe._pack(slot, indptrs, indices, w64)
+        except TypeError:  # mixed index widths / non-contiguous arrays: the NumPy packer handles those
+            info = None
+        if info is not None:
+            hb = HostBatch.from_packed(slot.staging_np, info)
+            if hb.num_nodes > 0 and len(hb.size_buckets()) == 1 and pipe.supported(slot, info):
+                res = pipe.result(pipe._launch(slot, info), copy=True)
+                res["scores"] = res["scores"].reshape(-1, 1)
+                return res, hb.graph_ptr.copy()
+            if mode == "fused" and hb.num_nodes > 0 and not pipe.supported(slot, info):
+                raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")
+            return solve_host_batch(eng, model, hb, predict, mode), hb.graph_ptr.copy()
+    hb = HostBatch.from_csr_lists(indptrs, indices, w64)
+    return solve_host_batch(eng, model, hb, predict, mode, X=X), hb.graph_ptr
 
 
 def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str = "auto", X=None):

@@ -15,7 +15,7 @@ from .api_common import as_csr, get_engine
 from .batch import HostBatch
 from .gcn import utils as gutils
 from .gcn.models import GCN2_DQN
-from .mwis_dqn_call import _State, solve_host_batch
+from .mwis_dqn_call import _State, solve_csr_lists, solve_host_batch
 from .runtime_config import FLAGS, flags  # noqa: F401
 
 
@@ -86,14 +86,17 @@ class MWISSolver(object):
 
     def solve_mwis_batch(self, adjs: Sequence, wts_list: Sequence, mode: str = "auto") -> List[tuple]:
         csrs = [as_csr(a) for a in adjs]
-        hb = HostBatch.from_csr_lists([c.indptr for c in csrs],
-                                      [c.indices for c in csrs],
-                                      [np.asarray(w, dtype=np.float64).reshape(-1, self.feature_size)[:, 0] for w in wts_list])
-        res = solve_host_batch(get_engine(), self.model, hb, self.flags.predict, mode, X=self._features(hb))
+        ws = [np.asarray(w, dtype=np.float64).reshape(-1, self.feature_size)[:, 0] for w in wts_list]
+        if self.flags.predict == "mwis":  # constant features: the lean path (one pack, one launch, cached buffers)
+            res, gp = solve_csr_lists(get_engine(), self.model, [c.indptr for c in csrs], [c.indices for c in csrs], ws,
+                                      self.flags.predict, mode)
+        else:
+            hb = HostBatch.from_csr_lists([c.indptr for c in csrs], [c.indices for c in csrs], ws)
+            res, gp = solve_host_batch(get_engine(), self.model, hb, self.flags.predict, mode, X=self._features(hb)), hb.graph_ptr
         out = []
-        for g, (n0, n1) in enumerate(hb.graph_slices()):
-            sel = np.flatnonzero(res["state"][n0:n1] == 1)
-            out.append((set(int(i) for i in sel), np.float64(res["totals"][g])))
+        for g in range(len(csrs)):
+            sel = np.flatnonzero(res["state"][gp[g]:gp[g + 1]] == 1)
+            out.append((set(sel.tolist()), np.float64(res["totals"][g])))
         return out
 
 

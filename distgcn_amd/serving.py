@@ -47,11 +47,11 @@ class _Slot:
             self.staging_np = self.staging.numpy()
             self.dev = t.empty(nbytes, dtype=t.uint8, device=self.device)
 
-    def ensure_out(self, n, B):
+    def ensure_out(self, n, B, want_scores=False):
         if n > self.cap[0] or B > self.cap[1] or self.out is None:
             t = self.torch
             cap = (max(int(n * 1.25), 64), max(int(B * 1.25), 8))
-            size, self.layout = packed_layout(solve_buffer_specs(cap[0], cap[1], False))
+            size, self.layout = packed_layout(solve_buffer_specs(cap[0], cap[1], want_scores))
             self.out = t.zeros(size, dtype=t.uint8, device=self.device)
             self.res = t.empty(size, dtype=t.uint8, pin_memory=True)
             self.res_np = self.res.numpy()
@@ -59,8 +59,10 @@ class _Slot:
 
 
 class SolvePipeline:
-    def __init__(self, engine: Engine, model: DeviceModel, depth: int = 2, predict: str = "mwis", pack_threads: int = 0):
+    def __init__(self, engine: Engine, model: DeviceModel, depth: int = 2, predict: str = "mwis", pack_threads: int = 0,
+                 want_scores: bool = False):
         self.eng, self.model, self.predict = engine, model, predict
+        self.want_scores = want_scores
         self.torch = engine.torch
         self.lib = engine.lib
         self.pack_threads = pack_threads
@@ -83,17 +85,27 @@ class SolvePipeline:
                     raise
                 slot.ensure_staging(int(str(e).split("(")[1].split()[0]))
 
+    def _batch_struct(self, slot: _Slot, info):
+        base = slot.dev.data_ptr()
+        return _lib.DgcnBatch(int(info.num_graphs), int(info.num_nodes), int(info.num_edges), int(info.max_nodes),
+                              int(info.max_graph_edges), base + int(info.off_graph_ptr), base + int(info.off_row_ptr),
+                              base + int(info.off_col_idx))
+
+    def supported(self, slot: _Slot, info) -> bool:
+        """Does the fused kernel take this (packed) batch with this model?"""
+        return (int(info.max_degree) < self.table.numel() and
+                bool(self.lib.dgcn_solve_supported(C.byref(self._batch_struct(slot, info)), C.byref(self.model.c))))
+
     def _launch(self, slot: _Slot, info) -> _Slot:
         """Device stage: one copy in, one fused launch, one copy out, all on the slot's stream; returns at once."""
         t = self.torch
         n, B, e_ = int(info.num_nodes), int(info.num_graphs), int(info.num_edges)
         if int(info.max_degree) >= self.table.numel():
             raise _lib.DgcnError("vertex degree %d beyond the pipeline's d^-1/2 table" % int(info.max_degree))
-        slot.ensure_out(n, B)
+        slot.ensure_out(n, B, self.want_scores)
         total = int(info.total_bytes)
         base = slot.dev.data_ptr()
-        bc = _lib.DgcnBatch(B, n, e_, int(info.max_nodes), int(info.max_graph_edges), base + int(info.off_graph_ptr),
-                            base + int(info.off_row_ptr), base + int(info.off_col_idx))
+        bc = self._batch_struct(slot, info)
         if not self.lib.dgcn_solve_supported(C.byref(bc), C.byref(self.model.c)):
             raise _lib.DgcnError("this model / batch shape is outside the fused kernel: use mwis_dqn_call.solve_host_batch")
         need = int(self.lib.dgcn_solve_workspace(C.byref(bc), C.byref(self.model.c)))
@@ -105,7 +117,8 @@ class SolvePipeline:
             slot.dev[:total].copy_(slot.staging[:total], non_blocking=True)
             _lib.check(self.lib.dgcn_solve_batch(
                 C.byref(bc), C.byref(self.model.c), self.table.data_ptr(), int(self.table.numel()), None, self.x_const,
-                base + int(info.off_weights), 1 if self.predict == "mwis" else 0, None, ob + lay["state"][0],
+                base + int(info.off_weights), 1 if self.predict == "mwis" else 0,
+                (ob + lay["scores"][0]) if self.want_scores else None, ob + lay["state"][0],
                 ob + lay["rounds"][0], ob + lay["totals"][0], ob + lay["status"][0], slot.ws.data_ptr(), need,
                 C.c_void_p(slot.stream.cuda_stream)), "dgcn_solve_batch")
             slot.res.copy_(slot.out, non_blocking=True)
@@ -133,7 +146,7 @@ class SolvePipeline:
         n, B = slot.shape
         host = slot.res_np
         out = {}
-        for name, count in (("state", n), ("totals", B), ("rounds", B), ("status", 1)):
+        for name, count in (("state", n), ("totals", B), ("rounds", B), ("status", 1)) + ((("scores", n),) if self.want_scores else ()):
             o, nb, dt = slot.layout[name]
             v = host[o:o + nb].view(_NP[dt])[:count]
             out[name] = v.copy() if copy else v

@@ -411,13 +411,18 @@ def solve_mwis_cit(scores_fn, adj_0, wts_0, predict="mwis"):
     return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
 
-def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, rescore=True, by_priority=False):
+def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, rescore=True, by_priority=False,
+                       reference_ties=False):
     """Top-b GCN candidates, each scored by its weight plus a greedy completion of the residual
     (mwis_gdpg_call.py:596-659).  The reference breaks score ties with ``np.random.choice`` and ranks
     with an unstable sort; here ties go to the first candidate / lower index unless ``rng`` is given.
     Variants (mwis_gdpg_call.py:413-594): ``rescore=False`` runs the GCN once on the full graph (rollout00,
     rollout0); ``by_priority=True`` orders the greedy completions by the GCN priority instead of the weight,
-    still valuing them by weight (rollout0, rollout1)."""
+    still valuing them by weight (rollout0, rollout1).
+    ``reference_ties=True`` reproduces the reference's own tie handling bit for bit - candidate totals summed in
+    its order (``np.sum(wts_ro[list(ps)])`` over the CPython set), exact ``scores == scores.max()``, one
+    ``rng.choice`` per step (pass ``numpy.random`` seeded like the run to replay) and NumPy's default argsort: the
+    mode tests/test_oracle_golden.py uses against the reference-executed vectors (tests/golden/ref_exec.npz)."""
     adj_0 = sp.csr_matrix(adj_0)
     wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
     nIS_vec = -np.ones(adj_0.shape[0])
@@ -430,7 +435,7 @@ def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, 
             break
         act_vals = scores_fn(adj_nn, wts_nn) if rescore else full_scores[rmap]
         gcn_wts = priority(act_vals, wts_nn, predict)
-        children = np.argsort(-gcn_wts.flatten(), kind="stable")[0:b]
+        children = (np.argsort(-gcn_wts.flatten()) if reference_ties else np.argsort(-gcn_wts.flatten(), kind="stable"))[0:b]
         scores = wts_nn[children].copy()
         if len(scores) > 1:
             for i, child in enumerate(children):
@@ -439,15 +444,19 @@ def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, 
                 _, nb_v = np.nonzero(adj_nn[child])
                 keep[nb_v] = False
                 adj_ro = adj_nn[keep, :][:, keep]
-                if by_priority:
-                    ps, _ = greedy_search(adj_ro, gcn_wts.flatten()[keep])
-                    ss = np.sum(wts_nn[keep][sorted(ps)])
+                if by_priority or (reference_ties and not rescore):
+                    # rollout00 / 0 / 1 (mwis_gdpg_call.py:456-458, 517-519, 578-580) re-sum the completion themselves
+                    ps, _ = greedy_search(adj_ro, gcn_wts.flatten()[keep] if by_priority else wts_nn[keep])
+                    ss = np.sum(wts_nn[keep][list(ps)]) if reference_ties else np.sum(wts_nn[keep][sorted(ps)])
                 else:
                     _, ss = greedy_search(adj_ro, wts_nn[keep])
                 scores[i] += ss
-        # candidates that complete to the same set tie mathematically but not bit for bit (the sums run in
-        # different orders): totals within 1e-12 relative count as tied
-        ties = np.flatnonzero(np.isclose(scores, scores.max(), rtol=1e-12, atol=0.0))
+        if reference_ties:
+            ties = np.flatnonzero(scores == scores.max())
+        else:
+            # candidates that complete to the same set tie mathematically but not bit for bit (the sums run in
+            # different orders): totals within 1e-12 relative count as tied
+            ties = np.flatnonzero(np.isclose(scores, scores.max(), rtol=1e-12, atol=0.0))
         i_best = int(rng.choice(ties)) if rng is not None else int(ties[0])
         pick = int(children[i_best])
         _, nb_v = np.nonzero(adj_nn[pick])
@@ -463,31 +472,33 @@ def _components(adj):
     return [np.flatnonzero(labels == c) for c in range(ncomp)]
 
 
-def solve_wrap(inner, scores_fn, adj_0, wts_0, **kw):
+def solve_wrap(inner, scores_fn, adj_0, wts_0, reference_mapping=False, **kw):
     """``solve_mwis_cit_wrap`` / ``solve_mwis_rollout_wrap`` (mwis_gdpg_call.py:320-341, 386-411): run
-    ``inner`` per connected component and add the utilities."""
+    ``inner`` per connected component and add the utilities.
+
+    ``reference_mapping=True`` reproduces the reference to the letter, including a latent bug: it takes the
+    components from NetworkX as Python sets, slices the adjacency with a boolean mask (ascending vertex order) but maps
+    the component-local solution back through ``list(component_set)[i]`` - CPython's set iteration order, which is not
+    ascending for every component (fixture g01: {93, 21} iterates as [93, 21]).  The returned set can then hold a vertex
+    the component's solver did not pick, and its weight no longer equals the returned total (26.607 vs 27.070 on g01).
+    The default maps through the ascending order the slice used; totals are identical either way."""
     adj_0 = sp.csr_matrix(adj_0)
     wts = np.reshape(np.asarray(wts_0, dtype=np.float64), (adj_0.shape[0], -1))
     total = np.array([0.0])
     chosen = set()
+    if reference_mapping:
+        import networkx as nx
+        graph = nx.from_scipy_sparse_array(adj_0) if hasattr(nx, "from_scipy_sparse_array") else nx.from_scipy_sparse_matrix(adj_0)
+        for comp_set in nx.connected_components(graph):
+            order = list(comp_set)
+            mask = np.zeros(adj_0.shape[0], dtype=bool)
+            mask[order] = True
+            sub, util = inner(scores_fn, adj_0[mask, :][:, mask], wts[mask, :], **kw)
+            total = total + util
+            chosen |= set(int(order[i]) for i in sub)
+        return chosen, total
     for comp in _components(adj_0):
         sub, util = inner(scores_fn, adj_0[comp, :][:, comp], wts[comp, :], **kw)
         total = total + util
         chosen |= set(int(comp[i]) for i in sub)
     return chosen, total
-
-
-def margin_risk(indptr, indices, prio, state, delta, wabs=None):
-    """SURVEY 7.3(c), checker for dgcn_margin_risk_batch: the number of excluded vertices (state 2) without a member
-    neighbour u (state 1) whose priority leads by more than delta * (|w_u| + |w_v|).  The local greedy search
-    (heuristics.py:77-116) returns the unique independent set in which every excluded vertex has a member neighbour
-    ahead of it in (priority desc, index asc); zero risky vertices means no score error up to ``delta`` changes it."""
-    prio = np.asarray(prio, dtype=np.float64)
-    wabs = np.ones_like(prio) if wabs is None else np.abs(np.asarray(wabs, dtype=np.float64))
-    risky = 0
-    for v in np.flatnonzero(np.asarray(state) == 2):
-        nb = indices[indptr[v]:indptr[v + 1]]
-        nb = nb[np.asarray(state)[nb] == 1]
-        if not np.any(prio[nb] - prio[v] > delta * (wabs[nb] + wabs[v])):
-            risky += 1
-    return risky

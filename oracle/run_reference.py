@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Execute the REFERENCE'S OWN Python (mwis_dqn_call.py, mwis_gdpg_call.py, gcn/models.py, gcn/layers.py ...) in the
+build container and store what it returns as golden vectors: tests/golden/ref_exec.npz.  TEST INFRASTRUCTURE.
+
+    python oracle/run_reference.py            # needs /root/reference; never runs on the GPU box
+
+The reference imports TensorFlow, which cannot be installed here.  oracle/tf_shim/ puts a NumPy stand-in for the
+~60 tf.compat.v1 entry points its model code touches first on sys.path (lazy graph nodes evaluated in float32 by
+NumPy / SciPy; see that package's docstring), so the reference's files run UNMODIFIED from where they lie - nothing
+is copied.  Old-library spellings the reference relies on are aliased for the import only (networkx's
+from_scipy_sparse_matrix / adjacency_matrix -> SciPy matrices, np.bool) and three unused heavy imports are empty
+stand-ins (dwave_networkx, igraph, pulp), exactly as oracle/make_golden.py does.
+
+What these vectors pin (reference code executed, not restated): model assembly (layer count, widths, which layers
+get which activation, bias, support slicing), checkpoint restore by variable name, makestate of both agents,
+predict, the whole of DQNAgent.solve_mwis (zero-weight pruning with NetworkX, index mapping, local greedy search,
+totals) and MWISSolver.solve_mwis / _dit / _cit / _rollout / _wrap control flow.  What they do NOT pin: the
+arithmetic inside TensorFlow's kernels - the stand-in evaluates sparse_tensor_dense_matmul / matmul / add_n with
+SciPy / NumPy float32, so the GCN scores here equal oracle/ref_numpy.py's float32 restatement whenever the two
+agree on the STRUCTURE, and say nothing about TF's summation order ("parity unpinned" at that boundary remains).
+
+Each configuration runs in a fresh interpreter (the reference builds its model and a module-level agent at import).
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("DGCN_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden", "ref_exec.npz")
+
+DQN_MODELS = [  # (checkpoint dir name, flags)
+    ("result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn", dict(feature_size=1, hidden1=32, num_layer=20, max_degree=1)),
+    ("result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn", dict(feature_size=1, hidden1=32, num_layer=1, max_degree=1)),
+    ("result_DQNBA_deep_ld1_c32_l3_cheb1_diver1_mwis_dqn", dict(feature_size=1, hidden1=32, num_layer=3, max_degree=1)),
+    ("result_IS4SAT_deep_ld1_c16_l4_cheb1_diver1_mwis_dqn", dict(feature_size=1, hidden1=16, num_layer=4, max_degree=1)),
+    ("result_IS4SAT_deep_ld32_c32_l20_cheb1_diver1_mwis_dqn", dict(feature_size=32, hidden1=32, num_layer=20, max_degree=1)),
+    ("result_IS4SAT_deep_ld32_c64_l2_cheb1_diver1_mwis_dqn", dict(feature_size=32, hidden1=64, num_layer=2, max_degree=1)),
+    ("result_IS4SAT_deep_ld1_c1_l2_cheb2_diver1_mwis_dqn", dict(feature_size=1, hidden1=1, num_layer=2, max_degree=2)),
+    ("result_DQNEPI_deep_ld1_c32_l20_cheb1_diver1_mis_dqn", dict(feature_size=1, hidden1=32, num_layer=20, max_degree=1, predict="mis")),
+]
+GRAPHS = [0, 2, 9, 12]  # fixture graph ids of tests/golden/graphs.npz
+GDPG_CONFIGS = [dict(feature_size=1, hidden1=32, num_layer=3, max_degree=1, predict="mwis"),
+                dict(feature_size=1, hidden1=32, num_layer=3, max_degree=1, predict="mis")]
+GDPG_GRAPHS = [1, 7, 2]  # small graphs: the iterative solvers run hundreds of forward passes
+
+
+def prepare_reference_imports():
+    """sys.path + stand-ins so that the reference's modules import here."""
+    for name in ("dwave_networkx", "igraph", "pulp"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            if name == "pulp":
+                mod.GLPK = object
+            sys.modules[name] = mod
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    if not hasattr(np, "float"):
+        np.float = float
+    import networkx as nx
+    if not hasattr(nx, "from_scipy_sparse_matrix"):
+        nx.from_scipy_sparse_matrix = nx.from_scipy_sparse_array
+    _adj = nx.adjacency_matrix
+    nx.adjacency_matrix = lambda g, *a, **k: sp.csr_matrix(_adj(g, *a, **k))  # networkx 2.x returned a SciPy *matrix*
+    sys.path.insert(0, ROOT)  # distgcn_amd.checkpoint: the bundle reader behind the shim's Saver.restore
+    sys.path.insert(0, os.path.join(REF, "gcn"))
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(HERE, "tf_shim"))
+
+
+def fixture(i):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz"))
+    k = "g%02d" % i
+    w = z[k + "_weights"]
+    adj = sp.csr_matrix((np.ones(z[k + "_indices"].size), z[k + "_indices"], z[k + "_indptr"]), shape=(w.size, w.size))
+    return adj, w
+
+
+def flag_args(flags):
+    base = dict(diver_num=1, epsilon=0.0002, wts_init="random")
+    base.update(flags)
+    return ["--%s=%s" % (k, v) for k, v in base.items()]
+
+
+# ---------------------------------------------------------------------------------------------- workers
+def worker_dqn(model_dir, out_path):
+    prepare_reference_imports()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import mwis_dqn_call as m  # builds placeholders, the model and `dqn_agent` at import
+        m.dqn_agent.load(os.path.join(REF, "model", model_dir))
+    import tensorflow as tf
+    out = {"variable_names": np.array(sorted(tf.shim_variables()))}
+    rng = np.random.default_rng(11)
+    for gi in GRAPHS:
+        adj, w = fixture(gi)
+        state = m.dqn_agent.makestate(adj, w.reshape(-1, 1))
+        act_values, action = m.dqn_agent.predict(state)
+        out["g%02d|scores" % gi] = np.asarray(act_values, dtype=np.float32)
+        out["g%02d|action" % gi] = np.asarray(action, dtype=np.int64)
+        wz = w.copy()
+        wz[rng.random(w.size) < 0.1] = 0.0  # the pruning branch of solve_mwis (mwis_dqn_call.py:202-207)
+        for tag, ww in (("full", w), ("zeros", wz)):
+            sol, total, reward = m.dqn_agent.solve_mwis(adj, ww, train=False)
+            out["g%02d|%s|weights" % (gi, tag)] = ww
+            out["g%02d|%s|set" % (gi, tag)] = np.array(sorted(int(v) for v in sol), dtype=np.int64)
+            out["g%02d|%s|total" % (gi, tag)] = np.float64(total)
+            out["g%02d|%s|reward" % (gi, tag)] = np.float64(reward)
+    np.savez_compressed(out_path, **out)
+
+
+def worker_gdpg(out_path):
+    prepare_reference_imports()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import mwis_gdpg_call as m
+        agent = m.DQNAgent(m.FLAGS, 5000)
+    import tensorflow as tf
+    out = {}
+    rng = np.random.RandomState(5)
+    for name, val in tf.shim_variables().items():
+        if name.startswith("model/") and name.endswith("/bias"):  # biases start at 0: make them matter
+            for v in tf._variables:
+                if v.name == name + ":0":
+                    v.value_ = rng.uniform(-0.2, 0.2, size=np.shape(val)).astype(np.float32)
+    for name, val in tf.shim_variables().items():
+        if name.startswith("model/"):
+            out["var|" + name] = np.asarray(val)
+    for gi in GDPG_GRAPHS:
+        adj, w = fixture(gi)
+        state = agent.makestate(adj, w.reshape(-1, 1))
+        act_values, action = agent.predict(state)
+        out["g%02d|scores" % gi] = np.asarray(act_values, dtype=np.float32)
+        out["g%02d|action" % gi] = np.asarray(action, dtype=np.int64)
+        for which in ("solve_mwis", "solve_mwis_dit", "solve_mwis_cit", "solve_mwis_cit_wrap", "solve_mwis_rollout",
+                      "solve_mwis_rollout_wrap", "solve_mwis_rollout00", "solve_mwis_rollout0", "solve_mwis_rollout1"):
+            fn = getattr(agent, which, None)
+            if fn is None:
+                continue
+            np.random.seed(1234)  # the rollouts break ties with np.random.choice
+            kw = dict(b=8) if "rollout" in which else {}
+            try:
+                sol, total = fn(adj, w, train=False, **kw)
+            except TypeError:
+                sol, total = fn(adj, w, **kw)
+            out["g%02d|%s|set" % (gi, which)] = np.array(sorted(int(v) for v in sol), dtype=np.int64)
+            out["g%02d|%s|total" % (gi, which)] = np.float64(np.asarray(total).ravel()[0])
+    np.savez_compressed(out_path, **out)
+
+
+# ---------------------------------------------------------------------------------------------- driver
+def run_worker(kind, extra, flags):
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "o.npz")
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", kind, path] + extra + flag_args(flags)
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=REF)
+        if r.returncode != 0:
+            raise RuntimeError("reference worker %s failed:\n%s" % (kind, r.stderr[-4000:]))
+        z = np.load(path)
+        return {k: z[k] for k in z.files}
+
+
+def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "--worker":
+        kind, path = sys.argv[2], sys.argv[3]
+        rest = sys.argv[4:]
+        if kind == "dqn":
+            model_dir = rest[0]
+            sys.argv = [sys.argv[0]] + rest[1:]
+            worker_dqn(model_dir, path)
+        else:
+            sys.argv = [sys.argv[0]] + rest
+            worker_gdpg(path)
+        return
+    out = {"dqn_models": np.array([m for m, _ in DQN_MODELS]), "graphs": np.array(GRAPHS), "gdpg_graphs": np.array(GDPG_GRAPHS),
+           "dqn_flags": np.array([json.dumps(f) for _, f in DQN_MODELS]), "gdpg_flags": np.array([json.dumps(f) for f in GDPG_CONFIGS])}
+    for model_dir, flags in DQN_MODELS:
+        res = run_worker("dqn", [model_dir], flags)
+        for k, v in res.items():
+            out["dqn|%s|%s" % (model_dir, k)] = v
+        print("dqn  %-60s ok (%d arrays)" % (model_dir, len(res)))
+    for ci, flags in enumerate(GDPG_CONFIGS):
+        res = run_worker("gdpg", [], flags)
+        for k, v in res.items():
+            out["gdpg|%d|%s" % (ci, k)] = v
+        print("gdpg config %d %s ok (%d arrays)" % (ci, flags, len(res)))
+    np.savez_compressed(OUT, **out)
+    print("%s: %d arrays, %d bytes" % (OUT, len(out), os.path.getsize(OUT)))
+
+
+if __name__ == "__main__":
+    main()

@@ -785,3 +785,80 @@ def test_serving_pipeline_host_to_host(engine, golden):
     with pytest.raises(DgcnError, match="NaN"):
         pipe.result(pipe.submit(*bad))
     assert np.array_equal(pipe.result(pipe.submit(*batches[1]))["state"], refs[1]["state"])  # the pipeline recovers
+
+
+def _ref_exec():
+    import json
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "ref_exec.npz"))
+    dqn = [(str(m), json.loads(str(f))) for m, f in zip(z["dqn_models"], z["dqn_flags"])]
+    gdpg = [json.loads(str(f)) for f in z["gdpg_flags"]]
+    return z, dqn, gdpg
+
+
+def test_against_the_executed_reference_dqn_agent(engine, golden, all_models):
+    """The drop-in DQNAgent against vectors the reference's OWN mwis_dqn_call.py produced (oracle/run_reference.py:
+    the reference's Python executed with a NumPy stand-in for TensorFlow's ops): 8 shipped checkpoints x 4 graphs -
+    act_values within 1e-5, the same argmax action, and solve_mwis (with and without zero weights: NetworkX pruning
+    and id mapping in the reference) returning the same set, total and reward."""
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    z, dqn, _ = _ref_exec()
+    worst = 0.0
+    for m, fl in dqn:
+        agent = DQNAgent(fl["feature_size"], flags=_flags(**fl))
+        agent.model.set_params(all_models.params(m))
+        for gi in (int(g) for g in z["graphs"]):
+            adj, w = golden.scipy(gi), golden.csr(gi)[2]
+            act_values, action = agent.predict(agent.makestate(adj, w.reshape(-1, 1)))
+            ref = z["dqn|%s|g%02d|scores" % (m, gi)]
+            worst = max(worst, float(np.abs(act_values - ref).max()))
+            assert act_values.shape == ref.shape and np.abs(act_values - ref).max() <= 1e-5, (m, gi)
+            assert action[0] == z["dqn|%s|g%02d|action" % (m, gi)][0] or \
+                abs(ref[action[0], 0] - ref.max()) <= 2e-5, (m, gi)
+            for tag in ("full", "zeros"):
+                ww = z["dqn|%s|g%02d|%s|weights" % (m, gi, tag)]
+                got, tot, reward = agent.solve_mwis(adj, ww)
+                assert sorted(got) == z["dqn|%s|g%02d|%s|set" % (m, gi, tag)].tolist(), (m, gi, tag)
+                assert tot == pytest.approx(float(z["dqn|%s|g%02d|%s|total" % (m, gi, tag)]), rel=1e-12) and reward == 1.0
+    assert worst <= 1e-5
+
+
+def test_against_the_executed_reference_gdpg_solvers(engine, golden):
+    """mwis_gdpg_call.DQNAgent (GCN2_DQN: bias on every layer, activation on the last) against the reference's own
+    run: act_values within 1e-5; solve_mwis, solve_mwis_dit, solve_mwis_cit give the reference's sets and totals;
+    the rollout family - where the reference draws np.random.choice among tied candidates - gives the reference's set
+    whenever the deterministic tie rule (first candidate) reproduces it on the oracle, which must be the case for most;
+    the per-component wrappers return the reference's TOTAL (its set mapping is off for one component of g01, see
+    oracle/ref_numpy.solve_wrap)."""
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    z, _, gdpg = _ref_exec()
+    agree = total = 0
+    for ci, fl in enumerate(gdpg):
+        agent = DQNAgent(_flags(**fl), seed=1)
+        pre = "gdpg|%d|var|" % ci
+        agent.model.set_params({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+        layers = agent.model.layers
+        fn = orc._default_scores_fn(layers, 1, 1, fl["predict"])
+        for gi in (int(g) for g in z["gdpg_graphs"]):
+            adj, w = golden.scipy(gi), golden.csr(gi)[2]
+            vals, action = agent.predict(agent.makestate(adj, w.reshape(-1, 1)))
+            assert np.abs(vals - z["gdpg|%d|g%02d|scores" % (ci, gi)]).max() <= 1e-5
+            for name in ("solve_mwis", "solve_mwis_dit", "solve_mwis_cit"):
+                got, tot = getattr(agent, name)(adj, w)
+                assert sorted(got) == z["gdpg|%d|g%02d|%s|set" % (ci, gi, name)].tolist(), (ci, gi, name)
+                assert float(np.asarray(tot).ravel()[0]) == pytest.approx(float(z["gdpg|%d|g%02d|%s|total" % (ci, gi, name)]), rel=1e-12)
+            for name in ("solve_mwis_cit_wrap",):
+                got, tot = getattr(agent, name)(adj, w)
+                assert float(np.asarray(tot).ravel()[0]) == pytest.approx(float(z["gdpg|%d|g%02d|%s|total" % (ci, gi, name)]), rel=1e-12)
+                assert float(w[sorted(got)].sum()) == pytest.approx(float(np.asarray(tot).ravel()[0]), rel=1e-12)
+            variants = {"solve_mwis_rollout": dict(), "solve_mwis_rollout00": dict(rescore=False),
+                        "solve_mwis_rollout0": dict(rescore=False, by_priority=True), "solve_mwis_rollout1": dict(by_priority=True)}
+            for name, kw in variants.items():
+                got, tot = getattr(agent, name)(adj, w, b=8)
+                ref_set = z["gdpg|%d|g%02d|%s|set" % (ci, gi, name)].tolist()
+                det, _ = orc.solve_mwis_rollout(fn, adj, w, b=8, predict=fl["predict"], **kw)  # first-candidate tie rule
+                assert sorted(got) == sorted(det), (ci, gi, name)
+                total += 1
+                agree += sorted(got) == ref_set
+    assert agree >= total * 2 // 3, (agree, total)

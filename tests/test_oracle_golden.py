@@ -252,3 +252,113 @@ def test_known_answers_of_100_shipped_graphs(dataset100):
         assert total == pytest.approx(z["greedy_utility"][i], rel=1e-9)
         st, rounds = orc.lgs_vectorised(p, c, w)
         assert rounds == z["lgs_rounds"][i] and np.sum(w[st == 1]) == pytest.approx(z["lgs_total"][i], rel=1e-12)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Vectors produced by EXECUTING the reference's own mwis_dqn_call.py / mwis_gdpg_call.py / gcn/*.py
+# (oracle/run_reference.py, with oracle/tf_shim standing in for TensorFlow's ops in NumPy float32).  They pin
+# everything the reference's Python decides - model assembly, variable names, makestate, predict, solve_mwis with its
+# NetworkX pruning and id mapping, the iterative solvers' control flow and tie handling - not TF's kernel arithmetic.
+class RefExec:
+    def __init__(self):
+        import json
+        import os
+        from conftest import GOLDEN
+        self.z = np.load(os.path.join(GOLDEN, "ref_exec.npz"))
+        self.dqn = [(str(m), json.loads(str(f))) for m, f in zip(self.z["dqn_models"], self.z["dqn_flags"])]
+        self.gdpg = [json.loads(str(f)) for f in self.z["gdpg_flags"]]
+        self.graphs = [int(g) for g in self.z["graphs"]]
+        self.gdpg_graphs = [int(g) for g in self.z["gdpg_graphs"]]
+
+    def gdpg_params(self, ci):
+        pre = "gdpg|%d|var|" % ci
+        return {k[len(pre):]: self.z[k] for k in self.z.files if k.startswith(pre)}
+
+
+@pytest.fixture(scope="module")
+def ref_exec():
+    return RefExec()
+
+
+def test_restatement_equals_executed_reference_dqn_agent(golden, all_models, ref_exec):
+    """mwis_dqn_call.DQNAgent as the reference itself ran it (8 shipped checkpoints incl. F = 32, hidden 64, l = 1..20,
+    max_degree = 2 and a predict = 'mis' model; 4 graphs each): restored variable names, act_values (bit for bit: the
+    restatement makes the same NumPy calls the stand-in makes for TF's ops), argmax action, and solve_mwis with and
+    without zero weights - sets, totals, reward."""
+    z = ref_exec.z
+    for m, fl in ref_exec.dqn:
+        params = all_models.params(m)
+        assert sorted(params) == [str(x) for x in z["dqn|%s|variable_names" % m]], m
+        layers = orc.gcn_layer_specs(params, num_supports=fl["max_degree"] + 1)
+        predict = fl.get("predict", "mwis")
+        for gi in ref_exec.graphs:
+            adj, w = golden.scipy(gi), golden.csr(gi)[2]
+            state = orc.makestate(adj, w.reshape(-1, 1), fl["feature_size"], fl["max_degree"], "dqn_call")
+            s32, action = orc.gcn_forward(layers, state, np.float32)
+            assert np.array_equal(s32, z["dqn|%s|g%02d|scores" % (m, gi)]), (m, gi)
+            assert np.array_equal(action, z["dqn|%s|g%02d|action" % (m, gi)])
+            for tag in ("full", "zeros"):
+                ww = z["dqn|%s|g%02d|%s|weights" % (m, gi, tag)]
+                sol, tot, reward = orc.solve_mwis_dqn(layers, adj, ww, feature_size=fl["feature_size"],
+                                                      max_degree=fl["max_degree"], predict=predict)
+                assert sorted(int(v) for v in sol) == z["dqn|%s|g%02d|%s|set" % (m, gi, tag)].tolist(), (m, gi, tag)
+                assert float(tot) == float(z["dqn|%s|g%02d|%s|total" % (m, gi, tag)]) and reward == 1.0
+
+
+def test_restatement_equals_executed_reference_gdpg_solvers(golden, ref_exec):
+    """mwis_gdpg_call.DQNAgent (GCN2_DQN with bias, activation on the last layer) as the reference ran it, predict =
+    'mwis' and 'mis': act_values bit for bit, and every solver - solve_mwis, _dit, _cit, _cit_wrap, _rollout,
+    _rollout_wrap, _rollout00 / 0 / 1 - sets and totals, with the restatement in its reference-tie mode (the
+    reference's exact-equality ties, np.random.choice stream and summation order) and reference id mapping."""
+    z = ref_exec.z
+    for ci, fl in enumerate(ref_exec.gdpg):
+        layers = orc.gcn_layer_specs(ref_exec.gdpg_params(ci), model="GCN2_DQN", scope="model/gcn2_dqn")
+        assert [l["act"] for l in layers] == ["leaky_relu"] * 3 and all(l["bias"] is not None for l in layers)
+        predict = fl["predict"]
+        fn = orc._default_scores_fn(layers, 1, 1, predict)
+        R = dict(reference_ties=True, rng=np.random, b=8, predict=predict)
+        for gi in ref_exec.gdpg_graphs:
+            adj, w = golden.scipy(gi), golden.csr(gi)[2]
+            state = orc.makestate(adj, w.reshape(-1, 1), 1, 1, "gdpg", predict)
+            s32, action = orc.gcn_forward(layers, state, np.float32)
+            assert np.array_equal(s32, z["gdpg|%d|g%02d|scores" % (ci, gi)])
+            assert np.array_equal(action, z["gdpg|%d|g%02d|action" % (ci, gi)])
+            calls = {
+                "solve_mwis": lambda: orc.solve_mwis_gdpg(layers, adj, w, 1, 1, predict),
+                "solve_mwis_dit": lambda: orc.solve_mwis_dit(fn, adj, w, predict),
+                "solve_mwis_cit": lambda: orc.solve_mwis_cit(fn, adj, w, predict),
+                "solve_mwis_cit_wrap": lambda: orc.solve_wrap(orc.solve_mwis_cit, fn, adj, w, reference_mapping=True, predict=predict),
+                "solve_mwis_rollout": lambda: orc.solve_mwis_rollout(fn, adj, w, **R),
+                "solve_mwis_rollout_wrap": lambda: orc.solve_wrap(orc.solve_mwis_rollout, fn, adj, w, reference_mapping=True, **R),
+                "solve_mwis_rollout00": lambda: orc.solve_mwis_rollout(fn, adj, w, rescore=False, **R),
+                "solve_mwis_rollout0": lambda: orc.solve_mwis_rollout(fn, adj, w, rescore=False, by_priority=True, **R),
+                "solve_mwis_rollout1": lambda: orc.solve_mwis_rollout(fn, adj, w, by_priority=True, **R),
+            }
+            for name, f in calls.items():
+                np.random.seed(1234)  # oracle/run_reference.py seeds the reference's np.random.choice the same way
+                sol, tot = f()
+                assert sorted(int(v) for v in sol) == z["gdpg|%d|g%02d|%s|set" % (ci, gi, name)].tolist(), (ci, gi, name)
+                assert float(np.asarray(tot).ravel()[0]) == float(z["gdpg|%d|g%02d|%s|total" % (ci, gi, name)]), (ci, gi, name)
+    # the default (ascending) id mapping of the wrappers returns a set whose weight equals the reported total;
+    # the reference's own mapping does not on fixture g01 (a component CPython iterates out of order)
+    adj, w = golden.scipy(1), golden.csr(1)[2]
+    layers = orc.gcn_layer_specs(ref_exec.gdpg_params(0), model="GCN2_DQN", scope="model/gcn2_dqn")
+    fn = orc._default_scores_fn(layers, 1, 1, "mwis")
+    sol, tot = orc.solve_wrap(orc.solve_mwis_cit, fn, adj, w, predict="mwis")
+    assert float(w[sorted(sol)].sum()) == pytest.approx(float(tot[0]), rel=1e-12)
+    ref_set = z["gdpg|0|g01|solve_mwis_cit_wrap|set"]
+    assert float(tot[0]) == float(z["gdpg|0|g01|solve_mwis_cit_wrap|total"]) and sorted(sol) != ref_set.tolist()
+    assert abs(float(w[ref_set].sum()) - float(tot[0])) > 0.1
+
+
+def test_reference_execution_is_reproducible_when_available(ref_exec):
+    """In the build container only: run the reference through the stand-in again for one configuration and compare
+    with the committed vectors (guards the generator, oracle/run_reference.py)."""
+    import os
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle import run_reference
+    m, fl = ref_exec.dqn[1]
+    res = run_reference.run_worker("dqn", [m], fl)
+    for k, v in res.items():
+        assert np.array_equal(v, ref_exec.z["dqn|%s|%s" % (m, k)]), k
