@@ -210,11 +210,17 @@ class MWISSolver(object):
             best = np.dot(nIS_vec, wts)
         return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
-    def _rollout(self, which, adj_0, wts_0, b=16, rng=None):
+    def _rollout(self, which, adj_0, wts_0, b=16, rng=None, reference_ties=False):
         """The four rollout searches of the reference share one loop; ``ROLLOUT_VARIANTS[which]`` says
-        whether the GCN is re-run on every residual graph and what orders the greedy completions."""
+        whether the GCN is re-run on every residual graph and what orders the greedy completions.
+        ``reference_ties=True`` (host-controlled path, needs ``rng`` with ``choice``, e.g. a seeded ``numpy.random``)
+        breaks ties exactly as the reference does: candidate totals summed in ITS order - ``np.sum`` over the CPython
+        set the completion was collected in - compared with ``==`` and drawn with one ``rng.choice`` per step, NumPy's
+        default argsort for the candidates; with the same seed the reference's own result comes back."""
         import torch
         rescore, by_prio = ROLLOUT_VARIANTS[which]
+        if reference_ties and rng is None:
+            raise ValueError("reference_ties needs rng (the reference draws np.random.choice at every step)")
         if rng is None and self.device_iterative:
             dev = self.solve_iterative_batch([adj_0], [wts_0], which, b=b)
             if dev is not None:
@@ -239,7 +245,7 @@ class MWISSolver(object):
                 db = eng.upload(hb)
                 act_vals = full_scores.flatten()[rmap]
             gcn_wts = act_vals * wts_nn.flatten() if self.flags.predict == "mwis" else act_vals.astype(np.float64)
-            children = np.argsort(-gcn_wts, kind="stable")[0:b]
+            children = (np.argsort(-gcn_wts) if reference_ties else np.argsort(-gcn_wts, kind="stable"))[0:b]
             cand = wts_nn[children].copy()
             if len(cand) > 1:
                 init = np.zeros((len(children), n), dtype=np.uint8)
@@ -250,10 +256,29 @@ class MWISSolver(object):
                 ro = eng.lgs_masked(db, prio, torch.from_numpy(init).to(eng.device), len(children),
                                     sum_weights=db.weights)
                 eng.check_status(ro["status"])
-                cand[:, 0] += ro["totals"].cpu().numpy()[:, 0]
-            # candidates that complete to the same set tie mathematically but not bit for bit (the sums run
-            # in different orders): totals within 1e-12 relative count as tied
-            ties = np.flatnonzero(np.isclose(cand, cand.max(), rtol=1e-12, atol=0.0))
+                if reference_ties:
+                    # the reference's float: np.sum(wts_ro[list(ps)]) with ps the Python set greedy_search filled in
+                    # pick order (descending completion priority), indices in the re-sliced (adj_ro) numbering
+                    st = ro["state"].cpu().numpy()
+                    order_key = gcn_wts if by_prio else wts_nn[:, 0]
+                    for i in range(len(children)):
+                        keep = init[i] == 0
+                        renum = np.cumsum(keep) - 1
+                        members = np.flatnonzero(st[i] == 1)
+                        members = members[np.argsort(-order_key[members], kind="stable")]
+                        ps = set()
+                        for v in renum[members]:
+                            ps.add(v)
+                        wts_ro = wts_nn[keep]
+                        cand[i, 0] += np.sum(wts_ro[list(ps)]) if (by_prio or not rescore) else np.sum(wts_ro[:, 0][list(ps)])
+                else:
+                    cand[:, 0] += ro["totals"].cpu().numpy()[:, 0]
+            if reference_ties:
+                ties = np.flatnonzero(cand == cand.max())
+            else:
+                # candidates that complete to the same set tie mathematically but not bit for bit (the sums run
+                # in different orders): totals within 1e-12 relative count as tied
+                ties = np.flatnonzero(np.isclose(cand, cand.max(), rtol=1e-12, atol=0.0))
             i_best = int(rng.choice(ties)) if rng is not None else int(ties[0])
             pick = int(children[i_best])
             nb_v = adj_nn.indices[adj_nn.indptr[pick]:adj_nn.indptr[pick + 1]]
@@ -262,26 +287,26 @@ class MWISSolver(object):
             best = np.dot(nIS_vec, wts)
         return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
-    def solve_mwis_rollout(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+    def solve_mwis_rollout(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None, reference_ties=False):
         """Top-``b`` GCN candidates, each scored by its weight plus a greedy completion (by weight) of what is
         left; the GCN is re-run on every residual graph (``mwis_gdpg_call.py:596-659``).  On the device the
         whole step is one launch; on the host-re-slicing path the ``b`` completions are ONE launch of the
         masked greedy kernel.  The reference breaks score ties with ``np.random.choice`` (unseeded) and ranks
         with an unstable sort: here ties go to the first candidate / lower index unless ``rng`` (a
         ``numpy.random.Generator``) is given."""
-        return self._rollout("rollout", adj_0, wts_0, b=b, rng=rng)
+        return self._rollout("rollout", adj_0, wts_0, b=b, rng=rng, reference_ties=reference_ties)
 
-    def solve_mwis_rollout00(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+    def solve_mwis_rollout00(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None, reference_ties=False):
         """``mwis_gdpg_call.py:413-472``: the GCN runs ONCE on the full graph; completions by weight."""
-        return self._rollout("rollout00", adj_0, wts_0, b=b, rng=rng)
+        return self._rollout("rollout00", adj_0, wts_0, b=b, rng=rng, reference_ties=reference_ties)
 
-    def solve_mwis_rollout0(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+    def solve_mwis_rollout0(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None, reference_ties=False):
         """``:474-533``: GCN once; completions ordered by the GCN priority, valued by weight."""
-        return self._rollout("rollout0", adj_0, wts_0, b=b, rng=rng)
+        return self._rollout("rollout0", adj_0, wts_0, b=b, rng=rng, reference_ties=reference_ties)
 
-    def solve_mwis_rollout1(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None):
+    def solve_mwis_rollout1(self, adj_0, wts_0, train=False, grd=1.0, b=16, rng=None, reference_ties=False):
         """``:535-594``: GCN on every residual graph; completions ordered by the GCN priority."""
-        return self._rollout("rollout1", adj_0, wts_0, b=b, rng=rng)
+        return self._rollout("rollout1", adj_0, wts_0, b=b, rng=rng, reference_ties=reference_ties)
 
     # ---- thin inference helpers of the reference class ------------------------------------------------
     @staticmethod

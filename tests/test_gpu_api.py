@@ -859,6 +859,12 @@ def test_against_the_executed_reference_gdpg_solvers(engine, golden):
                 ref_set = z["gdpg|%d|g%02d|%s|set" % (ci, gi, name)].tolist()
                 det, _ = orc.solve_mwis_rollout(fn, adj, w, b=8, predict=fl["predict"], **kw)  # first-candidate tie rule
                 assert sorted(got) == sorted(det), (ci, gi, name)
+                # and with the reference's own tie handling (exact ==, its summation order, np.random.choice
+                # replayed from the seed oracle/run_reference.py used): the reference's set and total
+                np.random.seed(1234)
+                got_r, tot_r = getattr(agent, name)(adj, w, b=8, rng=np.random, reference_ties=True)
                 total += 1
-                agree += sorted(got) == ref_set
-    assert agree >= total * 2 // 3, (agree, total)
+                agree += sorted(got_r) == ref_set and float(np.asarray(tot_r).ravel()[0]) == pytest.approx(
+                    float(z["gdpg|%d|g%02d|%s|total" % (ci, gi, name)]), rel=1e-12)
+    # (a float32 score ordering flip between the kernels and NumPy could legitimately change a candidate list)
+    assert agree >= total - 2, (agree, total)
