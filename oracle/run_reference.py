@@ -155,6 +155,58 @@ def worker_gdpg(out_path):
     np.savez_compressed(out_path, **out)
 
 
+def worker_test_loop(out_path):
+    """The reference's evaluation script itself, mwis_dqn_test.py:304-348 (A12): run with runpy from a scratch
+    directory holding ./model -> the reference's model/ and ./data/<folder> -> symlinks to the 50 .mat files of
+    tests/golden/dataset100.npz, so that the reference tree is never written to.  Collects the ./output/*.csv it writes."""
+    prepare_reference_imports()
+    import contextlib, io, runpy
+    import pandas as pd
+    if not hasattr(pd.DataFrame, "append"):  # pandas < 2 spelling used at mwis_dqn_test.py:340
+        pd.DataFrame.append = lambda self, other, ignore_index=False: pd.concat([self, pd.DataFrame([other])], ignore_index=ignore_index)
+    import scipy.io as sio
+    _loadmat = sio.loadmat
+
+    def loadmat_csc(*a, **k):  # SciPy of the reference's time handed sparse variables out as csc_matrix, not COO
+        m = _loadmat(*a, **k)
+        return {key: (sp.csc_matrix(v) if sp.issparse(v) else v) for key, v in m.items()}
+    sio.loadmat = loadmat_csc
+    np.random.seed(20230601)  # the script draws np.random.permutation and, per graph, one np.random.rand() (epsilon branch)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        runpy.run_path(os.path.join(REF, "mwis_dqn_test.py"), run_name="__main__")
+    csvs = [f for f in os.listdir("output") if f.endswith(".csv")]
+    df = pd.read_csv(os.path.join("output", csvs[0]))
+    fired = sum(1 for ln in buf.getvalue().splitlines() if "Ratio" in ln)
+    np.savez_compressed(out_path, data=np.array([str(x) for x in df["data"]]), p=df["p"].to_numpy(dtype=np.float64),
+                        printed=np.int64(fired))
+
+
+TEST_LOOP = [("IS4SAT", 1), ("IS4SAT", 20), ("DQNBA", 1), ("DQNBA", 20)]  # bash/generalization_dqn_test.sh:20-33
+
+
+def run_test_loop(training_set, num_layer, family):
+    """-> {file name: p} of the reference's own mwis_dqn_test.py on dataset100's graphs of one family."""
+    names = [str(n) for n in np.load(os.path.join(ROOT, "tests", "golden", "dataset100.npz"))["names"] if str(n).startswith(family + "/")]
+    folder = "%s_Graph_Uniform_GEN21_test2" % family
+    with tempfile.TemporaryDirectory() as d:
+        os.symlink(os.path.join(REF, "model"), os.path.join(d, "model"))
+        os.makedirs(os.path.join(d, "data", folder))
+        os.makedirs(os.path.join(d, "output"))
+        for n in names:
+            os.symlink(os.path.join(REF, "data", folder, n.split("/", 1)[1]), os.path.join(d, "data", folder, n.split("/", 1)[1]))
+        path = os.path.join(d, "o.npz")
+        flags = ["--training_set=%s" % training_set, "--epsilon=.0002", "--feature_size=1", "--diver_num=1",
+                 "--datapath=./data/%s" % folder, "--max_degree=1", "--predict=mwis", "--learning_rate=0.00001", "--hidden1=32",
+                 "--num_layer=%d" % num_layer, "--epochs=10"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "test_loop", path] + flags
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
+        if r.returncode != 0:
+            raise RuntimeError("reference mwis_dqn_test.py failed:\n%s" % r.stderr[-4000:])
+        z = np.load(path)
+        return {family + "/" + str(k): float(v) for k, v in zip(z["data"], z["p"])}
+
+
 # ---------------------------------------------------------------------------------------------- driver
 def run_worker(kind, extra, flags):
     with tempfile.TemporaryDirectory() as d:
@@ -175,6 +227,9 @@ def main():
             model_dir = rest[0]
             sys.argv = [sys.argv[0]] + rest[1:]
             worker_dqn(model_dir, path)
+        elif kind == "test_loop":
+            sys.argv = [sys.argv[0]] + rest
+            worker_test_loop(path)
         else:
             sys.argv = [sys.argv[0]] + rest
             worker_gdpg(path)
@@ -191,6 +246,13 @@ def main():
         for k, v in res.items():
             out["gdpg|%d|%s" % (ci, k)] = v
         print("gdpg config %d %s ok (%d arrays)" % (ci, flags, len(res)))
+    names = [str(n) for n in np.load(os.path.join(ROOT, "tests", "golden", "dataset100.npz"))["names"]]
+    for ts, nl in TEST_LOOP:
+        p = {}
+        for fam in ("ER", "BA"):
+            p.update(run_test_loop(ts, nl, fam))
+        out["test_loop|%s|l%d" % (ts, nl)] = np.array([p[n] for n in names], dtype=np.float64)
+        print("mwis_dqn_test.py %s l=%d: mean p = %.6f over %d graphs" % (ts, nl, float(np.mean(list(p.values()))), len(p)))
     np.savez_compressed(OUT, **out)
     print("%s: %d arrays, %d bytes" % (OUT, len(out), os.path.getsize(OUT)))
 

@@ -742,6 +742,31 @@ def test_known_answers_of_100_shipped_graphs_on_gpu(engine, dataset100, all_mode
         assert 0.75 < p.min() and p.max() < 1.5
 
 
+def test_test_loop_against_the_executed_reference(engine, dataset100, all_models):
+    """A12 against the reference's own run of mwis_dqn_test.py (tests/golden/ref_exec.npz test_loop|*): harness.evaluate on
+    the same 100 shipped graphs with the same four checkpoints gives the reference's ratio column (float32 reorderings
+    may flip at most a couple of near-ties per model)."""
+    import scipy.sparse as sp
+    from distgcn_amd import harness
+    from distgcn_amd.mwis_dqn_call import DQNAgent
+    z = _ref_exec()[0]
+    adjs, wts = [], []
+    for i in range(dataset100.n):
+        p, c, w = dataset100.csr(i)
+        adjs.append(sp.csr_matrix((np.ones(c.size), c, p), shape=(w.size, w.size)))
+        wts.append(w)
+    gu = [float(x) for x in dataset100.z["greedy_utility"]]
+    for ts, nl in (("IS4SAT", 1), ("IS4SAT", 20), ("DQNBA", 1), ("DQNBA", 20)):
+        name = "result_%s_deep_ld1_c32_l%d_cheb1_diver1_mwis_dqn" % (ts, nl)
+        agent = DQNAgent(1, flags=_flags(num_layer=nl))
+        agent.model.set_params(all_models.params(name))
+        rows = harness.evaluate(agent, adjs, wts, gu)
+        p = np.array([r["p"] for r in rows])
+        ref = z["test_loop|%s|l%d" % (ts, nl)]
+        assert np.sum(~np.isclose(p, ref, rtol=1e-9)) <= 2, (name, int(np.sum(~np.isclose(p, ref, rtol=1e-9))))
+        assert abs(p.mean() - ref.mean()) < 2e-3
+
+
 def _solve(engine, db, dm):
     out = engine.solve_buffers(db, False)
     engine.solve_fused(db, dm, want_scores=False, out=out)

@@ -351,6 +351,18 @@ def test_restatement_equals_executed_reference_gdpg_solvers(golden, ref_exec):
     assert abs(float(w[ref_set].sum()) - float(tot[0])) > 0.1
 
 
+def test_reference_test_loop_ratios(dataset100, ref_exec):
+    """The reference's own evaluation script (mwis_dqn_test.py:304-348, executed by oracle/run_reference.py on the 100
+    shipped graphs of dataset100.npz for the four checkpoints of bash/generalization_dqn_test.sh): its per-graph ratios
+    p = total / greedy_utility equal the restatement-derived ratios stored with the dataset."""
+    z = ref_exec.z
+    for ts, nl in (("IS4SAT", 1), ("IS4SAT", 20), ("DQNBA", 1), ("DQNBA", 20)):
+        ref = z["test_loop|%s|l%d" % (ts, nl)]
+        mine = dataset100.z["ratio|result_%s_deep_ld1_c32_l%d_cheb1_diver1_mwis_dqn" % (ts, nl)]
+        assert ref.shape == (100,) and np.allclose(ref, mine, rtol=1e-12, atol=0), (ts, nl)
+        assert 1.0 < ref.mean() < 1.2
+
+
 def test_reference_execution_is_reproducible_when_available(ref_exec):
     """In the build container only: run the reference through the stand-in again for one configuration and compare
     with the committed vectors (guards the generator, oracle/run_reference.py)."""
