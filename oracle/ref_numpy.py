@@ -502,3 +502,20 @@ def solve_wrap(inner, scores_fn, adj_0, wts_0, reference_mapping=False, **kw):
         total = total + util
         chosen |= set(int(comp[i]) for i in sub)
     return chosen, total
+
+
+def margin_risk(indptr, indices, prio, state, delta, wabs=None):
+    """SURVEY 7.3(c), checker for dgcn_margin_risk_batch: the number of excluded vertices (state 2) without a member
+    neighbour u (state 1) whose priority leads by more than delta * (|w_u| + |w_v|).  The local greedy search
+    (heuristics.py:77-116) returns the unique independent set in which every excluded vertex has a member neighbour
+    ahead of it in (priority desc, index asc); zero risky vertices means no score error up to ``delta`` changes it."""
+    prio = np.asarray(prio, dtype=np.float64)
+    wabs = np.ones_like(prio) if wabs is None else np.abs(np.asarray(wabs, dtype=np.float64))
+    state = np.asarray(state)
+    risky = 0
+    for v in np.flatnonzero(state == 2):
+        nb = indices[indptr[v]:indptr[v + 1]]
+        nb = nb[state[nb] == 1]
+        if not np.any(prio[nb] - prio[v] > delta * (wabs[nb] + wabs[v])):
+            risky += 1
+    return risky
