@@ -17,6 +17,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _lib
 from .batch import HostBatch
 
 
@@ -83,6 +84,52 @@ def solve_sharded(hb: HostBatch, solve_fn: Callable[[HostBatch], Dict[str, np.nd
         totals[a:b] = allb[r, :g * 8].view(np.float64)
         rounds[a:b] = allb[r, cap_graphs * 8:cap_graphs * 8 + g * 4].view(np.int32)
         state[n0:n1] = allb[r, cap_graphs * 12:cap_graphs * 12 + (n1 - n0)]
+    return {"state": state, "totals": totals, "rounds": rounds}
+
+
+def solve_sharded_device(engine, model, hb: HostBatch, predict: str = "mwis", group=None) -> Dict[str, np.ndarray]:
+    """``solve_sharded`` for the HIP engine without the host round trip: every rank uploads its shard, runs the ONE
+    fused launch into a packed result buffer laid out for the largest shard (``Engine.solve_buffers(cap_*)``), the ranks
+    exchange those buffers with ONE ``all_gather_into_tensor`` on the device (RCCL over xGMI), and a single
+    device-to-host copy brings the whole batch's membership / totals / rounds home.  Every rank calls this with the
+    SAME full host batch; shapes outside the fused kernel raise (use ``solve_sharded`` with the layered path)."""
+    import torch
+    import torch.distributed as dist
+    from .engine import packed_layout, solve_buffer_specs, _NP
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ranges = shard_ranges(hb, world)
+    lo, hi = ranges[rank]
+    sub = hb.subset(lo, hi)
+    cap_nodes = max(max(int(hb.graph_ptr[b] - hb.graph_ptr[a]) for a, b in ranges), 1)
+    cap_graphs = max(max(b - a for a, b in ranges), 1)
+    db = engine.upload(sub)
+    dm = model if hasattr(model, "c") else model.device_model(engine)
+    out = engine.solve_buffers(db, want_scores=False, cap_nodes=cap_nodes, cap_graphs=cap_graphs)
+    if sub.num_nodes:
+        if not engine.solve_supported(db, dm):
+            raise _lib.DgcnError("solve_sharded_device: this model / batch shape is outside the fused kernel")
+        engine.solve_fused(db, dm, predict=predict, want_scores=False, out=out)
+    flat = out["flat"]
+    if world > 1:
+        recv = torch.empty(world * flat.numel(), dtype=torch.uint8, device=flat.device)
+        dist.all_gather_into_tensor(recv, flat, group=group)  # the ONE collective of the batch
+    else:
+        recv = flat
+    allb = recv.cpu().numpy().reshape(world, -1)
+    lay = out["layout"]
+    state = np.empty(hb.num_nodes, np.uint8)
+    totals = np.empty(hb.num_graphs, np.float64)
+    rounds = np.empty(hb.num_graphs, np.int32)
+    bits = 0
+    view = lambda r, name: allb[r, lay[name][0]:lay[name][0] + lay[name][1]].view(_NP[lay[name][2]])
+    for r, (a, b) in enumerate(ranges):
+        n0, n1 = int(hb.graph_ptr[a]), int(hb.graph_ptr[b])
+        state[n0:n1] = view(r, "state")[:n1 - n0]
+        totals[a:b] = view(r, "totals")[:b - a]
+        rounds[a:b] = view(r, "rounds")[:b - a]
+        bits |= int(view(r, "status")[0])
+    engine.check_status_bits(bits)
     return {"state": state, "totals": totals, "rounds": rounds}
 
 

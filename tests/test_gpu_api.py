@@ -893,3 +893,47 @@ def test_against_the_executed_reference_gdpg_solvers(engine, golden):
                     float(z["gdpg|%d|g%02d|%s|total" % (ci, gi, name)]), rel=1e-12)
     # (a float32 score ordering flip between the kernels and NumPy could legitimately change a candidate list)
     assert agree >= total - 2, (agree, total)
+
+
+def test_c4_full_batch_and_its_eight_shards(engine, golden):
+    """BASELINE config 4 at full size on ONE GPU: the 4 000-graph BA test2 batch with the trained DQNBA l=20 weights.
+    Independence + maximality on all 4 000 sets; scores / sets bit-equal to the twin on every 10th graph; and the eight
+    shards `parallel.shard_ranges` would hand to eight ranks, each solved as its own batch, reassemble to exactly the
+    single-batch result (graphs are independent: sharding must not change a bit).  The device-resident sharded solve
+    (`solve_sharded_device`, one rank here) returns the same."""
+    from distgcn_amd import datagen, parallel
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = datagen.ba_test2_batch(4000)
+    layers = golden.layers("result_DQNBA_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn")
+    dm = DeviceModel(layers, engine.device)
+    db = engine.upload(hb)
+    res = engine.solve_fused(db, dm)
+    engine.check_status(res["status"])
+    state, totals, rounds = res["state"].cpu().numpy(), res["totals"].cpu().numpy(), res["rounds"].cpu().numpy()
+    scores = res["scores"].cpu().numpy()
+    import scipy.sparse as sp
+    adj = sp.csr_matrix((np.ones(hb.col_idx.size, np.float32), hb.col_idx, hb.row_ptr), shape=(hb.num_nodes, hb.num_nodes))
+    sel = (state == 1).astype(np.float32)
+    hits = adj @ sel
+    assert not np.any((hits > 0) & (state == 1)) and np.all((hits > 0) | (state == 1)) and not np.any(state == 0)
+    sample = hb.select(range(0, 4000, 10))
+    ref = ctwin.solve(sample, layers)
+    k = 0
+    for g in range(0, 4000, 10):
+        n0, n1 = int(hb.graph_ptr[g]), int(hb.graph_ptr[g + 1])
+        m = n1 - n0
+        assert np.array_equal(state[n0:n1], ref["state"][k:k + m]) and rounds[g] == ref["rounds"][g // 10]
+        assert np.array_equal(scores[n0:n1, 0].view(np.uint32), ref["scores"][k:k + m, 0].view(np.uint32))
+        k += m
+    ranges = parallel.shard_ranges(hb, 8)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 4000 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    cost = [int(hb.row_ptr[hb.graph_ptr[b]] - hb.row_ptr[hb.graph_ptr[a]] + hb.graph_ptr[b] - hb.graph_ptr[a]) for a, b in ranges]
+    assert max(cost) <= 1.05 * (sum(cost) / 8)  # balanced on sum(nnz + N)
+    for a, b in ranges:
+        sub = hb.subset(a, b)
+        r = engine.solve_fused(engine.upload(sub), dm)
+        n0, n1 = int(hb.graph_ptr[a]), int(hb.graph_ptr[b])
+        assert np.array_equal(r["state"].cpu().numpy(), state[n0:n1]) and np.array_equal(r["totals"].cpu().numpy(), totals[a:b])
+    one = parallel.solve_sharded_device(engine, dm, hb)
+    assert np.array_equal(one["state"], state) and np.array_equal(one["totals"], totals) and np.array_equal(one["rounds"], rounds)
