@@ -568,11 +568,11 @@ def main(argv=None, workload_factory=None):
     roofline, kernel_us, traffic_db = roofline_objects(args, wl, fam_ms)
 
     spmm_line = None
-    if rank == 0 and not args.no_spmm_probe and isinstance(wl, GpuWorkload):
+    if rank == 0 and world == 1 and not args.no_spmm_probe and isinstance(wl, GpuWorkload):  # N = 1 line only: ranks must not wait on it
         spmm_line = spmm_probe(args, wl, traffic_db)
 
     margin = None
-    if rank == 0 and isinstance(wl, GpuWorkload) and wl.ring is not None:
+    if rank == 0 and world == 1 and isinstance(wl, GpuWorkload) and wl.ring is not None:
         margin = margin_probe(wl)
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e and isinstance(wl, GpuWorkload) and wl.ring is not None:
