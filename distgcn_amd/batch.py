@@ -137,7 +137,7 @@ class HostBatch:
             w = None if weights is None else [x if (isinstance(x, np.ndarray) and x.ndim == 1) else np.ascontiguousarray(x, dtype=np.float64).ravel()
                                               for x in weights]
             return HostBatch.from_packed(*pack_csr_lists(indptrs, indices, w, staging=staging, alloc=alloc))
-        except TypeError:
+        except (TypeError, BufferError):  # mixed index widths, non-contiguous or non-array inputs: the NumPy packer takes those
             pass
         B = len(indptrs)
         sizes = np.fromiter((p.size - 1 for p in indptrs), dtype=np.int64, count=B)

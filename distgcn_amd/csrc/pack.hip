@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "common.h"
 
 namespace dgcn {
@@ -25,13 +27,17 @@ namespace dgcn {
 class Pool {
 public:
     static Pool& get() {
-        static Pool p;
-        return p;
+        static Pool* p = new Pool;  // never destroyed: its (detached) workers may outlive static destruction
+        return *p;
     }
     // run fn(part) for part in [0, parts) on up to `parts` threads (the caller takes part 0)
     void run(int parts, const std::function<void(int)>& fn) {
         if (parts <= 1) { fn(0); return; }
         std::unique_lock<std::mutex> call_lock(call_mu_);  // one parallel region at a time
+        if (getpid() != pid_) {  // forked child: the parent's worker threads do not exist here
+            pid_ = getpid();
+            nworkers_ = 0;
+        }
         ensure(parts - 1);
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -49,17 +55,12 @@ public:
     }
 
 private:
-    Pool() = default;
-    ~Pool() {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
+    Pool() : pid_(getpid()) {}
     void ensure(int n) {
-        while ((int)workers_.size() < n) workers_.emplace_back([this] { loop(); });
+        while (nworkers_ < n) {
+            std::thread([this] { loop(); }).detach();
+            ++nworkers_;
+        }
     }
     void loop() {
         unsigned long seen = 0;
@@ -83,7 +84,8 @@ private:
     }
     std::mutex call_mu_, mu_;
     std::condition_variable cv_, done_cv_;
-    std::vector<std::thread> workers_;
+    int nworkers_ = 0;
+    pid_t pid_;
     const std::function<void(int)>* fn_ = nullptr;
     int parts_ = 0, next_ = 0, pending_ = 0;
     unsigned long epoch_ = 0;

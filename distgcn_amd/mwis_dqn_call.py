@@ -143,7 +143,7 @@ def solve_csr_lists(eng, model, indptrs, indices, weights, predict: str = "mwis"
         slot = pipe._next_slot()
         try:
             info = pipe._pack(slot, indptrs, indices, w64)
-        except TypeError:  # mixed index widths / non-contiguous arrays: the NumPy packer handles those
+        except (TypeError, BufferError):  # mixed index widths / non-contiguous arrays: the NumPy packer handles those
             info = None
         if info is not None:
             hb = HostBatch.from_packed(slot.staging_np, info)

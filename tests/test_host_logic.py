@@ -234,3 +234,29 @@ def test_native_pack_rejects_malformed_input():
         pack_csr_lists([i32(0, 1, 2)], [i32(1, 0)], [np.ones(2)], staging=np.empty(8, np.uint8))
     empty = HostBatch.from_csr_lists([], [], [])
     assert empty.num_graphs == 0 and empty.num_nodes == 0 and empty.graph_ptr.tolist() == [0]
+
+
+def test_native_pack_survives_fork():
+    """The packer's worker threads do not exist in a forked child: it must start its own instead of waiting for them."""
+    import os
+    from distgcn_amd.batch import HostBatch
+    ps, cs, ws = _random_csr_lists(np.random.default_rng(9), 900, np.int32)
+    want = HostBatch.from_csr_lists(ps, cs, ws)  # parent: several workers started
+    pid = os.fork()
+    if pid == 0:
+        ok = 1
+        try:
+            got = HostBatch.from_csr_lists(ps, cs, ws)
+            ok = 0 if (np.array_equal(got.col_idx, want.col_idx) and np.array_equal(got.row_ptr, want.row_ptr)) else 2
+        finally:
+            os._exit(ok)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+            return
+        time.sleep(0.05)
+    os.kill(pid, 9)
+    raise AssertionError("forked child hung in dgcn_pack_batch")
