@@ -351,6 +351,17 @@ class MWISSolver(object):
         ncomp, labels = csg.connected_components(adj_0, directed=False)
         total = np.array([0.0])
         chosen = set()
+        which = {"solve_mwis_cit": "cit", "solve_mwis_rollout": "rollout"}.get(getattr(inner, "__name__", ""))
+        if which and self.device_iterative and kw.get("rng") is None and not kw.get("reference_ties"):
+            # all components advance together: they are the graphs of ONE device batch, one launch per solver step
+            comps = [np.flatnonzero(labels == c) for c in range(ncomp)]
+            dev = self.solve_iterative_batch([adj_0[c, :][:, c] for c in comps], [wts[c, :] for c in comps], which,
+                                             b=kw.get("b", 16))
+            if dev is not None:
+                for comp, (sub, util) in zip(comps, dev):
+                    total = total + util
+                    chosen |= set(int(comp[i]) for i in sub)
+                return chosen, total
         for c in range(ncomp):
             comp = np.flatnonzero(labels == c)
             sub, util = inner(adj_0[comp, :][:, comp], wts[comp, :], **kw)

@@ -7,7 +7,9 @@ slot's arrivals, per-link weights are built from queue lengths and link rates (`
 links drain ``min(queue, rate)`` packets (``:285-293``).  One solver call per slot per instance there; here one
 launch per slot for ALL instances: queues, weights, schedule and departures stay on the device.
 
-Solvers (``algo``): ``"Greedy"`` = ``local_greedy_search`` on the raw weights (``:236-238``); ``"DGCN-LGS"`` =
+Solvers (``algo``): ``"DGCN-LGS-it"`` = ``solve_mwis_dit`` (``:251-254``) and ``"DGCN-RS"`` = ``solve_mwis_rollout_wrap``
+(``:256-260``) of ``mwis_gdpg_call.DQNAgent``, every instance (connected component) advanced by the same launches;
+``"Greedy"`` = ``local_greedy_search`` on the raw weights (``:236-238``); ``"DGCN-LGS"`` =
 ``mwis_dqn_call.DQNAgent.solve_mwis`` (``:271-283``), i.e. zero-weight links are dropped from the conflict graph
 before the GCN runs (``mwis_dqn_call.py:202-207``) - a mask of the residual-graph kernel
 (``dgcn_solve_residual_batch``) instead of a re-sliced matrix.  The Gurobi denominators (``mlp_gurobi``) and the
@@ -66,30 +68,46 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
     [T, nflows], "total_wt": [T], "scheduled": [T]}`` (queue lengths AFTER the slot's departures, as the
     reference's ``queue_mtx_dict``)."""
     import torch
-    if algo not in ("Greedy", "DGCN-LGS"):
-        raise ValueError("algo must be 'Greedy' or 'DGCN-LGS'")
-    if algo == "DGCN-LGS" and agent is None:
-        raise ValueError("DGCN-LGS needs an agent (mwis_dqn_call.DQNAgent)")
+    if algo not in ("Greedy", "DGCN-LGS", "DGCN-LGS-it", "DGCN-RS"):
+        raise ValueError("algo must be 'Greedy', 'DGCN-LGS', 'DGCN-LGS-it' or 'DGCN-RS'")
+    if algo != "Greedy" and agent is None:
+        raise ValueError("%s needs an agent (mwis_dqn_call.DQNAgent / mwis_gdpg_call.DQNAgent)" % algo)
     eng = get_engine()
     t = torch
     csrs = [as_csr(a) for a in adjs]
+    if algo == "DGCN-RS":
+        # solve_mwis_rollout_wrap (wireless_dqn_test.py:256-260) searches every connected component on its own
+        # (mwis_gdpg_call.py:386-411).  The conflict graphs do not change from slot to slot, so the components are cut
+        # once and become the graphs of the device batch; vertices are renumbered component by component.
+        import scipy.sparse.csgraph as csg
+        comp_csrs, order = [], []
+        for c in csrs:
+            ncomp, labels = csg.connected_components(c, directed=False)
+            ids = np.argsort(labels, kind="stable")  # ascending vertex order inside every component
+            order.append(ids)
+            bounds = np.concatenate([[0], np.cumsum(np.bincount(labels, minlength=ncomp))])
+            for k in range(ncomp):
+                comp = ids[bounds[k]:bounds[k + 1]]
+                comp_csrs.append(as_csr(c[comp][:, comp]))
+    else:
+        comp_csrs, order = csrs, [np.arange(c.shape[0]) for c in csrs]
     T = int(traffics[0]["arrival_pkts"].shape[0])
     chans = [int(tr["link_rates"].shape[2]) for tr in traffics]  # channels may differ between instances
     flows = [int(tr["arrival_pkts"].shape[1]) for tr in traffics]
     for c, f, k, tr in zip(csrs, flows, chans, traffics):
         if c.shape[0] != f * k or tr["arrival_pkts"].shape[0] != T or tr["link_rates"].shape[:2] != (T, f):
             raise ValueError("conflict graph / traffic shapes disagree")
-    hb = HostBatch.from_csr_lists([c.indptr for c in csrs], [c.indices for c in csrs],
-                                  [np.zeros(c.shape[0]) for c in csrs])
+    hb = HostBatch.from_csr_lists([c.indptr for c in comp_csrs], [c.indices for c in comp_csrs],
+                                  [np.zeros(c.shape[0]) for c in comp_csrs])
     db = eng.upload(hb)
     foff = np.concatenate([[0], np.cumsum(flows)])
-    # vertex -> (global flow, channel, instance); vertex v of instance i is channel v // F_i, flow v % F_i
-    vflow = np.concatenate([foff[i] + np.arange(f * k) % f for i, (f, k) in enumerate(zip(flows, chans))])
-    vch = np.concatenate([np.arange(f * k) // f for f, k in zip(flows, chans)])
+    # batch position -> (global flow, channel, instance); vertex v of instance i is channel v // F_i, flow v % F_i
+    vflow = np.concatenate([foff[i] + order[i] % f for i, (f, k) in enumerate(zip(flows, chans))])
+    vch = np.concatenate([order[i] // f for i, (f, k) in enumerate(zip(flows, chans))])
     vinst = np.concatenate([np.full(f * k, i) for i, (f, k) in enumerate(zip(flows, chans))])
     arr = t.from_numpy(np.concatenate([tr["arrival_pkts"] for tr in traffics], axis=1).astype(np.float64)).to(eng.device)
-    rates = t.from_numpy(np.concatenate([tr["link_rates"].transpose(0, 2, 1).reshape(T, -1) for tr in traffics],
-                                        axis=1).astype(np.float64)).to(eng.device)  # [T, vertices], vertex order
+    rates = t.from_numpy(np.concatenate([tr["link_rates"].transpose(0, 2, 1).reshape(T, -1)[:, order[i]]
+                                         for i, tr in enumerate(traffics)], axis=1).astype(np.float64)).to(eng.device)  # [T, batch positions]
     vflow_d = t.from_numpy(vflow).to(eng.device)
     vinst_d = t.from_numpy(vinst).to(eng.device)
     ch_masks = [t.from_numpy(vch == c).to(eng.device) for c in range(max(chans))]
@@ -99,7 +117,7 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
     dep_out = t.zeros((T, F), dtype=t.float64, device=eng.device)
     tot_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
     cnt_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
-    dm = agent.model.device_model(eng) if algo == "DGCN-LGS" else None
+    dm = agent.model.device_model(eng) if algo != "Greedy" else None
     if dm is not None and not eng.solve_supported(db, dm):
         raise NotImplementedError("conflict graphs / model outside the fused kernel (<= 512 vertices, hidden <= 32)")
     out = eng.solve_buffers(db, False) if dm is not None else None
@@ -112,10 +130,19 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
             res = eng.lgs(db, prio=db.weights, want_totals=False)
             st = res["state"]
             status = res["status"]
-        else:
+        elif algo == "DGCN-LGS":
             state.copy_((w <= 0).to(t.uint8) * 2)  # zero-weight links leave the graph (mwis_dqn_call.py:202-207)
             res = eng.solve_residual(db, dm, state, predict=agent.flags.predict, greedy=eng.GREEDY_ROUNDS, max_rounds=0,
                                      max_steps=1, out=out)
+            st, status = state[:hb.num_nodes], res["status"]
+        else:
+            # 'DGCN-LGS-it' = solve_mwis_dit (wireless_dqn_test.py:251-254): the GCN is re-run on the residual graph
+            # before every greedy round; 'DGCN-RS' = solve_mwis_rollout_wrap (:256-260): top-16 candidates, greedy
+            # completions, per connected component.  Both: one launch per solver step for every instance / component.
+            state.zero_()
+            res = eng.solve_residual(db, dm, state, predict=agent.flags.predict,
+                                     greedy=eng.GREEDY_ROUNDS if algo == "DGCN-LGS-it" else eng.GREEDY_ROLLOUT,
+                                     max_rounds=1, beam=16, weight_features=agent.flags.predict != "mwis", out=out)
             st, status = state[:hb.num_nodes], res["status"]
         sel = st == 1
         cap = t.zeros(F, dtype=t.float64, device=eng.device)

@@ -663,6 +663,51 @@ def test_wireless_simulation_matches_restatement(engine, algo):
     assert set(wireless.summarize(got[0])) == {"avg_queue_len", "50p_queue_len", "95p_queue_len", "5p_queue_len"}
 
 
+@pytest.mark.parametrize("algo", ["DGCN-LGS-it", "DGCN-RS"])
+def test_wireless_simulation_iterative_schedulers(engine, algo):
+    """The slot loop with the reference's iterative schedulers: 'DGCN-LGS-it' = solve_mwis_dit
+    (wireless_dqn_test.py:251-254) and 'DGCN-RS' = solve_mwis_rollout_wrap (:256-260, per connected component), all
+    instances (components) advanced by the same launches, against the per-instance CPU restatement with the oracle's
+    solvers (pinned by the executed reference) fed by the twin's scores."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen, wireless
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc, ref_wireless
+    rng = np.random.default_rng(78)
+    agent = DQNAgent(_flags(num_layer=3), seed=4)
+    for k in agent.model.vars:  # non-zero biases
+        if k.endswith("/bias"):
+            agent.model.vars[k] = rng.uniform(-0.2, 0.2, agent.model.vars[k].shape).astype(np.float32)
+    agent.model._device_model = None
+    fn = _twin_scores_fn(agent.model.layers)
+    adjs, traffics = [], []
+    for i, (nflows, n_ch, p) in enumerate([(30, 1, 0.06), (40, 1, 0.04), (18, 2, 0.08)]):  # sparse: several components
+        indptr, indices = datagen.er_graph(nflows * n_ch, p, rng)
+        adjs.append(sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(nflows * n_ch,) * 2))
+        traffics.append(wireless.make_traffic(nflows, 12, 0.03, n_ch=n_ch, seed=10 + i))
+
+    def dit_fn(adj, w):
+        return orc.solve_mwis_dit(fn, adj, w)[0] if w.size else set()
+
+    def rs_fn(adj, w):
+        return orc.solve_wrap(orc.solve_mwis_rollout, fn, adj, w, b=16)[0] if w.size else set()
+
+    got = wireless.simulate(adjs, traffics, algo=algo, agent=agent, wt_sel="qr")
+    for i in range(len(adjs)):
+        want = ref_wireless.simulate_one(adjs[i], traffics[i]["arrival_pkts"], traffics[i]["link_rates"],
+                                         dit_fn if algo == "DGCN-LGS-it" else rs_fn, "qr")
+        assert np.array_equal(got[i]["queue"], want["queue"]), i
+        assert np.array_equal(got[i]["depart"], want["depart"]), i
+        assert np.allclose(got[i]["total_wt"], want["total_wt"], rtol=1e-12)
+        assert got[i]["depart"].sum() > 0
+    # the per-component wrappers of the agent batch their components into one device call: same result as the oracle
+    adj, w = adjs[1], rng.random(adjs[1].shape[0])
+    for name, inner in (("solve_mwis_cit_wrap", orc.solve_mwis_cit), ("solve_mwis_rollout_wrap", orc.solve_mwis_rollout)):
+        sol, tot = getattr(agent, name)(adj, w)
+        want, wtot = orc.solve_wrap(inner, fn, adj, w)
+        assert sol == want and float(np.asarray(tot).ravel()[0]) == pytest.approx(float(wtot[0]), rel=1e-12), name
+
+
 def _example_inputs():
     """The inputs examples/solve_batch.cpp builds (same 64-bit LCG stream)."""
     from distgcn_amd.batch import HostBatch
