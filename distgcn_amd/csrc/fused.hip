@@ -206,11 +206,11 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 // the cycles): each wave runs a dependent metadata -> address -> ds_read_b128 -> fmaf chain and only four waves
 // per SIMD are there to hide it.  The loop is therefore built for few instructions per entry - one xor forms a
 // gather address, two words / two values come with one LDS read - and eight gathers in flight per trip.
-template <int BLOCK>
-__device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
-                                                 const unsigned* rinfo, const unsigned short* perm,
-                                                 const float* vals, const unsigned short* words, unsigned wmask,
-                                                 int lane_map) {
+template <int BLOCK, int ACT>
+__device__ __forceinline__ void aggregate_rows(const float* bias_ptr, int ng, float* bufA, const float* bufB,
+                                               const unsigned* rinfo, const unsigned short* perm,
+                                               const float* vals, const unsigned short* words, unsigned wmask,
+                                               int lane_map) {
     // wmask: 0xffffffff, except in DGCN_DIAG experiments that redirect every gather to a few rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Which 8 lanes share a row.  A ds_read_b128 is served in four bank groups of 16 lanes,
@@ -222,8 +222,9 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
     const int gw = rho >> 3, q = rho & 7;
     constexpr int kWaves = BLOCK / 64;
     const unsigned qx = (unsigned)q << 4;  // gather address = word ^ qx (the word carries the row's swizzle key)
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (L.bias) bias = *reinterpret_cast<const float4*>(L.bias + 4 * q);
+    // no bias = -0.0f: x + (-0.0f) == x for every x, so the row epilogue needs no branch
+    float4 bias = make_float4(-0.f, -0.f, -0.f, -0.f);
+    if (bias_ptr) bias = *reinterpret_cast<const float4*>(bias_ptr + 4 * q);
     const int blocks = (ng + 7) >> 3;
     for (int k = 0; k * kWaves < blocks; ++k) {
         const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
@@ -286,10 +287,23 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
         float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
         const float4 z = *own;
         float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
-        if (L.bias) { o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w; }
-        o.x = apply_act(o.x, L.act); o.y = apply_act(o.y, L.act); o.z = apply_act(o.z, L.act); o.w = apply_act(o.w, L.act);
+        o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+        o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
         *own = o;
     }
+}
+
+// The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
+template <int BLOCK>
+__device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
+                                                 const unsigned* rinfo, const unsigned short* perm,
+                                                 const float* vals, const unsigned short* words, unsigned wmask,
+                                                 int lane_map) {
+    const float* bias = L.bias;
+    const int act = L.act;
+    if (act == DGCN_ACT_RELU) aggregate_rows<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
+    else aggregate_rows<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would

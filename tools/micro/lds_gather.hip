@@ -28,6 +28,12 @@ __global__ void k(const unsigned* __restrict__ idx, float* out, int iters, int n
             if (MODE == 0 || MODE == 3) {
                 const float4 z = *reinterpret_cast<const float4*>(base + row * 128 + sub * 16);
                 acc0 += z.x; acc1 += z.y; acc2 += z.z; acc3 += z.w;
+            } else if (MODE == 4) {   // metadata-style read: 8 lanes share one 8-byte pair (ds_read_b64, broadcast inside the group)
+                const float2 z = *reinterpret_cast<const float2*>(base + row * 128 + (it & 15) * 8);
+                acc0 += z.x; acc1 += z.y;
+            } else if (MODE == 5) {   // ... and one 4-byte word pair
+                const float z = *reinterpret_cast<const float*>(base + row * 128 + (it & 31) * 4);
+                acc0 += z;
             } else if (MODE == 1) {
                 const float2 z = *reinterpret_cast<const float2*>(base + row * 128 + sub * 8);
                 acc0 += z.x; acc1 += z.y;
@@ -58,7 +64,7 @@ void run(const char* name, unsigned* didx, float* dout, unsigned long long* dcyc
         avg /= blocks;
         const double instr_per_wave = iters * 8.0;
         const double cyc_per_cu_instr = avg / (instr_per_wave * waves);  // CU-level cycles per wave-instruction
-        const double bytes = (MODE == 1 ? 512.0 : (MODE == 2 ? 256.0 : 1024.0));
+        const double bytes = (MODE == 1 || MODE == 4 ? 512.0 : (MODE == 2 || MODE == 5 ? 256.0 : 1024.0));
         printf("%-28s waves/CU %2d: %7.2f cycles per wave-instr per wave, %6.2f CU-cycles per instr, %6.1f B/clk/CU\n", name,
                waves, avg / instr_per_wave, cyc_per_cu_instr, bytes / cyc_per_cu_instr);
     }
@@ -75,5 +81,7 @@ int main() {
     run<1>("b64 x 16 lanes/row random", didx, dout, dcyc);
     run<2>("b32 x 32 lanes/row random", didx, dout, dcyc);
     run<3>("b128 same rows (broadcast)", didx, dout, dcyc);
+    run<4>("b64 one address per 8 lanes", didx, dout, dcyc);
+    run<5>("b32 one address per 8 lanes", didx, dout, dcyc);
     return 0;
 }
