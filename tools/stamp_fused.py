@@ -22,6 +22,14 @@ print("phase clocks of wave 0, microseconds: mean over graphs / max")
 for i, n in enumerate(names):
     print("%-24s %8.2f %8.2f" % (n, s[:, i].mean(), s[:, i].max()))
 print("%-24s %8.2f" % ("sum of means", s[:, :12].mean(axis=0).sum()))
+tot = s[:, :12].sum(axis=1)
+print("per-workgroup total: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f;  first-dispatched half mean %.1f, second half mean %.1f"
+      % (tot.min(), np.percentile(tot, 10), np.median(tot), np.percentile(tot, 90), tot.max(), tot[:256].mean(), tot[256:].mean()))
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(50): eng.solve(db, model, mode=MODE_FUSED)
+ev1.record(); torch.cuda.synchronize()
+print("launch time of this build: %.1f us" % (ev0.elapsed_time(ev1) * 1e3 / 50))
 
 raw = st.cpu().numpy().reshape(-1, 64)
 print("timeline of co-resident workgroups (block b and b + 256 share a CU), microseconds from the first stamp;")
