@@ -54,6 +54,7 @@ struct FusedArgs {
     const int32_t* row_ptr;
     const int32_t* col_idx;
     const float* vals;         // values of the given support CSR; unused when from_adj
+    uint2* grec;               // [num_graphs][meta_cap] entry records {value bits, gather word} for the hidden aggregation
     float* gvals;              // k_fused<*, true>: [num_graphs][meta_cap] entry values kept in global memory
     const double* dinv_table;  // from_adj: float64 d^-1/2 table
     int32_t table_len;
@@ -75,7 +76,7 @@ struct FusedArgs {
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
     int32_t lane_map;   // gather phase: 1 = lanes rotated by 4 inside each 16-lane row (two whole rows per ds_read_b128 bank group)
-    int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS
+    int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS; a 128-byte zero row follows
     // residual-graph variant (k_fused<true>): `state` is in/out, vertices with state != 0 are not part of the graph
     int32_t feature_mode;  // 1: X[v][*] = (float)(w[v] / (max residual w + 1e-9)), computed here
     int32_t greedy_mode;   // 0 local greedy rounds, 1 one centralised step (global best joins), 2 one rollout step
@@ -312,8 +313,15 @@ __device__ __forceinline__ void aggregate_rows(const float* bias_ptr, int ng, fl
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
 template <int BLOCK, int ACT>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, float* bufA, const unsigned* rinfo,
-                                                 const unsigned short* perm, const float* vals,
-                                                 const unsigned short* words) {
+                                                 const unsigned short* perm, const uint2* rec, unsigned zrow,
+                                                 int diag, unsigned long long* st) {
+    (void)diag; (void)st;
+#ifdef DGCN_DIAG
+#define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == BLOCK - 64) st[i] += _t - bt; bt = _t; } while (0)
+    unsigned long long bt = 0;
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     const int cfirst = kq | (((s >> 1) & 1) << 2), csecond = cfirst ^ 4;  // logical chunks of this lane
@@ -329,40 +337,56 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
         const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
         const int slot = blk * 16 + s;
         if (blk >= blocks || slot >= ng) continue;
+#ifdef DGCN_DIAG
+        bt = __builtin_amdgcn_s_memtime();
+#endif
         const int v = perm[slot];
         const unsigned ri = rinfo[v];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-        int j = rs;  // even by construction
+        BSTAMP(0);
+        // Entry metadata comes from GLOBAL memory, not from the LDS: the gather phase is paced by the LDS instruction
+        // stream (an LDS round trip takes ~450 cycles there: 16 waves x 8 ds_read_b128 queued), and the two metadata
+        // reads per trip were a quarter of it.  A lane loads ONE 8-byte record {value, word} per trip - entry j + kq of
+        // its row, 64 distinct addresses per wave - one trip ahead; the four lanes of a row then hand their entries
+        // round with quad-broadcast DPP moves (the row's lanes are a quad).  A row's last 1..3 entries run as one more
+        // trip whose missing entries are neutralised in the owning lane: value -0.0f on the zero row, and
+        // fmaf(-0.0f, +0.0f, acc) == acc for every acc.
+        // (Tried and dropped: issuing the 8 gathers of trip t + 1 before the 16 packed FMAs of trip t - uniform trip count
+        // from the block's first row, ping-pong buffers, no spills: 211.8 us against 205.2 us per C3 launch.)
+        int j = rs;
+        uint2 cur = rec[j + kq];
+#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, false)
+#define DGCN_TRIP(NE)                                                                                          \
+        {                                                                                                      \
+            float4 zA[NE], zB[NE];                                                                             \
+            float av[NE];                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                   \
+                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(cur.y, 0) : e == 1 ? DGCN_QB(cur.y, 1)          \
+                                              : e == 2 ? DGCN_QB(cur.y, 2) : DGCN_QB(cur.y, 3));               \
+                av[e] = __int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)                 \
+                                       : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));                      \
+                zA[e] = lds_chunk(w ^ cA);                                                                     \
+                zB[e] = lds_chunk(w ^ cB);                                                                     \
+            }                                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                   \
+                accA = fma4(av[e], zA[e], accA);                                                               \
+                accB = fma4(av[e], zB[e], accB);                                                               \
+            }                                                                                                  \
+        }
         for (; j + 4 <= re; j += 4) {
-            const unsigned w01 = *reinterpret_cast<const unsigned*>(words + j);
-            const unsigned w23 = *reinterpret_cast<const unsigned*>(words + j + 2);
-            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float2 a23 = *reinterpret_cast<const float2*>(vals + j + 2);
-            const float4 zA0 = lds_chunk((w01 & 0xffffu) ^ cA), zB0 = lds_chunk((w01 & 0xffffu) ^ cB);
-            const float4 zA1 = lds_chunk((w01 >> 16) ^ cA), zB1 = lds_chunk((w01 >> 16) ^ cB);
-            const float4 zA2 = lds_chunk((w23 & 0xffffu) ^ cA), zB2 = lds_chunk((w23 & 0xffffu) ^ cB);
-            const float4 zA3 = lds_chunk((w23 >> 16) ^ cA), zB3 = lds_chunk((w23 >> 16) ^ cB);
-            accA = fma4(a01.x, zA0, accA); accB = fma4(a01.x, zB0, accB);
-            accA = fma4(a01.y, zA1, accA); accB = fma4(a01.y, zB1, accB);
-            accA = fma4(a23.x, zA2, accA); accB = fma4(a23.x, zB2, accB);
-            accA = fma4(a23.y, zA3, accA); accB = fma4(a23.y, zB3, accB);
+            const uint2 nxt = rec[j + 4 + kq];  // may be the next row's entry or slack: neutralised below if so
+            DGCN_TRIP(4)
+            cur = nxt;
         }
-        if (j + 2 <= re) {
-            const unsigned w01 = *reinterpret_cast<const unsigned*>(words + j);
-            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float4 zA0 = lds_chunk((w01 & 0xffffu) ^ cA), zB0 = lds_chunk((w01 & 0xffffu) ^ cB);
-            const float4 zA1 = lds_chunk((w01 >> 16) ^ cA), zB1 = lds_chunk((w01 >> 16) ^ cB);
-            accA = fma4(a01.x, zA0, accA); accB = fma4(a01.x, zB0, accB);
-            accA = fma4(a01.y, zA1, accA); accB = fma4(a01.y, zB1, accB);
-            j += 2;
-        }
+        BSTAMP(1);
         if (j < re) {
-            const unsigned w0 = words[j];
-            const float a0 = vals[j];
-            accA = fma4(a0, lds_chunk(w0 ^ cA), accA);
-            accB = fma4(a0, lds_chunk(w0 ^ cB), accB);
+            if (j + kq >= re) cur = make_uint2(0x80000000u, zrow);
+            DGCN_TRIP(3)
         }
+#undef DGCN_TRIP
+#undef DGCN_QB
+        BSTAMP(2);
         float4* ownA = reinterpret_cast<float4*>(bufA + v * kHid + ((cfirst ^ (v & 7)) << 2));
         float4* ownB = reinterpret_cast<float4*>(bufA + v * kHid + ((csecond ^ (v & 7)) << 2));
         const float4 yA = *ownA, yB = *ownB;
@@ -374,7 +398,12 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
         oB.x = apply_act(oB.x, ACT); oB.y = apply_act(oB.y, ACT); oB.z = apply_act(oB.z, ACT); oB.w = apply_act(oB.w, ACT);
         *ownA = oA;
         *ownB = oB;
+        BSTAMP(3);
+#ifdef DGCN_DIAG
+        if (st && threadIdx.x == BLOCK - 64) { st[4] += 1; st[5] += (unsigned long long)((re - rs) >> 2); }
+#endif
     }
+#undef BSTAMP
 }
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
@@ -382,14 +411,15 @@ template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
                                                  const unsigned* rinfo, const unsigned short* perm,
                                                  const float* vals, const unsigned short* words, unsigned wmask,
-                                                 int lane_map) {
+                                                 int lane_map, const uint2* rec, unsigned zrow,
+                                                 unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
 #if DGCN_GATHER16
-    (void)bufB; (void)wmask; (void)lane_map;
-    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, rinfo, perm, vals, words);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, rinfo, perm, vals, words);
-    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, rinfo, perm, vals, words);
+    (void)bufB; (void)lane_map;
+    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
+    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
     return;
 #endif
     if (act == DGCN_ACT_RELU) aggregate_rows<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
@@ -500,6 +530,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     float* bufA = bufB + (size_t)a.max_nodes * kHid;
     unsigned* rinfo = reinterpret_cast<unsigned*>(bufA + (size_t)a.max_nodes * kHid);
     unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
+    const unsigned zrow = (unsigned)a.flags_off + 128u;  // LDS byte address of 128 zero bytes
+    if (threadIdx.x < 32) wflags[32 + threadIdx.x] = 0u;
+    uint2* rec = a.grec + (size_t)blockIdx.x * a.meta_cap;
     float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
     unsigned short* words = reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
@@ -714,6 +747,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     }
     }
     __syncthreads();  // scratch (bufA, bufB) is dead from here on
+    {
+        // the support once more as 8-byte records in global memory (L2-resident: 19 layers re-read them)
+        const unsigned rl = rinfo[ng - 1];
+        const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
+        for (int j = threadIdx.x; j < used; j += BLOCK)
+            rec[j] = make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
+    }
+    __syncthreads();
     STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
@@ -735,7 +776,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], ng, bufA, bufB, rinfo, perm, vals, words, 0xffffffffu, a.lane_map);
+            hidden_aggregate<BLOCK>(a.layers[p], ng, bufA, bufB, rinfo, perm, vals, words, 0u, a.lane_map, rec, zrow);
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -776,22 +817,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-            #ifdef DGCN_DIAG
-            // diag bits 8..10: 1 = all gathers hit row 0, 2 = rows 0/1 only (parity conflicts kept), 3 = rows 0..3,
-            // 4 = full 8-entry trips take synthetic metadata from registers (no metadata reads)
-            const unsigned wmask = ((a.diag >> 8) & 7) == 1 ? 0x70u : ((a.diag >> 8) & 7) == 2 ? 0xf0u
-                                   : ((a.diag >> 8) & 7) == 3 ? 0x1f0u : ((a.diag >> 8) & 7) == 4 ? 0x3f0u : 0xffffffffu;
+#ifdef DGCN_DIAG
+            const unsigned wmask = (unsigned)a.diag;  // bit 4: gathers without FMAs, bit 5: FMAs without gathers (experiments)
 #else
-            constexpr unsigned wmask = 0xffffffffu;
+            constexpr unsigned wmask = 0u;
 #endif
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask, a.lane_map);
+            #ifdef DGCN_DIAG
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask, a.lane_map, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+#else
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask, a.lane_map, rec, zrow);
+#endif
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
             // their 32 registers are not live during the gather phase
+            // (both branches define bfrag: otherwise its 32 registers count as live through the gather of every layer)
             if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bfrag[i][c] = 0.f;
+            }
             __syncthreads();
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
         } else {
@@ -1084,12 +1133,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 
 // ---------------------------------------------------------------------------------------------
 // entry slots: the entries themselves plus at most one padding slot per row (even row starts)
-static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 3) & ~3; }
+static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 8 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
 
 static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
     const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
-    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 2 + 15) & ~(size_t)15) + 64;  // + block-OR flags
+    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 2 + 127) & ~(size_t)127) + 256;  // + block-OR flags (128 B) + a zero row (128 B)
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -1233,9 +1282,18 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
             return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry values of large graphs), got %zu", who,
                         need, workspace ? workspace_bytes : (size_t)0);
         a->gvals = static_cast<float*>(workspace);
+        workspace = static_cast<char*>(workspace) + need;
+        workspace_bytes -= need;
+    }
+    {
+        const size_t need = (size_t)b->num_graphs * a->meta_cap * sizeof(uint2) + 256;
+        if (!workspace || workspace_bytes < need)
+            return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry records), got %zu", who, need,
+                        workspace ? workspace_bytes : (size_t)0);
+        a->grec = reinterpret_cast<uint2*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
-    a->flags_off = (int32_t)(*lds - 64);
+    a->flags_off = (int32_t)(*lds - 256);
     return DGCN_OK;
 }
 
@@ -1297,7 +1355,8 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
 static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap) {
     size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
-    return need ? need : 256;
+    need += (size_t)b->num_graphs * meta_cap * sizeof(uint2) + 256;  // entry records of the hidden aggregation
+    return need;
 }
 
 size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m) {
