@@ -73,6 +73,7 @@ struct FusedArgs {
     int32_t max_nodes;
     int32_t meta_cap;
     int32_t prio_second;
+    int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
     int32_t lane_map;   // gather phase: 1 = lanes rotated by 4 inside each 16-lane row (two whole rows per ds_read_b128 bank group)
@@ -106,22 +107,26 @@ struct FusedArgs {
 __device__ __forceinline__ int swz(int row, int col) {  // float index of H[row][col] in a swizzled buffer
     return row * kHid + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));
 }
+// (Tried and dropped: rows of bufA / bufB in a permuted slot order - slot p = feature 4 * (p % 8) + p / 8 - that makes the
+// eight features 4s + kq of an MFMA lane two ds_read_b128 instead of eight ds_read_b32.  The reads got 2 us cheaper per
+// launch, but every wave then fetches its weight fragments with a stride of four columns and the doubled L1 traffic of
+// that cost 30 us.)
 
-#ifndef DGCN_GATHER16
-#define DGCN_GATHER16 1
-#endif
 // bufB swizzle key of a row (xor-ed into the chunk index, inside the 64-byte half)
-#if DGCN_GATHER16
 __device__ __forceinline__ int keyB(int row) { return (row >> 1) & 3; }
-#else
-__device__ __forceinline__ int keyB(int row) { return row & 3; }
-#endif
 __device__ __forceinline__ unsigned short enc_word(int u) { return (unsigned short)((u << 7) | (keyB(u) << 4)); }
 __device__ __forceinline__ int swzB(int row, int col) {
     return row * kHid + ((((col >> 2) ^ keyB(row)) << 2) | (col & 3));
 }
 
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
+__device__ __forceinline__ void set_prio(int p) {  // s_setprio takes an immediate
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const FusedLayer& L, int n0, int ng,
                                                       float* bufA, float* bufB, float xfill) {
@@ -196,9 +201,6 @@ __device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng,
     }
 }
 
-// ---- aggregation at width 32: 8 lanes x float4 per row, sequential fmaf chain over the row's entries.
-// Rows are taken in `perm` order (descending entry count), blocks of 8 dealt to the 8 waves in snake
-// order: only the processing order changes, never the arithmetic.
 __device__ __forceinline__ float4 fma4(float a, float4 z, float4 acc) {
     acc.x = fmaf(a, z.x, acc.x); acc.y = fmaf(a, z.y, acc.y); acc.z = fmaf(a, z.z, acc.z); acc.w = fmaf(a, z.w, acc.w);
     return acc;
@@ -211,102 +213,10 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
-// Half of the kernel's time is spent here.  No single resource explains it (removing all
-// bank conflicts saves 5 %, removing the metadata reads 1 %, packed FMAs nothing; VALU is busy 40 %, the LDS 56 % of
-// the cycles): each wave runs a dependent metadata -> address -> ds_read_b128 -> fmaf chain and only four waves
-// per SIMD are there to hide it.  The loop is therefore built for few instructions per entry - one xor forms a
-// gather address, two words / two values come with one LDS read - and eight gathers in flight per trip.
-template <int BLOCK, int ACT>
-__device__ __forceinline__ void aggregate_rows(const float* bias_ptr, int ng, float* bufA, const float* bufB,
-                                               const unsigned* rinfo, const unsigned short* perm,
-                                               const float* vals, const unsigned short* words, unsigned wmask,
-                                               int lane_map) {
-    // wmask: 0xffffffff, except in DGCN_DIAG experiments that redirect every gather to a few rows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Which 8 lanes share a row.  A ds_read_b128 is served in four bank groups of 16 lanes,
-    // {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 (MI355X_MICROARCH.md, LDS).  With the plain map
-    // (row slot = lane / 8) each group holds HALF rows of four different vertices; rotating the lanes of every
-    // 16-lane row by 4 makes each group two WHOLE rows (128 B each = half the banks): they collide only when the
-    // two vertices have the same parity, instead of whenever any two of four half rows share a bank quarter.
-    const int rho = lane_map ? (((lane & 15) + 4) & 15) | (lane & 48) : lane;
-    const int gw = rho >> 3, q = rho & 7;
-    constexpr int kWaves = BLOCK / 64;
-    const unsigned qx = (unsigned)q << 4;  // gather address = word ^ qx (the word carries the row's swizzle key)
-    // no bias = -0.0f: x + (-0.0f) == x for every x, so the row epilogue needs no branch
-    float4 bias = make_float4(-0.f, -0.f, -0.f, -0.f);
-    if (bias_ptr) bias = *reinterpret_cast<const float4*>(bias_ptr + 4 * q);
-    const int blocks = (ng + 7) >> 3;
-    for (int k = 0; k * kWaves < blocks; ++k) {
-        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
-        const int slot = blk * 8 + gw;
-        if (blk >= blocks || slot >= ng) continue;
-        const int v = perm[slot];
-        const unsigned ri = rinfo[v];
-        const int rs = ri & 0xffff, re = rs + (ri >> 16);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = rs;  // even by construction: 4-byte aligned word pairs, 8-byte aligned value pairs
-        for (; j + 8 <= re; j += 8) {
-            unsigned w[4];
-            float2 a2[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#ifdef DGCN_DIAG
-                if (wmask == 0x3f0u) {  // experiment: no metadata reads (synthetic words / values from registers)
-                    w[i] = (unsigned)(((j + 2 * i) & 127) << 7) | (unsigned)(((j + 2 * i + 1) & 127) << 23);
-                    a2[i] = make_float2(0.01f, -0.01f);
-                    continue;
-                }
-#endif
-                w[i] = *reinterpret_cast<const unsigned*>(words + j + 2 * i);
-                a2[i] = *reinterpret_cast<const float2*>(vals + j + 2 * i);
-            }
-            float4 z[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                z[2 * i] = lds_chunk((w[i] & 0xffffu & wmask) ^ qx);
-                z[2 * i + 1] = lds_chunk(((w[i] >> 16) & wmask) ^ qx);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc = fma4(a2[i].x, z[2 * i], acc);
-                acc = fma4(a2[i].y, z[2 * i + 1], acc);
-            }
-        }
-        if (j + 4 <= re) {
-            const unsigned w0 = *reinterpret_cast<const unsigned*>(words + j);
-            const unsigned w1 = *reinterpret_cast<const unsigned*>(words + j + 2);
-            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float2 a23 = *reinterpret_cast<const float2*>(vals + j + 2);
-            const float4 z0 = lds_chunk((w0 & 0xffffu & wmask) ^ qx), z1 = lds_chunk(((w0 >> 16) & wmask) ^ qx);
-            const float4 z2 = lds_chunk((w1 & 0xffffu & wmask) ^ qx), z3 = lds_chunk(((w1 >> 16) & wmask) ^ qx);
-            acc = fma4(a01.x, z0, acc);
-            acc = fma4(a01.y, z1, acc);
-            acc = fma4(a23.x, z2, acc);
-            acc = fma4(a23.y, z3, acc);
-            j += 4;
-        }
-        if (j + 2 <= re) {
-            const unsigned w0 = *reinterpret_cast<const unsigned*>(words + j);
-            const float2 a01 = *reinterpret_cast<const float2*>(vals + j);
-            const float4 z0 = lds_chunk((w0 & 0xffffu & wmask) ^ qx), z1 = lds_chunk(((w0 >> 16) & wmask) ^ qx);
-            acc = fma4(a01.x, z0, acc);
-            acc = fma4(a01.y, z1, acc);
-            j += 2;
-        }
-        if (j < re) acc = fma4(vals[j], lds_chunk(((unsigned)words[j] & wmask) ^ qx), acc);
-        float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
-        const float4 z = *own;
-        float4 o = make_float4(z.x + acc.x, z.y + acc.y, z.z + acc.z, z.w + acc.w);
-        o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
-        o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
-        *own = o;
-    }
-}
-
-// ---- the same aggregation with 4 lanes x 2 float4 per row: 16 rows per wave pass.  Per row the arithmetic is the one
-// above (sequential fmaf chain over the row's entries, feature by feature); what changes is how many instructions a
-// wave issues around it: one metadata read serves 16 rows instead of 8, and the row prologue (perm, rinfo), the 2- and
-// 1-entry tails and the epilogue run once per 16 rows.  A lane (slot s = lane / 4, kq = lane % 4) owns chunks kq and
+// ---- aggregation at width 32: 4 lanes x 2 float4 per row, 16 rows per wave pass, rows in `perm` order (descending
+// entry count; only the processing order changes, never the arithmetic).  Per row: sequential fmaf chain over the
+// row's entries, slot by slot.  (Round 2 started with 8 lanes x float4 per row and 8 rows per pass: twice the
+// prologue / tail / epilogue instructions per row for the same gathers.)  A lane (slot s = lane / 4, kq = lane % 4) owns chunks kq and
 // kq + 4 of its row; slots with (s >> 1) & 1 set read the upper half first.  A ds_read_b128 is served in bank groups
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
@@ -415,16 +325,10 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, fl
                                                  unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
-#if DGCN_GATHER16
-    (void)bufB; (void)lane_map;
+    (void)bufB; (void)lane_map; (void)vals; (void)words;
     if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
     else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
     else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
-    return;
-#endif
-    if (act == DGCN_ACT_RELU) aggregate_rows<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
-    else aggregate_rows<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, bufB, rinfo, perm, vals, words, wmask, lane_map);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
@@ -798,10 +702,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     if (a.num_layers > 2 && P == 1 && !scores_given) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
     for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
-        if (second && a.prio_second) {
-            if ((l & 7) < a.prio_second) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
+        // fp32 MFMAs and VALU work exclude each other on a SIMD and the older wave wins (tools/micro/mfma_valu.hip):
+        // while one workgroup transforms, the other one's gather waves cannot even form their next addresses and the
+        // LDS runs dry.  Waves therefore raise their priority for the aggregation phase (a handful of short VALU
+        // instructions per LDS round trip) and drop it for the MFMA-paced transform.
+        const int prio_base = (second && a.prio_second && (l & 7) < a.prio_second) ? 1 : 0;
+        if (a.prio_second || a.prio_gather) set_prio(prio_base);
         if (L.cout == kHid) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
@@ -817,6 +723,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
+            if (a.prio_gather) set_prio(prio_base + a.prio_gather);
 #ifdef DGCN_DIAG
             const unsigned wmask = (unsigned)a.diag;  // bit 4: gathers without FMAs, bit 5: FMAs without gathers (experiments)
 #else
@@ -1069,52 +976,96 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     {
         int cnt = 0;
         if (mine) {
+            // uniform trip count and eight priority reads in flight (a divergent exit made the compiler wait for every
+            // single read: 100 LDS round trips per vertex pair)
             const double pvv = pr[vv];
-#pragma unroll 4
-            for (int w = sub; w < ng; w += lpv) {
-                const double pw = pr[w];
-                cnt += (pw > pvv) || (pw == pvv && w < vv);
+            const int iters = (ng + lpv - 1) >> lsh;
+            for (int i0 = 0; i0 < iters; i0 += 8) {
+                double pw[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pw[k] = pr[min(sub + ((i0 + k) << lsh), ng - 1)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int w = sub + ((i0 + k) << lsh);
+                    cnt += (w < ng) && ((pw[k] > pvv) || (pw[k] == pvv && w < vv));
+                }
             }
         }
         for (int off = 1; off < lpv; off <<= 1) cnt += __shfl_xor(cnt, off);
         if (mine && sub == 0) { key[vv] = (unsigned short)cnt; st[vv] = 0; }
     }
+    // Rounds.  The rank of a vertex never changes, only whether it is still there: every lane keeps its share of the
+    // row's neighbours as (rank << 16 | vertex) in registers and a round reads one "gone" byte per neighbour - one LDS
+    // round trip instead of a dependent word -> rank pair per entry.  The gone bytes are double-buffered (a round reads
+    // `cur`, winners and the already-gone write 1s into `nxt`: every writer writes the same value), so a round needs ONE
+    // barrier; whether anybody was still alive travels through three rotating flag words.  Same rounds, same sets as
+    // the two-barrier loop of greedy_rounds().
+    uint8_t* gone0 = st + a.max_nodes;
+    uint8_t* gone1 = gone0 + a.max_nodes;
+    STAMP(a, g, 15, tclk);  // priorities and ranks
+    unsigned* alive_flag = wflags + 16;  // [3]
+    if (mine && sub == 0) { gone0[vv] = 0; gone1[vv] = 0; }
+    if (threadIdx.x < 3) alive_flag[threadIdx.x] = 0u;
     __syncthreads();
     int rounds = 0;
     const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
+    constexpr int kNb = 16;
+    const unsigned none = (kDead << 16) | (unsigned)(mine ? vv : 0);  // rank "dead", reads the lane's own byte
+    unsigned nb[kNb];
+    int kmax = 0;
+#pragma unroll
+    for (int i = 0; i < kNb; ++i) {
+        const int j = rs + sub + i * lpv;
+        nb[i] = none;
+        if (j < re) {
+            const unsigned u = (unsigned)words[j] >> 7;
+            if ((int)u != vv) nb[i] = ((unsigned)key[u] << 16) | u;
+        }
+        if (__any(j < re)) kmax = i + 1;
+    }
+    const bool spill = rs + sub + kNb * lpv < re;  // more neighbours than the registers hold: walked in the LDS
+    const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
+    uint8_t *cur = gone0, *nxt = gone1;
     while (!DIAG_ON(a, 2)) {
-        const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
-        const bool live = mykey != kDead;
+        const bool live = mine && cur[vv] == 0;
         unsigned m = kDead;
         if (live) {
-            int j = rs + sub;
-            for (; j + 3 * lpv < re; j += 4 * lpv) {  // four independent word -> rank chains in flight
-                const int u0 = words[j] >> 7, u1 = words[j + lpv] >> 7, u2 = words[j + 2 * lpv] >> 7,
-                          u3 = words[j + 3 * lpv] >> 7;
-                const unsigned k0 = key[u0], k1 = key[u1], k2 = key[u2], k3 = key[u3];
-                m = min(m, u0 != vv ? k0 : kDead);
-                m = min(m, u1 != vv ? k1 : kDead);
-                m = min(m, u2 != vv ? k2 : kDead);
-                m = min(m, u3 != vv ? k3 : kDead);
-            }
-            for (; j < re; j += lpv) {
-                const int u = words[j] >> 7;
-                const unsigned k = key[u];
-                if (u != vv) m = min(m, k);
+            unsigned char d[kNb];
+#pragma unroll
+            for (int i = 0; i < kNb; ++i)
+                if (i < kmax) d[i] = cur[nb[i] & 0xffffu];
+#pragma unroll
+            for (int i = 0; i < kNb; ++i)
+                if (i < kmax) m = min(m, d[i] ? kDead : (nb[i] >> 16));
+            if (spill) {
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+                    const int u = words[j] >> 7;
+                    if (u != vv && cur[u] == 0) m = min(m, (unsigned)key[u]);
+                }
             }
         }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && mykey < m;
-        if (!block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every rank read before the kills below
-        ++rounds;
+        const int fl = rounds % 3;
+        if (live) alive_flag[fl] = 1u;
+        if (threadIdx.x == 0) alive_flag[fl == 2 ? 0 : fl + 1] = 0u;  // last read two barriers ago
+        if (mine && !live && sub == 0) nxt[vv] = 1;
         if (won) {
-            for (int j = rs + sub; j < re; j += lpv) {
-                const int u = words[j] >> 7;
-                if (u != vv && key[u] != kDead) { key[u] = (unsigned short)kDead; st[u] = 2; }
+#pragma unroll
+            for (int i = 0; i < kNb; ++i)
+                if (i < kmax && (nb[i] >> 16) != kDead) { nxt[nb[i] & 0xffffu] = 1; st[nb[i] & 0xffffu] = 2; }
+            if (spill) {
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+                    const int u = words[j] >> 7;
+                    if (u != vv) { nxt[u] = 1; st[u] = 2; }
+                }
             }
-            if (sub == 0) { key[vv] = (unsigned short)kDead; st[vv] = 1; }
+            if (sub == 0) { nxt[vv] = 1; st[vv] = 1; }
         }
         __syncthreads();
+        if (alive_flag[fl] == 0u) break;
+        ++rounds;
+        uint8_t* t = cur; cur = nxt; nxt = t;
     }
     STAMP(a, g, 10, tclk);  // priorities, ranks, greedy rounds
     const int tv = threadIdx.x;
@@ -1337,6 +1288,7 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
 }
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
+    a.prio_gather = getenv("DGCN_FUSED_PRIOG") ? atoi(getenv("DGCN_FUSED_PRIOG")) : 1;
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 5;
     a.lane_map = getenv("DGCN_FUSED_LANEMAP") ? atoi(getenv("DGCN_FUSED_LANEMAP")) : 1;  // measured: 224.7 -> 218.8 us on C3
 #ifdef DGCN_DIAG

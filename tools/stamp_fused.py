@@ -17,11 +17,12 @@ eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
 os.environ.pop("DGCN_FUSED_STAMPS")
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0  # s_memtime ticks at 100 MHz -> us
 names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
-         "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]
+         "hidden A (sum)", "barrier after A (sum)", "last layer", "greedy rounds", "tail", "priorities + ranks"]
 print("phase clocks of wave 0, microseconds: mean over graphs / max")
-for i, n in enumerate(names):
+cols = list(range(12)) + [15]
+for i, n in zip(cols, names):
     print("%-24s %8.2f %8.2f" % (n, s[:, i].mean(), s[:, i].max()))
-print("%-24s %8.2f" % ("sum of means", s[:, :12].mean(axis=0).sum()))
+print("%-24s %8.2f" % ("sum of means", s[:, cols].mean(axis=0).sum()))
 blk = st.cpu().numpy().reshape(-1, 64)[:, 48:54].astype(np.float64)
 if blk[:, 4].sum() > 0:
     nb, ntr = blk[:, 4].mean(), blk[:, 5].mean()
@@ -29,7 +30,7 @@ if blk[:, 4].sum() > 0:
           % (nb, ntr, blk[:, 0].mean() / 100, blk[:, 1].mean() / 100, blk[:, 2].mean() / 100, blk[:, 3].mean() / 100))
     print("  per block: prologue %.0f cycles, tails %.0f, epilogue %.0f; per full trip %.0f cycles"
           % (blk[:, 0].mean() / nb, blk[:, 2].mean() / nb, blk[:, 3].mean() / nb, blk[:, 1].mean() / ntr))
-tot = s[:, :12].sum(axis=1)
+tot = s[:, cols].sum(axis=1)
 print("per-workgroup total: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f;  first-dispatched half mean %.1f, second half mean %.1f"
       % (tot.min(), np.percentile(tot, 10), np.median(tot), np.percentile(tot, 90), tot.max(), tot[:256].mean(), tot[256:].mean()))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,4 +19,5 @@ for rnd in range(5):
     torch.cuda.synchronize(); eng.timing(False)
     ms, n = eng.timing_read("fused_solve")
     res.append(ms / n * 1e3)
+print("rounds per graph: mean %.1f max %d" % (out["rounds"].float().mean().item(), out["rounds"].max().item()))
 print("%s median %7.2f us  min %7.2f us" % (" ".join(sys.argv[1:]), float(np.median(res)), min(res)))
