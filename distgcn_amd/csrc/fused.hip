@@ -155,8 +155,18 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
 // C/D: col = l & 15, row = 4 * (l >> 4) + reg.  Z0 overwrites the tile's own rows of bufA.
 // The B fragments of a layer are fetched one layer ahead (load_bfrag) so that their global-memory
 // latency hides under the previous layer's gather phase.
-__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4]) {
+__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4], int skip = 0) {
     const int lane = threadIdx.x & 63;
+#ifdef DGCN_DIAG
+    if (skip) {  // experiment: no weight fetch
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) b[s][ct] = 0.01f * (float)(s + ct);
+        return;
+    }
+#endif
+    (void)skip;
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 8; ++s)
@@ -213,6 +223,39 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
+// What a lane needs to start on its (up to four) row blocks of the aggregation: the row, its entry range and the record
+// of its first entry.  None of it changes from layer to layer, so it is read once per graph and stays in registers: a
+// block starts with its gathers instead of three dependent round trips (perm -> rinfo -> record).
+constexpr int kMaxRowBlocks = 4;  // 512 vertices / (16 rows x 8 waves)
+struct RowBlocks {
+    int v[kMaxRowBlocks];        // row of this lane's slot in block k, -1 = none
+    unsigned ri[kMaxRowBlocks];  // rinfo of that row
+    uint2 first[kMaxRowBlocks];  // record of entry kq of the row
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
+                                                const uint2* rec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane >> 2, kq = lane & 3;
+    constexpr int kWaves = BLOCK / 64;
+    const int blocks = (ng + 15) >> 4;
+#pragma unroll
+    for (int k = 0; k < kMaxRowBlocks; ++k) {
+        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
+        const int slot = blk * 16 + s;
+        rb.v[k] = -1;
+        rb.ri[k] = 0u;
+        rb.first[k] = make_uint2(0u, 0u);
+        if (blk < blocks && slot < ng) {
+            const int v = perm[slot];
+            rb.v[k] = v;
+            rb.ri[k] = rinfo[v];
+            rb.first[k] = rec[(rb.ri[k] & 0xffff) + kq];
+        }
+    }
+}
+
 // ---- aggregation at width 32: 4 lanes x 2 float4 per row, 16 rows per wave pass, rows in `perm` order (descending
 // entry count; only the processing order changes, never the arithmetic).  Per row: sequential fmaf chain over the
 // row's entries, slot by slot.  (Round 2 started with 8 lanes x float4 per row and 8 rows per pass: twice the
@@ -222,9 +265,8 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
 template <int BLOCK, int ACT>
-__device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, float* bufA, const unsigned* rinfo,
-                                                 const unsigned short* perm, const uint2* rec, unsigned zrow,
-                                                 int diag, unsigned long long* st) {
+__device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
+                                                 const uint2* rec, unsigned zrow, int diag, unsigned long long* st) {
     (void)diag; (void)st;
 #ifdef DGCN_DIAG
 #define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == BLOCK - 64) st[i] += _t - bt; bt = _t; } while (0)
@@ -234,6 +276,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
 #endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
+    (void)wave;
     const int cfirst = kq | (((s >> 1) & 1) << 2), csecond = cfirst ^ 4;  // logical chunks of this lane
     const unsigned cA = (unsigned)cfirst << 4, cB = (unsigned)csecond << 4;
     constexpr int kWaves = BLOCK / 64;
@@ -242,16 +285,16 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
         biasA = *reinterpret_cast<const float4*>(bias_ptr + 4 * cfirst);
         biasB = *reinterpret_cast<const float4*>(bias_ptr + 4 * csecond);
     }
-    const int blocks = (ng + 15) >> 4;
-    for (int k = 0; k * kWaves < blocks; ++k) {
-        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
-        const int slot = blk * 16 + s;
-        if (blk >= blocks || slot >= ng) continue;
+    (void)kWaves;
+#pragma unroll
+    for (int k = 0; k < kMaxRowBlocks; ++k) {
+        if (!__any(rb.v[k] >= 0)) continue;
+        if (rb.v[k] < 0) continue;
 #ifdef DGCN_DIAG
         bt = __builtin_amdgcn_s_memtime();
 #endif
-        const int v = perm[slot];
-        const unsigned ri = rinfo[v];
+        const int v = rb.v[k];
+        const unsigned ri = rb.ri[k];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
         BSTAMP(0);
@@ -265,7 +308,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
         // (Tried and dropped: issuing the 8 gathers of trip t + 1 before the 16 packed FMAs of trip t - uniform trip count
         // from the block's first row, ping-pong buffers, no spills: 211.8 us against 205.2 us per C3 launch.)
         int j = rs;
-        uint2 cur = rec[j + kq];
+        uint2 cur = rb.first[k];
 #define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, false)
 #define DGCN_TRIP(NE)                                                                                          \
         {                                                                                                      \
@@ -318,17 +361,13 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, int ng, 
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
 template <int BLOCK>
-__device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, int ng, float* bufA, const float* bufB,
-                                                 const unsigned* rinfo, const unsigned short* perm,
-                                                 const float* vals, const unsigned short* words, unsigned wmask,
-                                                 int lane_map, const uint2* rec, unsigned zrow,
-                                                 unsigned long long* st = nullptr) {
+__device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
+                                                 unsigned zrow, int diag = 0, unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
-    (void)bufB; (void)lane_map; (void)vals; (void)words;
-    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
-    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, ng, bufA, rinfo, perm, rec, zrow, (int)wmask, st);
+    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, bufA, rb, rec, zrow, diag, st);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, rb, rec, zrow, diag, st);
+    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, rb, rec, zrow, diag, st);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
@@ -659,6 +698,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             rec[j] = make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
     }
     __syncthreads();
+    RowBlocks rb;
+    row_blocks_init<BLOCK>(rb, ng, rinfo, perm, rec);
     STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
@@ -680,7 +721,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], ng, bufA, bufB, rinfo, perm, vals, words, 0u, a.lane_map, rec, zrow);
+            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow);
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -699,7 +740,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         if (v < ng) { bufA[v] = zc0; bufB[v] = zc1; }
         l_first = P;
     }
-    if (a.num_layers > 2 && P == 1 && !scores_given) load_bfrag(a.layers[1].W, bfrag);  // first hidden 32x64 product
+    if (a.num_layers > 2 && P == 1 && !scores_given) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3));  // first hidden 32x64 product
     for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
         // fp32 MFMAs and VALU work exclude each other on a SIMD and the older wave wins (tools/micro/mfma_valu.hip):
@@ -730,9 +771,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             constexpr unsigned wmask = 0u;
 #endif
             #ifdef DGCN_DIAG
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask, a.lane_map, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, (int)wmask, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, ng, bufA, bufB, rinfo, perm, vals, words, wmask, a.lane_map, rec, zrow);
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
 #endif
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
@@ -741,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
             // their 32 registers are not live during the gather phase
             // (both branches define bfrag: otherwise its 32 registers count as live through the gather of every layer)
-            if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag);
+            if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
             else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
