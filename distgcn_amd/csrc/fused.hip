@@ -233,9 +233,18 @@ struct RowBlocks {
     uint2 first[kMaxRowBlocks];  // record of entry kq of the row
 };
 
-template <int BLOCK>
+// Where a lane finds entry j of the support: the global records, or - for a workgroup that has the CU (and its LDS
+// queue) to itself and whose values are in the LDS - the LDS arrays: ~100 cycles instead of an L2 round trip that a
+// lone workgroup has nothing to hide under.
+template <bool LDSMETA>
+__device__ __forceinline__ uint2 entry_record(const uint2* rec, const float* vals, const unsigned short* words, int j) {
+    if constexpr (LDSMETA) return make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
+    else return rec[j];
+}
+
+template <int BLOCK, bool LDSMETA>
 __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                const uint2* rec) {
+                                                const uint2* rec, const float* vals, const unsigned short* words) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     constexpr int kWaves = BLOCK / 64;
@@ -251,7 +260,7 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
             const int v = perm[slot];
             rb.v[k] = v;
             rb.ri[k] = rinfo[v];
-            rb.first[k] = rec[(rb.ri[k] & 0xffff) + kq];
+            rb.first[k] = entry_record<LDSMETA>(rec, vals, words, (int)(rb.ri[k] & 0xffff) + kq);
         }
     }
 }
@@ -264,9 +273,10 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-template <int BLOCK, int ACT>
+template <int BLOCK, int ACT, bool LDSMETA>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
-                                                 const uint2* rec, unsigned zrow, int diag, unsigned long long* st) {
+                                                 const uint2* rec, const float* vals, const unsigned short* words,
+                                                 unsigned zrow, int diag, unsigned long long* st) {
     (void)diag; (void)st;
 #ifdef DGCN_DIAG
 #define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == BLOCK - 64) st[i] += _t - bt; bt = _t; } while (0)
@@ -328,7 +338,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
             }                                                                                                  \
         }
         for (; j + 4 <= re; j += 4) {
-            const uint2 nxt = rec[j + 4 + kq];  // may be the next row's entry or slack: neutralised below if so
+            const uint2 nxt = entry_record<LDSMETA>(rec, vals, words, j + 4 + kq);  // next row's entry or slack: neutralised below
             DGCN_TRIP(4)
             cur = nxt;
         }
@@ -360,14 +370,15 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 }
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
-template <int BLOCK>
+template <int BLOCK, bool LDSMETA>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
-                                                 unsigned zrow, int diag = 0, unsigned long long* st = nullptr) {
+                                                 const float* vals, const unsigned short* words, unsigned zrow,
+                                                 int diag = 0, unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
-    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, bufA, rb, rec, zrow, diag, st);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, rb, rec, zrow, diag, st);
-    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, rb, rec, zrow, diag, st);
+    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
+    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
@@ -690,7 +701,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     }
     }
     __syncthreads();  // scratch (bufA, bufB) is dead from here on
-    {
+    // (Tried: a lone 1024-thread workgroup taking its entry metadata from the LDS instead of the global records - 136.0 vs
+    // 132.5 us for one graph, 448 vs 455 us for the C4 share: no clear winner, one code path kept.)
+    constexpr bool kLdsMeta = false;
+    // (32-wide aggregations only: a one-layer model has none)
+    const bool has_wide = !(MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN)) &&
+                          (a.wide_passes > 1 || (a.num_layers > 1 && a.layers[0].cout == kHid));
+    if (has_wide && !kLdsMeta) {
         // the support once more as 8-byte records in global memory (L2-resident: 19 layers re-read them)
         const unsigned rl = rinfo[ng - 1];
         const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     }
     __syncthreads();
     RowBlocks rb;
-    row_blocks_init<BLOCK>(rb, ng, rinfo, perm, rec);
+    row_blocks_init<BLOCK, kLdsMeta>(rb, has_wide ? ng : 0, rinfo, perm, rec, vals, words);
     STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
@@ -721,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow);
+            hidden_aggregate<BLOCK, kLdsMeta>(a.layers[p], bufA, rb, rec, vals, words, zrow);
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -771,9 +788,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             constexpr unsigned wmask = 0u;
 #endif
             #ifdef DGCN_DIAG
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, (int)wmask, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK, kLdsMeta>(L, bufA, rb, rec, vals, words, zrow, (int)wmask, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK, kLdsMeta>(L, bufA, rb, rec, vals, words, zrow);
 #endif
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
@@ -1017,96 +1034,56 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     {
         int cnt = 0;
         if (mine) {
-            // uniform trip count and eight priority reads in flight (a divergent exit made the compiler wait for every
-            // single read: 100 LDS round trips per vertex pair)
             const double pvv = pr[vv];
-            const int iters = (ng + lpv - 1) >> lsh;
-            for (int i0 = 0; i0 < iters; i0 += 8) {
-                double pw[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pw[k] = pr[min(sub + ((i0 + k) << lsh), ng - 1)];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int w = sub + ((i0 + k) << lsh);
-                    cnt += (w < ng) && ((pw[k] > pvv) || (pw[k] == pvv && w < vv));
-                }
+#pragma unroll 4
+            for (int w = sub; w < ng; w += lpv) {
+                const double pw = pr[w];
+                cnt += (pw > pvv) || (pw == pvv && w < vv);
             }
         }
         for (int off = 1; off < lpv; off <<= 1) cnt += __shfl_xor(cnt, off);
         if (mine && sub == 0) { key[vv] = (unsigned short)cnt; st[vv] = 0; }
     }
-    // Rounds.  The rank of a vertex never changes, only whether it is still there: every lane keeps its share of the
-    // row's neighbours as (rank << 16 | vertex) in registers and a round reads one "gone" byte per neighbour - one LDS
-    // round trip instead of a dependent word -> rank pair per entry.  The gone bytes are double-buffered (a round reads
-    // `cur`, winners and the already-gone write 1s into `nxt`: every writer writes the same value), so a round needs ONE
-    // barrier; whether anybody was still alive travels through three rotating flag words.  Same rounds, same sets as
-    // the two-barrier loop of greedy_rounds().
-    uint8_t* gone0 = st + a.max_nodes;
-    uint8_t* gone1 = gone0 + a.max_nodes;
-    STAMP(a, g, 15, tclk);  // priorities and ranks
-    unsigned* alive_flag = wflags + 16;  // [3]
-    if (mine && sub == 0) { gone0[vv] = 0; gone1[vv] = 0; }
-    if (threadIdx.x < 3) alive_flag[threadIdx.x] = 0u;
+    // (Tried and dropped: rounds with every lane's neighbours as (rank << 16 | vertex) in registers, double-buffered "gone"
+    // bytes and one barrier per round, ranks with eight reads in flight.  14 -> 8.5 us when the phase runs alone, but the
+    // C3 launch did not move (the co-resident workgroup's gathers keep the LDS queue full: every dependent access costs
+    // ~500 cycles either way) and the one-layer configurations lost 10 % to the set-up.)
     __syncthreads();
     int rounds = 0;
     const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
-    constexpr int kNb = 16;
-    const unsigned none = (kDead << 16) | (unsigned)(mine ? vv : 0);  // rank "dead", reads the lane's own byte
-    unsigned nb[kNb];
-    int kmax = 0;
-#pragma unroll
-    for (int i = 0; i < kNb; ++i) {
-        const int j = rs + sub + i * lpv;
-        nb[i] = none;
-        if (j < re) {
-            const unsigned u = (unsigned)words[j] >> 7;
-            if ((int)u != vv) nb[i] = ((unsigned)key[u] << 16) | u;
-        }
-        if (__any(j < re)) kmax = i + 1;
-    }
-    const bool spill = rs + sub + kNb * lpv < re;  // more neighbours than the registers hold: walked in the LDS
-    const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
-    uint8_t *cur = gone0, *nxt = gone1;
     while (!DIAG_ON(a, 2)) {
-        const bool live = mine && cur[vv] == 0;
+        const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
+        const bool live = mykey != kDead;
         unsigned m = kDead;
         if (live) {
-            unsigned char d[kNb];
-#pragma unroll
-            for (int i = 0; i < kNb; ++i)
-                if (i < kmax) d[i] = cur[nb[i] & 0xffffu];
-#pragma unroll
-            for (int i = 0; i < kNb; ++i)
-                if (i < kmax) m = min(m, d[i] ? kDead : (nb[i] >> 16));
-            if (spill) {
-                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
-                    const int u = words[j] >> 7;
-                    if (u != vv && cur[u] == 0) m = min(m, (unsigned)key[u]);
-                }
+            int j = rs + sub;
+            for (; j + 3 * lpv < re; j += 4 * lpv) {  // four independent word -> rank chains in flight
+                const int u0 = words[j] >> 7, u1 = words[j + lpv] >> 7, u2 = words[j + 2 * lpv] >> 7,
+                          u3 = words[j + 3 * lpv] >> 7;
+                const unsigned k0 = key[u0], k1 = key[u1], k2 = key[u2], k3 = key[u3];
+                m = min(m, u0 != vv ? k0 : kDead);
+                m = min(m, u1 != vv ? k1 : kDead);
+                m = min(m, u2 != vv ? k2 : kDead);
+                m = min(m, u3 != vv ? k3 : kDead);
+            }
+            for (; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                const unsigned k = key[u];
+                if (u != vv) m = min(m, k);
             }
         }
         for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
         const bool won = live && mykey < m;
-        const int fl = rounds % 3;
-        if (live) alive_flag[fl] = 1u;
-        if (threadIdx.x == 0) alive_flag[fl == 2 ? 0 : fl + 1] = 0u;  // last read two barriers ago
-        if (mine && !live && sub == 0) nxt[vv] = 1;
+        if (!block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every rank read before the kills below
+        ++rounds;
         if (won) {
-#pragma unroll
-            for (int i = 0; i < kNb; ++i)
-                if (i < kmax && (nb[i] >> 16) != kDead) { nxt[nb[i] & 0xffffu] = 1; st[nb[i] & 0xffffu] = 2; }
-            if (spill) {
-                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
-                    const int u = words[j] >> 7;
-                    if (u != vv) { nxt[u] = 1; st[u] = 2; }
-                }
+            for (int j = rs + sub; j < re; j += lpv) {
+                const int u = words[j] >> 7;
+                if (u != vv && key[u] != kDead) { key[u] = (unsigned short)kDead; st[u] = 2; }
             }
-            if (sub == 0) { nxt[vv] = 1; st[vv] = 1; }
+            if (sub == 0) { key[vv] = (unsigned short)kDead; st[vv] = 1; }
         }
         __syncthreads();
-        if (alive_flag[fl] == 0u) break;
-        ++rounds;
-        uint8_t* t = cur; cur = nxt; nxt = t;
     }
     STAMP(a, g, 10, tclk);  // priorities, ranks, greedy rounds
     const int tv = threadIdx.x;

@@ -7,7 +7,8 @@ from distgcn_amd import datagen
 from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
 kind = sys.argv[1] if len(sys.argv) > 1 else "er"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-hb = datagen.er_batch(500, 200, 0.1) if kind == "er" else datagen.ba_test2_batch(500)
+nb_graphs = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+hb = datagen.er_batch(nb_graphs, 200, 0.1) if kind == "er" else datagen.ba_test2_batch(nb_graphs)
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
 for _ in range(3): eng.solve(db, model, mode=MODE_FUSED)
 torch.cuda.synchronize()
@@ -17,9 +18,9 @@ eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
 os.environ.pop("DGCN_FUSED_STAMPS")
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0  # s_memtime ticks at 100 MHz -> us
 names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
-         "hidden A (sum)", "barrier after A (sum)", "last layer", "greedy rounds", "tail", "priorities + ranks"]
+         "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]
 print("phase clocks of wave 0, microseconds: mean over graphs / max")
-cols = list(range(12)) + [15]
+cols = list(range(12))
 for i, n in zip(cols, names):
     print("%-24s %8.2f %8.2f" % (n, s[:, i].mean(), s[:, i].max()))
 print("%-24s %8.2f" % ("sum of means", s[:, cols].mean(axis=0).sum()))
