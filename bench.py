@@ -386,10 +386,10 @@ def spmm_probe(args, wl, traffic_db):
 
 def e2e_probe(args, wl, reference_state):
     """Host to host: per-graph CSR arrays (what a .mat parser hands over, mwis_dqn_test.py:304-310) in host memory
-    -> membership bytes + totals + rounds in host memory, through distgcn_amd.serving.SolvePipeline (native packing
-    into pinned memory, one H2D copy, one fused launch, one D2H copy; three batches in flight).  PCIe-inclusive,
-    so it is reported BESIDE ``value``, never as it."""
-    from distgcn_amd.serving import SolvePipeline
+    -> membership bytes + totals + rounds in host memory, through distgcn_amd.serving.HostSolver (dgcn_host_solver_*:
+    native packing into pinned memory, one H2D copy, one fused launch, one D2H copy; three batches in flight).
+    PCIe-inclusive, so it is reported BESIDE ``value``, never as it."""
+    from distgcn_amd.serving import HostSolver
     from distgcn_amd.batch import pack_csr_lists
     hb = wl.hb
     ps, cs, ws = [], [], []
@@ -398,7 +398,7 @@ def e2e_probe(args, wl, reference_state):
         ps.append(np.ascontiguousarray(hb.row_ptr[n0:n1 + 1] - e0, dtype=np.int32))
         cs.append(np.ascontiguousarray(hb.col_idx[e0:e1] - n0, dtype=np.int32))
         ws.append(np.ascontiguousarray(hb.weights[n0:n1]))
-    pipe = SolvePipeline(wl.eng, wl.model, depth=3)
+    pipe = HostSolver(wl.eng, wl.model, depth=3, pack_threads=16)
     batches = 300
     last = None
     for r in pipe.solve_many(((ps, cs, ws) for _ in range(10)), copy=False):
@@ -417,8 +417,9 @@ def e2e_probe(args, wl, reference_state):
         _, info = pack_csr_lists(ps, cs, ws, staging=staging)
     pack_ms = (time.perf_counter() - t1) / 20 * 1e3
     return {"value": hb.num_graphs * batches / dt, "unit": "graphs/s", "ms_per_batch": dt / batches * 1e3, "batches": batches,
-            "path": "per-graph CSR arrays in host memory -> dgcn_pack_batch into pinned memory -> 1 H2D copy (%.1f MB) -> "
-                    "dgcn_solve_batch -> 1 D2H copy (%.0f KB) -> membership + totals + rounds in host memory; 3 batches in flight"
+            "path": "dgcn_host_solver_submit / _result: per-graph CSR arrays in host memory -> dgcn_pack_batch into pinned memory -> "
+                    "1 H2D copy (%.1f MB) -> dgcn_solve_batch -> 1 D2H copy (%.0f KB) -> membership + totals + rounds in host memory; "
+                    "3 batches in flight"
                     % (int(info.total_bytes) / 1e6, (hb.num_nodes + 12 * hb.num_graphs) / 1e3),
             "pack_ms_per_batch": pack_ms, "results_equal_resident_step": same}
 

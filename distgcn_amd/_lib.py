@@ -26,6 +26,7 @@ FAULT_NAMES = {
 SYMBOLS = (
     "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_transform_batch",
     "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
+    "dgcn_host_solver_create", "dgcn_host_solver_destroy", "dgcn_host_solver_submit", "dgcn_host_solver_result",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
 
@@ -133,6 +134,15 @@ def load():
     lib.dgcn_solve_residual_batch.restype = C.c_int
     lib.dgcn_solve_residual_batch.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), vp, i32, vp, f32, i32, vp, i32,
                                               i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.dgcn_host_solver_create.restype = C.c_int
+    lib.dgcn_host_solver_create.argtypes = [C.POINTER(DgcnModel), vp, i32, i32, f32, i32, i32, i32, C.POINTER(vp)]
+    lib.dgcn_host_solver_destroy.restype = None
+    lib.dgcn_host_solver_destroy.argtypes = [vp]
+    lib.dgcn_host_solver_submit.restype = C.c_int
+    lib.dgcn_host_solver_submit.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+    lib.dgcn_host_solver_result.restype = C.c_int
+    lib.dgcn_host_solver_result.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32),
+                                            C.POINTER(i32), C.POINTER(i32)]
     lib.dgcn_timing_enable.restype = C.c_int
     lib.dgcn_timing_enable.argtypes = [i32]
     lib.dgcn_timing_reset.restype = C.c_int

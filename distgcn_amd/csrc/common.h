@@ -50,6 +50,11 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     return x;
 }
 
+// dgcn_pack_batch with one more check for callers whose kernel cannot report it (pack.hip)
+int pack_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
+               const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host,
+               size_t staging_bytes, DgcnPackInfo* info, int32_t num_threads, bool reject_self_loops);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace dgcn

@@ -1,0 +1,278 @@
+// Host-to-host solver object: per-graph CSR arrays in host memory -> selected sets in host memory, behind two C calls.
+//
+// The reference's agents are called with ONE graph at a time - `sess.run` per graph in solve_mwis
+// (mwis_dqn_call.py:140-143, mwis_gdpg_call.py:211-216), once per time slot in the wireless loop - and its test loop
+// feeds a directory of graphs one after the other (mwis_dqn_test.py:304-321).  For such callers the kernel is a
+// small part of a call: packing, two copies, a launch and a wait have to be cheap too.  This object keeps `depth`
+// slots of pinned staging memory, device buffers, a stream and an event each, so that
+//     dgcn_host_solver_submit  = dgcn_pack_batch into pinned memory -> 1 hipMemcpyAsync -> dgcn_solve_batch
+//                                -> 1 hipMemcpyAsync back -> event           (returns at once)
+//     dgcn_host_solver_result  = wait for the slot's event -> pointers into its pinned result
+// with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
+// consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
+// DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+struct DgcnHostSolver {
+    struct Slot {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        hipEvent_t copied = nullptr;  // the batch has arrived on the device (recorded on the shared copy stream)
+        void* in_host = nullptr;   // pinned: the packed batch
+        void* in_dev = nullptr;
+        size_t in_cap = 0;
+        void* out_host = nullptr;  // pinned: totals | rounds | status | state
+        void* out_dev = nullptr;
+        size_t out_cap = 0;
+        int cap_nodes = 0, cap_graphs = 0;
+        void* ws = nullptr;
+        size_t ws_cap = 0;
+        size_t off_totals = 0, off_scores = 0, off_rounds = 0, off_status = 0, off_state = 0, out_bytes = 0;
+        int num_nodes = 0, num_graphs = 0;
+        bool busy = false;
+    };
+    bool lgs_only = false;  // no model: priority = weight, the plain local greedy search (heuristics.py:77-116)
+    DgcnModel model;
+    std::vector<DgcnLayer> layers;
+    const double* table = nullptr;
+    int table_len = 0;
+    int predict_mwis = 1;
+    float x_const = 1.0f;
+    int pack_threads = 0;
+    int want_scores = 0;
+    int device = 0;
+    int next = 0;
+    // every host-to-device copy goes through ONE stream: copies issued round-robin on several streams ran at half the
+    // rate on MI355X (tools/micro/overlap.hip); the slot's own stream waits for `copied` and runs kernel + copy back
+    hipStream_t copy_stream = nullptr;
+    std::vector<Slot> slots;
+};
+
+namespace dgcn {
+
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+static void free_in(DgcnHostSolver::Slot& s) {
+    if (s.in_host) (void)hipHostFree(s.in_host);
+    if (s.in_dev) (void)hipFree(s.in_dev);
+    s.in_host = s.in_dev = nullptr;
+    s.in_cap = 0;
+}
+
+static void free_out(DgcnHostSolver::Slot& s) {
+    if (s.out_host) (void)hipHostFree(s.out_host);
+    if (s.out_dev) (void)hipFree(s.out_dev);
+    s.out_host = s.out_dev = nullptr;
+    s.out_cap = 0;
+}
+
+static int ensure_in(DgcnHostSolver::Slot& s, size_t bytes) {
+    if (bytes <= s.in_cap) return DGCN_OK;
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    free_in(s);
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&s.in_host, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&s.in_dev, cap) != hipSuccess) {
+        free_in(s);
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of staging memory", cap);
+    }
+    s.in_cap = cap;
+    return DGCN_OK;
+}
+
+// result layout, widest type first, every array 16-byte aligned:
+// totals f64[B] | scores f32[N] (optional) | rounds i32[B] | status i32 | state u8[N]
+static int ensure_out(DgcnHostSolver::Slot& s, int nodes, int graphs, bool want_scores) {
+    if (nodes <= s.cap_nodes && graphs <= s.cap_graphs && s.out_dev) return DGCN_OK;
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    free_out(s);
+    const int cn = nodes + nodes / 4 + 64, cg = graphs + graphs / 4 + 8;
+    s.off_totals = 0;
+    s.off_scores = align16((size_t)cg * 8);
+    s.off_rounds = s.off_scores + (want_scores ? align16((size_t)cn * 4) : 0);
+    s.off_status = s.off_rounds + align16((size_t)cg * 4);
+    s.off_state = s.off_status + 16;
+    s.out_bytes = s.off_state + align16((size_t)cn);
+    if (hipHostMalloc(&s.out_host, s.out_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&s.out_dev, s.out_bytes) != hipSuccess) {
+        free_out(s);
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of result memory", s.out_bytes);
+    }
+    if (hipMemset(s.out_dev, 0, s.out_bytes) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver: hipMemset failed");
+    s.out_cap = s.out_bytes;
+    s.cap_nodes = cn;
+    s.cap_graphs = cg;
+    return DGCN_OK;
+}
+
+static int ensure_ws(DgcnHostSolver::Slot& s, size_t bytes) {
+    if (bytes <= s.ws_cap) return DGCN_OK;
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.ws) (void)hipFree(s.ws);
+    s.ws = nullptr;
+    s.ws_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 256;
+    if (hipMalloc(&s.ws, cap) != hipSuccess) return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of scratch", cap);
+    s.ws_cap = cap;
+    return DGCN_OK;
+}
+
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" {
+
+int dgcn_host_solver_create(const DgcnModel* model, const double* dinv_table, int32_t table_len, int32_t predict_mwis,
+                            float x_const, int32_t want_scores, int32_t depth, int32_t pack_threads, DgcnHostSolver** out) {
+    if ((model && (!model->layers_host || model->num_layers < 1 || !dinv_table || table_len < 1)) || !out || depth < 1 || depth > 64)
+        return fail(DGCN_ERR_ARG, "dgcn_host_solver_create: bad argument");
+    DgcnHostSolver* h = new DgcnHostSolver;
+    h->lgs_only = model == nullptr;
+    h->model = DgcnModel{};
+    if (model) {
+        h->layers.assign(model->layers_host, model->layers_host + model->num_layers);  // the descriptors are copied, the
+        h->model = *model;                                                              // weights they point at are not
+        h->model.layers_host = h->layers.data();
+    }
+    h->table = dinv_table;
+    h->table_len = table_len;
+    h->predict_mwis = predict_mwis;
+    h->x_const = x_const;
+    h->pack_threads = pack_threads;
+    h->want_scores = (want_scores && model) ? 1 : 0;
+    (void)hipGetDevice(&h->device);
+    h->slots.resize(depth);
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        dgcn_host_solver_destroy(h);
+        return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver_create: cannot create a stream");
+    }
+    for (auto& s : h->slots) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+            dgcn_host_solver_destroy(h);
+            return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver_create: cannot create a stream / event");
+        }
+    }
+    *out = h;
+    return DGCN_OK;
+}
+
+void dgcn_host_solver_destroy(DgcnHostSolver* h) {
+    if (!h) return;
+    for (auto& s : h->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        free_in(s);
+        free_out(s);
+        if (s.ws) (void)hipFree(s.ws);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    delete h;
+}
+
+int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, const void* const* indices_host,
+                            const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                            int32_t index_bytes) {
+    if (!h || num_graphs < 0) return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: bad argument");
+    const int k = h->next;
+    DgcnHostSolver::Slot& s = h->slots[k];
+    if (s.busy)
+        return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: slot %d still holds an unread result (read it before submitting %zu more batches)",
+                    k, h->slots.size());
+    DgcnPackInfo info;
+    int rc = dgcn_pack_measure(indptr_host, num_nodes_host, num_graphs, index_bytes, weights_host ? 1 : 0, &info, nullptr);
+    if (rc) return rc;
+    if ((rc = ensure_in(s, (size_t)info.total_bytes))) return rc;
+    if (h->lgs_only && !weights_host) return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: the greedy search needs weights");
+    int threads = h->pack_threads;
+    if (threads <= 0) threads = 8;
+    rc = pack_batch(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, s.in_host, s.in_cap, &info,
+                    threads, h->lgs_only);
+    if (rc) return rc;
+    if (!h->lgs_only && info.max_degree >= h->table_len)
+        return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: vertex degree %d beyond the d^-1/2 table (%d entries)", info.max_degree,
+                    h->table_len);
+    char* base = static_cast<char*>(s.in_dev);
+    DgcnBatch b;
+    b.num_graphs = info.num_graphs;
+    b.num_nodes = info.num_nodes;
+    b.num_edges = info.num_edges;
+    b.max_nodes = info.max_nodes;
+    b.max_graph_edges = info.max_graph_edges;
+    b.graph_ptr = reinterpret_cast<const int32_t*>(base + info.off_graph_ptr);
+    b.row_ptr = reinterpret_cast<const int32_t*>(base + info.off_row_ptr);
+    b.col_idx = reinterpret_cast<const int32_t*>(base + info.off_col_idx);
+    if (!h->lgs_only && !dgcn_solve_supported(&b, &h->model))
+        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_host_solver_submit: this model / batch shape is outside the fused kernel");
+    if ((rc = ensure_out(s, info.num_nodes, info.num_graphs, h->want_scores != 0))) return rc;
+    if (!h->lgs_only) {
+        const size_t need = dgcn_solve_workspace(&b, &h->model);
+        if ((rc = ensure_ws(s, need))) return rc;
+    }
+    s.num_nodes = info.num_nodes;
+    s.num_graphs = info.num_graphs;
+    if (info.num_graphs > 0 && info.num_nodes > 0) {
+        if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
+            if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
+        } else if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
+                   hipEventRecord(s.copied, h->copy_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess) {
+            return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
+        }
+        char* ob = static_cast<char*>(s.out_dev);
+        const double* wdev = info.off_weights >= 0 ? reinterpret_cast<const double*>(base + info.off_weights) : nullptr;
+        if (h->lgs_only)
+            rc = dgcn_lgs_batch(&b, wdev, nullptr, nullptr, 0, reinterpret_cast<uint8_t*>(ob + s.off_state),
+                                reinterpret_cast<int32_t*>(ob + s.off_rounds), nullptr, nullptr, wdev,
+                                reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.stream);
+        else
+        rc = dgcn_solve_batch(&b, &h->model, h->table, h->table_len, nullptr, h->x_const,
+                              info.off_weights >= 0 ? reinterpret_cast<const double*>(base + info.off_weights) : nullptr,
+                              h->predict_mwis, h->want_scores ? reinterpret_cast<float*>(ob + s.off_scores) : nullptr,
+                              reinterpret_cast<uint8_t*>(ob + s.off_state),
+                              reinterpret_cast<int32_t*>(ob + s.off_rounds), reinterpret_cast<double*>(ob + s.off_totals),
+                              reinterpret_cast<int32_t*>(ob + s.off_status), s.ws, s.ws_cap, s.stream);
+        if (rc) return rc;
+        // one copy back: everything up to the end of the used part of `state`
+        const size_t used = s.off_state + (size_t)info.num_nodes;
+        if (hipMemcpyAsync(s.out_host, s.out_dev, used, hipMemcpyDeviceToHost, s.stream) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: device-to-host copy failed");
+    } else {  // nothing to launch: graphs without vertices have total 0 after 0 rounds
+        std::memset(s.out_host, 0, s.off_state);
+    }
+    if (hipEventRecord(s.done, s.stream) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: hipEventRecord failed");
+    s.busy = true;
+    h->next = (k + 1) % (int)h->slots.size();
+    return k;
+}
+
+int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** state, const double** totals,
+                            const int32_t** rounds, const float** scores, int32_t* status_bits, int32_t* num_nodes,
+                            int32_t* num_graphs) {
+    if (!h || slot < 0 || slot >= (int)h->slots.size()) return fail(DGCN_ERR_ARG, "dgcn_host_solver_result: bad slot");
+    DgcnHostSolver::Slot& s = h->slots[slot];
+    if (!s.busy) return fail(DGCN_ERR_ARG, "dgcn_host_solver_result: slot %d holds no result", slot);
+    if (hipEventSynchronize(s.done) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
+    s.busy = false;
+    const char* oh = static_cast<const char*>(s.out_host);
+    const int32_t bits = *reinterpret_cast<const int32_t*>(oh + s.off_status);
+    if (state) *state = reinterpret_cast<const uint8_t*>(oh + s.off_state);
+    if (totals) *totals = reinterpret_cast<const double*>(oh + s.off_totals);
+    if (rounds) *rounds = reinterpret_cast<const int32_t*>(oh + s.off_rounds);
+    if (scores) *scores = h->want_scores ? reinterpret_cast<const float*>(oh + s.off_scores) : nullptr;
+    if (status_bits) *status_bits = bits;
+    if (num_nodes) *num_nodes = s.num_nodes;
+    if (num_graphs) *num_graphs = s.num_graphs;
+    if (bits) {  // the status word accumulates: clear it for the slot's next batch
+        (void)hipMemsetAsync(static_cast<char*>(s.out_dev) + s.off_status, 0, 4, s.stream);
+    }
+    return DGCN_OK;
+}
+
+}  // extern "C"

@@ -132,7 +132,7 @@ static int measure_t(const void* const* indptr, const int32_t* num_nodes, int B,
 
 template <typename I>
 static int pack_t(const void* const* indptr, const void* const* indices, const double* const* weights,
-                  const int32_t* num_nodes, int B, char* dst, DgcnPackInfo* info, int threads) {
+                  const int32_t* num_nodes, int B, char* dst, DgcnPackInfo* info, int threads, bool reject_self_loops) {
     int32_t* graph_ptr = reinterpret_cast<int32_t*>(dst + info->off_graph_ptr);
     int32_t* row_ptr = reinterpret_cast<int32_t*>(dst + info->off_row_ptr);
     int32_t* col_idx = reinterpret_cast<int32_t*>(dst + info->off_col_idx);
@@ -193,13 +193,24 @@ static int pack_t(const void* const* indptr, const void* const* indices, const d
             ok &= eg >= prev;
             if (!ok) { bad_graph = g; bad_kind = 1; continue; }
             int32_t* cc = col_idx + e0;
-            unsigned range_bad = 0;
-            for (int64_t j = 0; j < eg; ++j) {
-                const int64_t u = (int64_t)c[j];
-                range_bad |= (unsigned)(u < 0) | (unsigned)(u >= ng);
-                cc[j] = (int32_t)(u + n0);
+            unsigned range_bad = 0, self_bad = 0;
+            if (reject_self_loops) {  // the plain greedy kernel has no status bit for them and would never finish
+                for (int v = 0; v < ng; ++v)
+                    for (int64_t j = (int64_t)p[v]; j < (int64_t)p[v + 1]; ++j) {
+                        const int64_t u = (int64_t)c[j];
+                        range_bad |= (unsigned)(u < 0) | (unsigned)(u >= ng);
+                        self_bad |= (unsigned)(u == v);
+                        cc[j] = (int32_t)(u + n0);
+                    }
+            } else {
+                for (int64_t j = 0; j < eg; ++j) {
+                    const int64_t u = (int64_t)c[j];
+                    range_bad |= (unsigned)(u < 0) | (unsigned)(u >= ng);
+                    cc[j] = (int32_t)(u + n0);
+                }
             }
             if (range_bad) { bad_graph = g; bad_kind = 2; continue; }
+            if (self_bad) { bad_graph = g; bad_kind = 5; continue; }
             if (wts) {
                 if (!weights || !weights[g]) { if (ng) { bad_graph = g; bad_kind = 4; } continue; }
                 std::memcpy(wts + n0, weights[g], (size_t)ng * sizeof(double));
@@ -210,7 +221,7 @@ static int pack_t(const void* const* indptr, const void* const* indices, const d
     Pool::get().run(threads, work);
     if (bad_graph.load() >= 0) {
         static const char* what[] = {"", "indptr is not non-decreasing", "a column index is outside [0, n)", "indices missing",
-                                     "weights missing"};
+                                     "weights missing", "the adjacency has a self-loop (heuristics.py:94 would never terminate)"};
         return fail(DGCN_ERR_ARG, "dgcn_pack_batch: graph %d: %s", bad_graph.load(), what[bad_kind.load()]);
     }
     int md = 0;
@@ -232,10 +243,10 @@ extern "C" int dgcn_pack_measure(const void* const* indptr_host, const int32_t* 
     return fail(DGCN_ERR_ARG, "dgcn_pack_measure: index_bytes must be 4 or 8");
 }
 
-extern "C" int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_host,
-                               const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
-                               int32_t index_bytes, void* staging_host, size_t staging_bytes, DgcnPackInfo* info,
-                               int32_t num_threads) {
+namespace dgcn {
+int pack_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
+               const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host,
+               size_t staging_bytes, DgcnPackInfo* info, int32_t num_threads, bool reject_self_loops) {
     if (!info || !staging_host || num_graphs < 0 || (num_graphs > 0 && (!indptr_host || !indices_host || !num_nodes_host)))
         return fail(DGCN_ERR_ARG, "dgcn_pack_batch: null argument");
     if ((int64_t)staging_bytes < info->total_bytes)
@@ -247,8 +258,19 @@ extern "C" int dgcn_pack_batch(const void* const* indptr_host, const void* const
     }
     char* dst = static_cast<char*>(staging_host);
     if (index_bytes == 4)
-        return pack_t<int32_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads);
+        return pack_t<int32_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads,
+                               reject_self_loops);
     if (index_bytes == 8)
-        return pack_t<int64_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads);
+        return pack_t<int64_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, num_threads,
+                               reject_self_loops);
     return fail(DGCN_ERR_ARG, "dgcn_pack_batch: index_bytes must be 4 or 8");
+}
+}  // namespace dgcn
+
+extern "C" int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_host,
+                               const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                               int32_t index_bytes, void* staging_host, size_t staging_bytes, DgcnPackInfo* info,
+                               int32_t num_threads) {
+    return dgcn::pack_batch(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, staging_host,
+                            staging_bytes, info, num_threads, false);
 }

@@ -16,9 +16,33 @@ from . import _lib
 from .api_common import get_engine, single_batch
 
 
+_native = {}
+
+
+def _run_native(eng, adj, w):
+    """The plain search (all rounds, no statistics) behind two native calls: ``dgcn_host_solver_*`` with no model."""
+    from .api_common import as_csr
+    hs = _native.get(id(eng))
+    if hs is None:
+        from .serving import HostSolver
+        hs = _native[id(eng)] = HostSolver(eng, None, depth=1)
+    a = as_csr(adj)
+    if a.shape[0] != w.size:
+        raise ValueError("adjacency has %d vertices, weights %d" % (a.shape[0], w.size))
+    h = hs.solve([a.indptr], [a.indices], [w], copy=False)
+    state = h["state"].copy()  # the pinned result buffer is re-used by the next call
+    return {"state": state, "mwis": set(np.flatnonzero(state == 1).tolist()), "total": np.float64(h["totals"][0]),
+            "rounds": int(h["rounds"][0])}
+
+
 def _run(adj, wts, max_rounds=0, want_stats=False, want_overhead=False):
     eng = get_engine()
     w = np.array(wts, dtype=np.float64).flatten()
+    if max_rounds == 0 and not want_stats and not want_overhead and w.size:
+        try:
+            return _run_native(eng, adj, w)
+        except (TypeError, BufferError):  # index arrays the native packer does not take: the NumPy path below
+            pass
     hb = single_batch(adj)
     if hb.num_nodes != w.size:
         raise ValueError("adjacency has %d vertices, weights %d" % (hb.num_nodes, w.size))

@@ -133,12 +133,45 @@ def _pipeline(eng, model, predict):
     return hit[1]
 
 
+_native = {}
+_NATIVE_MAX_GRAPHS = 63  # below HostBatch.size_buckets' split threshold: always one launch
+
+
+def _host_solver(eng, model, predict):
+    """Process-wide one-slot HostSolver per (engine, device model, predict) for the per-graph API calls."""
+    from .serving import HostSolver
+    dm = model.device_model(eng)
+    key = (id(eng), predict)
+    hit = _native.get(key)
+    if hit is None or hit[0] is not dm:
+        hit = (dm, HostSolver(eng, dm, depth=1, predict=predict, want_scores=True))
+        _native[key] = hit
+    return hit[1]
+
+
 def solve_csr_lists(eng, model, indptrs, indices, weights, predict: str = "mwis", mode: str = "auto", X=None):
     """Per-graph CSR arrays -> (result dict of NumPy arrays, graph_ptr).  The common case - a shape the fused kernel
     takes, no explicit features, one size class - is one native pack into pinned memory, one copy in, ONE launch, one
     copy out through the cached pipeline; everything else goes through ``solve_host_batch``."""
     w64 = [np.ascontiguousarray(w, dtype=np.float64).ravel() for w in weights]
-    if mode != "layered" and X is None and not getattr(model, "has_head", False) and len(indptrs):
+    plain = mode != "layered" and X is None and not getattr(model, "has_head", False)
+    if plain and 0 < len(indptrs) <= _NATIVE_MAX_GRAPHS:
+        # the reference's call pattern - one graph (or a handful) per call: everything behind two native calls
+        try:
+            hs = _host_solver(eng, model, predict)
+            res = hs.solve(indptrs, indices, w64)
+            res["scores"] = res["scores"].reshape(-1, 1)
+            gp = np.zeros(len(indptrs) + 1, np.int32)
+            np.cumsum(hs._nn, out=gp[1:])
+            return res, gp
+        except (TypeError, BufferError):  # mixed index widths / non-contiguous arrays: the NumPy packer handles those
+            pass
+        except _lib.DgcnError as e:
+            if "outside the fused kernel" not in str(e):
+                raise
+            if mode == "fused":
+                raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")
+    if plain and len(indptrs):
         pipe = _pipeline(eng, model, predict)
         slot = pipe._next_slot()
         try:

@@ -9,6 +9,10 @@ The reference's evaluation loop handles one graph at a time: load, ``makestate``
 ``SolvePipeline`` keeps ``depth`` slots (pinned staging, device buffers, a stream and an event each); while the
 GPU works on slot k the host packs slot k+1.  Only shapes the fused kernel takes are served here
 (``Engine.solve_supported``); other shapes go through ``mwis_dqn_call.solve_host_batch``.
+
+``HostSolver`` is the same loop behind two native calls (``dgcn_host_solver_submit`` / ``_result``, csrc/host_solver.hip):
+what a per-graph caller - ``solve_mwis(adj, weights)``, one ``sess.run`` per graph in the reference - goes through, with no
+framework call between the pack and the wait.
 """
 from __future__ import annotations
 
@@ -184,3 +188,102 @@ class SolvePipeline:
                 inflight.append(self._launch(slot, info))
             while inflight:
                 yield self.result(inflight.popleft(), copy)
+
+
+class HostSolver:
+    """``dgcn_host_solver_*`` (include/dgcn.h): pack -> copy in -> fused launch -> copy out in native code, ``depth``
+    batches in flight.  ``submit`` returns a slot number at once; ``result(slot)`` waits for it."""
+
+    def __init__(self, engine: Engine, model: Optional[DeviceModel], depth: int = 1, predict: str = "mwis",
+                 pack_threads: int = 0, want_scores: bool = False):
+        """``model=None``: no GCN, the plain local greedy search with the weights as priorities."""
+        self.eng, self.model, self.lib = engine, model, engine.lib
+        self.want_scores = want_scores and model is not None
+        self.table = engine._dinv(4095)
+        self.handle = C.c_void_p()
+        x_const = float(np.float32(1.0 / model.in_dim)) if model is not None else 1.0
+        with engine.torch.cuda.device(engine.device):
+            _lib.check(self.lib.dgcn_host_solver_create(C.byref(model.c) if model is not None else None, self.table.data_ptr(),
+                                                        int(self.table.numel()), 1 if predict == "mwis" else 0, x_const,
+                                                        1 if self.want_scores else 0, int(depth), int(pack_threads),
+                                                        C.byref(self.handle)),
+                       "dgcn_host_solver_create")
+        self.depth = int(depth)
+        self._p = [C.c_void_p() for _ in range(4)]
+        self._i = [C.c_int32() for _ in range(3)]
+
+    def close(self):
+        if self.handle:
+            self.lib.dgcn_host_solver_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, indptrs: Sequence[np.ndarray], indices: Sequence[np.ndarray], weights: Optional[Sequence[np.ndarray]]) -> int:
+        """Arrays must be contiguous, indptr / indices all int32 or all int64, weights float64 (TypeError otherwise)."""
+        from .batch import _addresses
+        B = len(indptrs)
+        if len(indices) != B or (weights is not None and len(weights) != B):
+            raise ValueError("indptr / indices / weights lists differ in length")
+        ap, cp, isz = _addresses(indptrs, 0)
+        if B and int(cp[:B].min()) < 1:
+            raise ValueError("an indptr array is empty")
+        ai, ci, _ = _addresses(indices, isz)
+        nn = (cp[:B] - 1).astype(np.int32)
+        aw = None
+        if weights is not None:
+            aw, cw, _ = _addresses(weights, 64)
+            if B and not np.array_equal(cw[:B], nn):
+                raise ValueError("a weights array does not match its graph's vertex count")
+        # the last indptr entry of every graph must be the length of its indices array (the library cannot see lengths)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        info = _lib.DgcnPackInfo()
+        nnz = np.empty(max(B, 1), dtype=np.int64)
+        _lib.check(self.lib.dgcn_pack_measure(vp(ap), vp(nn), B, isz, 1 if weights is not None else 0, C.byref(info), vp(nnz)),
+                   "dgcn_pack_measure")
+        if B and not np.array_equal(ci[:B], nnz[:B]):
+            raise ValueError("an indices array does not match its indptr")
+        slot = self.lib.dgcn_host_solver_submit(self.handle, vp(ap), vp(ai), vp(aw) if aw is not None else None, vp(nn), B, isz)
+        if slot < 0:
+            _lib.check(slot, "dgcn_host_solver_submit")
+        self._nn = nn
+        return slot
+
+    def result(self, slot: int, copy: bool = True):
+        p, i = self._p, self._i
+        _lib.check(self.lib.dgcn_host_solver_result(self.handle, slot, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3]),
+                                                    C.byref(i[0]), C.byref(i[1]), C.byref(i[2])), "dgcn_host_solver_result")
+        n, B = i[1].value, i[2].value
+        Engine.check_status_bits(i[0].value)
+
+        def view(ptr, count, ctype, dtype):
+            if count == 0 or not ptr.value:
+                return np.zeros(0, dtype)
+            a = np.frombuffer((ctype * count).from_address(ptr.value), dtype=dtype)
+            return a.copy() if copy else a
+        out = {"state": view(p[0], n, C.c_uint8, np.uint8), "totals": view(p[1], B, C.c_double, np.float64),
+               "rounds": view(p[2], B, C.c_int32, np.int32)}
+        if self.want_scores:
+            out["scores"] = view(p[3], n, C.c_float, np.float32)
+        return out
+
+    def solve(self, indptrs, indices, weights, copy: bool = True):
+        return self.result(self.submit(indptrs, indices, weights), copy)
+
+    def solve_many(self, batches, copy: bool = True, depth: Optional[int] = None):
+        """Generator: an iterable of (indptrs, indices, weights) batches -> results in order, up to ``depth`` (default: all
+        slots) batches in flight.  ``submit`` packs on the library's worker threads and returns as soon as the copies and
+        the launch are queued, so batch k + 1 is packed while the GPU works on batch k."""
+        from collections import deque
+        inflight = deque()
+        depth = int(depth or self.depth)
+        for b in batches:
+            if len(inflight) == depth:
+                yield self.result(inflight.popleft(), copy)
+            inflight.append(self.submit(*b))
+        while inflight:
+            yield self.result(inflight.popleft(), copy)

@@ -287,6 +287,32 @@ int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, co
                               int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ---- host to host: the reference's call pattern (one graph, or one directory of graphs, per call) -----------
+ * mwis_dqn_call.py:140-143 / mwis_gdpg_call.py:211-216 run one graph per sess.run; mwis_dqn_test.py:304-321 walks a
+ * directory.  A DgcnHostSolver keeps `depth` slots of pinned staging memory, device buffers, a stream and an event:
+ *   submit: dgcn_pack_batch into the slot's pinned memory -> one host-to-device copy -> dgcn_solve_batch -> one
+ *           device-to-host copy, all asynchronous; returns the slot index (>= 0) or a DGCN_ERR_* code (< 0)
+ *   result: waits for that slot; hands out pointers into its pinned result memory (valid until the slot's next submit):
+ *           state[num_nodes] (0 undecided / 1 in the set / 2 excluded), totals[num_graphs], rounds[num_graphs],
+ *           scores[num_nodes] when created with want_scores
+ * Up to `depth` batches may be in flight; slots are used round-robin and a slot must be read before it is re-used.
+ * `model` descriptors are copied, the DEVICE weights they point at and `dinv_table` (DEVICE, float64 d^-1/2) must outlive
+ * the object.  All graph pointers are HOST pointers as in dgcn_pack_batch; nothing is kept after submit returns.
+ * Shapes outside the fused kernel: DGCN_ERR_UNSUPPORTED (use the separate calls).  One thread at a time per object.
+ * model == NULL: no GCN - the plain local greedy search with the weights as priorities (heuristics.py:77-116,
+ * local_greedy_search / greedy_search; dgcn_lgs_batch underneath, any graph size); dinv_table is ignored, weights are
+ * required and an adjacency with a self-loop is refused at submit (the reference never terminates on one). */
+typedef struct DgcnHostSolver DgcnHostSolver;
+int dgcn_host_solver_create(const DgcnModel* model, const double* dinv_table, int32_t table_len, int32_t predict_mwis,
+                            float x_const, int32_t want_scores, int32_t depth, int32_t pack_threads, DgcnHostSolver** out);
+void dgcn_host_solver_destroy(DgcnHostSolver* solver);
+int dgcn_host_solver_submit(DgcnHostSolver* solver, const void* const* indptr_host, const void* const* indices_host,
+                            const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
+                            int32_t index_bytes);
+int dgcn_host_solver_result(DgcnHostSolver* solver, int32_t slot, const uint8_t** state, const double** totals,
+                            const int32_t** rounds, const float** scores /* NULL unless created with want_scores */,
+                            int32_t* status_bits, int32_t* num_nodes, int32_t* num_graphs);
+
 /* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
  * enable(1) makes every launch of the named kernel families record an event pair;
  * read() synchronises those events and returns the summed milliseconds and launch count. */

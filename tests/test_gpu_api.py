@@ -857,6 +857,61 @@ def test_serving_pipeline_host_to_host(engine, golden):
     assert np.array_equal(pipe.result(pipe.submit(*batches[1]))["state"], refs[1]["state"])  # the pipeline recovers
 
 
+def test_native_host_solver(engine, golden):
+    """dgcn_host_solver_* (csrc/host_solver.hip) through distgcn_amd.serving.HostSolver: the whole host-to-host call in
+    native code.  Same sets / rounds / totals / scores as the twin for ragged batches and for single graphs, two batches
+    in flight, a slot must be read before re-use and cannot be read twice, data faults surface at result() and the object
+    recovers, shapes outside the fused kernel are refused, empty graphs are fine."""
+    from distgcn_amd import datagen
+    from distgcn_amd._lib import DgcnError
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.serving import HostSolver
+    from oracle import ctwin
+    layers = golden.layers(M20)
+    dm = DeviceModel(layers, engine.device)
+
+    def lists(hb):
+        ps, cs, ws = [], [], []
+        for n0, n1 in hb.graph_slices():
+            e0, e1 = int(hb.row_ptr[n0]), int(hb.row_ptr[n1])
+            ps.append(np.ascontiguousarray(hb.row_ptr[n0:n1 + 1] - e0)); cs.append(np.ascontiguousarray(hb.col_idx[e0:e1] - n0))
+            ws.append(np.ascontiguousarray(hb.weights[n0:n1]))
+        return ps, cs, ws
+    hs = HostSolver(engine, dm, depth=2, want_scores=True)
+    batches, refs = [], []
+    for k, (count, n) in enumerate([(40, 200), (1, 200), (7, 60), (1, 1), (33, 120)]):
+        hb = datagen.er_batch(count, n, 0.1, first_index=3000 + 100 * k)
+        batches.append(lists(hb))
+        refs.append(ctwin.solve(hb, layers))
+    for b, r in zip(batches, refs):
+        g = hs.solve(*b)
+        assert np.array_equal(g["state"], r["state"]) and np.array_equal(g["rounds"], r["rounds"])
+        assert np.allclose(g["totals"], r["totals"], rtol=1e-12, atol=0)
+        assert np.array_equal(g["scores"].view(np.uint32), np.asarray(r["scores"], np.float32).ravel().view(np.uint32))
+    s0, s1 = hs.submit(*batches[0]), hs.submit(*batches[4])  # two in flight
+    with pytest.raises(DgcnError, match="unread result"):
+        hs.submit(*batches[1])
+    assert np.array_equal(hs.result(s1)["state"], refs[4]["state"]) and np.array_equal(hs.result(s0)["state"], refs[0]["state"])
+    with pytest.raises(DgcnError, match="holds no result"):
+        hs.result(s0)
+    bad = (batches[2][0], batches[2][1], [w.copy() for w in batches[2][2]])
+    bad[2][3][0] = np.nan
+    with pytest.raises(DgcnError, match="NaN"):
+        hs.solve(*bad)
+    assert np.array_equal(hs.solve(*batches[2])["state"], refs[2]["state"])  # recovers
+    big = datagen.er_batch(1, 600, 0.01, first_index=77)
+    with pytest.raises(DgcnError, match="outside the fused kernel"):
+        hs.solve(*lists(big))
+    empty = (np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    g = hs.solve([empty[0], batches[3][0][0]], [empty[1], batches[3][1][0]], [empty[2], batches[3][2][0]])
+    assert g["state"].size == 1 and g["totals"].size == 2 and g["totals"][0] == 0.0 and g["rounds"][0] == 0
+    g = hs.solve([empty[0]], [empty[1]], [empty[2]])
+    assert g["state"].size == 0 and g["totals"].tolist() == [0.0] and g["rounds"].tolist() == [0]
+    with pytest.raises(ValueError, match="does not match"):
+        hs.submit([batches[1][0][0]], [batches[1][1][0][:-2]], [batches[1][2][0]])
+    hs.close()
+
+
 def _ref_exec():
     import json
     from conftest import GOLDEN

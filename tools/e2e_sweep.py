@@ -29,3 +29,14 @@ for depth in (2, 3, 4):
         for _ in pipe.solve_many(((ps, cs, ws) for _ in range(300)), copy=False): pass
         dt = time.perf_counter() - t
         print("depth %d pack threads %2d: %.3f ms per batch, %.2f M graphs/s" % (depth, th, dt / 300 * 1e3, 500 * 300 / dt / 1e6))
+
+from distgcn_amd.serving import HostSolver
+for depth in (2, 3, 4):
+    for th in (4, 8, 16):
+        hs = HostSolver(eng, dm, depth=depth, pack_threads=th)
+        for _ in hs.solve_many(((ps, cs, ws) for _ in range(20)), copy=False): pass
+        t = time.perf_counter()
+        for _ in hs.solve_many(((ps, cs, ws) for _ in range(300)), copy=False): pass
+        dt = time.perf_counter() - t
+        print("native depth %d pack threads %2d: %.3f ms per batch, %.2f M graphs/s" % (depth, th, dt / 300 * 1e3, 500 * 300 / dt / 1e6))
+        hs.close()
