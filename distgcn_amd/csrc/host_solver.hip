@@ -55,6 +55,17 @@ namespace dgcn {
 
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// the object's buffers and streams live on the device that was current at create: make it current for a call
+struct DeviceScope {
+    explicit DeviceScope(int want) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = want;
+        if (prev != want) (void)hipSetDevice(want);
+        else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    int prev = -1;
+};
+
 static void free_in(DgcnHostSolver::Slot& s) {
     if (s.in_host) (void)hipHostFree(s.in_host);
     if (s.in_dev) (void)hipFree(s.in_dev);
@@ -163,6 +174,7 @@ int dgcn_host_solver_create(const DgcnModel* model, const double* dinv_table, in
 
 void dgcn_host_solver_destroy(DgcnHostSolver* h) {
     if (!h) return;
+    DeviceScope on_device(h->device);
     for (auto& s : h->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         free_in(s);
@@ -180,6 +192,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
                             const double* const* weights_host, const int32_t* num_nodes_host, int32_t num_graphs,
                             int32_t index_bytes) {
     if (!h || num_graphs < 0) return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: bad argument");
+    DeviceScope on_device(h->device);
     const int k = h->next;
     DgcnHostSolver::Slot& s = h->slots[k];
     if (s.busy)
@@ -258,6 +271,7 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
     if (!h || slot < 0 || slot >= (int)h->slots.size()) return fail(DGCN_ERR_ARG, "dgcn_host_solver_result: bad slot");
     DgcnHostSolver::Slot& s = h->slots[slot];
     if (!s.busy) return fail(DGCN_ERR_ARG, "dgcn_host_solver_result: slot %d holds no result", slot);
+    DeviceScope on_device(h->device);
     if (hipEventSynchronize(s.done) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
     s.busy = false;
     const char* oh = static_cast<const char*>(s.out_host);

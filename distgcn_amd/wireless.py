@@ -161,6 +161,92 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
              "scheduled": cnt_h[:, i].astype(np.int64)} for i in range(I)]
 
 
+def simulate_seq(adj_lists: Sequence[Sequence], traffics: Sequence[Dict[str, np.ndarray]], algo: str = "DGCN-LGS-Seq", agent=None
+                 ) -> List[Dict[str, np.ndarray]]:
+    """The channel-by-channel schedulers of ``wireless_dqn_test_mc.py:292-354`` (``--opt`` 5, 6, 7): in every slot the
+    channels are served one after the other - channel ``ic`` is scheduled on ITS conflict graph ``adj_lists[i][ic]``
+    (``nflows x nflows``) with the weights ``queue estimate x rate``, links without weight left out, and the queues the
+    next channel sees are reduced by what the links just scheduled can send.
+
+        "LGS-Seq"       ``local_greedy_search``                 (:292-311)
+        "DGCN-LGS-Seq"  ``dqn_agent.solve_mwis``               (:312-332)
+        "CGCN-RS-Seq"   ``dqn_agent.solve_mwis_rollout_wrap``  (:333-353)
+
+    The reference loops over instances, slots and channels with one solver call each; here the calls of all instances for
+    the same (slot, channel) are one batch (they are independent).  Weights are ``'qr'`` (the script asserts it).  The
+    bookkeeping after the channel loop is the reference's expression on the same Python sets (:358-366): when a link ends
+    up scheduled on several channels its capacity is the rate of whichever channel comes last in ``list(mwis)``.
+    -> per instance ``{"queue", "depart": [T, nflows], "scheduled": [T]}``."""
+    from . import heuristics
+    if algo not in ("LGS-Seq", "DGCN-LGS-Seq", "CGCN-RS-Seq"):
+        raise ValueError("algo must be 'LGS-Seq', 'DGCN-LGS-Seq' or 'CGCN-RS-Seq'")
+    if algo != "LGS-Seq" and agent is None:
+        raise ValueError("%s needs an agent" % algo)
+    if algo == "CGCN-RS-Seq" and not hasattr(agent, "solve_mwis_rollout_wrap"):
+        raise ValueError("CGCN-RS-Seq needs mwis_gdpg_call.DQNAgent (solve_mwis_rollout_wrap)")
+    I = len(adj_lists)
+    T = int(traffics[0]["arrival_pkts"].shape[0])
+    flows = [int(tr["arrival_pkts"].shape[1]) for tr in traffics]
+    chans = [int(tr["link_rates"].shape[2]) for tr in traffics]
+    lists = [[as_csr(a) for a in al] for al in adj_lists]
+    for al, f, k, tr in zip(lists, flows, chans, traffics):
+        if len(al) != k or any(a.shape[0] != f for a in al) or tr["arrival_pkts"].shape[0] != T or tr["link_rates"].shape[:2] != (T, f):
+            raise ValueError("conflict graphs / traffic shapes disagree")
+    queue = [np.zeros((T, f)) for f in flows]
+    dep = [np.zeros((T, f)) for f in flows]
+    sched = np.zeros((T, I), dtype=np.int64)
+
+    def solve_batch(jobs):
+        """jobs: (adjacency, weights) with all weights non-zero -> list of sets"""
+        if not jobs:
+            return []
+        if algo == "LGS-Seq":
+            return [heuristics.local_greedy_search(a, w)[0] for a, w in jobs]
+        if algo == "DGCN-LGS-Seq":
+            if hasattr(agent, "solve_mwis_batch"):
+                return [r[0] for r in agent.solve_mwis_batch([a for a, _ in jobs], [w for _, w in jobs])]
+            return [agent.solve_mwis(a, w)[0] for a, w in jobs]
+        return [agent.solve_mwis_rollout_wrap(a, w)[0] for a, w in jobs]
+
+    for t in range(1, T):
+        qa, mwis = [], []
+        for i in range(I):
+            queue[i][t] = queue[i][t - 1] + traffics[i]["arrival_pkts"][t]
+            qa.append(np.multiply(np.expand_dims(queue[i][t], axis=1), np.ones((flows[i], chans[i]))))
+            mwis.append(set())
+        for ic in range(max(chans)):
+            jobs, meta = [], []
+            for i in range(I):
+                if ic >= chans[i]:
+                    continue
+                wts_ic = qa[i][:, ic] * traffics[i]["link_rates"][t, :, ic]
+                wts_idx, = np.nonzero(wts_ic)
+                if wts_idx.size:
+                    a = lists[i][ic]
+                    jobs.append((as_csr(a[wts_idx, :][:, wts_idx]), wts_ic[wts_idx]))
+                meta.append((i, wts_idx, bool(wts_idx.size)))
+            sols = iter(solve_batch(jobs))
+            for i, wts_idx, has in meta:
+                mwis_c = next(sols) if has else set()
+                mwis_ic = np.array(wts_idx[list(mwis_c)]) + ic * flows[i]
+                mwis[i] = mwis[i].union(set(mwis_ic.flatten()))
+                if ic + 1 < chans[i]:
+                    mwis_ls = wts_idx[list(mwis_c)]
+                    depart_est = np.minimum(qa[i][:, ic], traffics[i]["link_rates"][t, :, ic])
+                    qa[i][:, ic + 1] = qa[i][:, ic]
+                    qa[i][mwis_ls, ic + 1] -= depart_est[mwis_ls]
+        for i in range(I):
+            schedule_mv = np.array(list(mwis[i]), dtype=np.int64)
+            link_rates_ts = np.reshape(traffics[i]["link_rates"][t, :, :], flows[i] * chans[i], order="F")
+            capacity = np.zeros(flows[i])
+            if schedule_mv.size:
+                capacity[schedule_mv % flows[i]] = link_rates_ts[schedule_mv]
+            dep[i][t] = np.minimum(qa[i][:, 0], capacity)
+            queue[i][t] = queue[i][t] - dep[i][t]
+            sched[t, i] = schedule_mv.size
+    return [{"queue": queue[i], "depart": dep[i], "scheduled": sched[:, i]} for i in range(I)]
+
+
 def summarize(result: Dict[str, np.ndarray]) -> Dict[str, float]:
     """The per-run metrics the reference writes to its CSV (``wireless_dqn_test.py:303-336``)."""
     qm = result["queue"]

@@ -708,6 +708,63 @@ def test_wireless_simulation_iterative_schedulers(engine, algo):
         assert sol == want and float(np.asarray(tot).ravel()[0]) == pytest.approx(float(wtot[0]), rel=1e-12), name
 
 
+@pytest.mark.parametrize("algo", ["LGS-Seq", "DGCN-LGS-Seq", "CGCN-RS-Seq"])
+def test_wireless_multichannel_sequential_schedulers(engine, algo):
+    """wireless_dqn_test_mc.py:292-354 (--opt 5/6/7): channels scheduled one after the other on their own conflict graphs,
+    queue estimates handed from channel to channel; all instances' calls of one (slot, channel) batched; against the
+    per-instance CPU restatement (oracle/ref_wireless.simulate_seq_one) with the oracle's solvers on the twin's scores."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen, wireless
+    from distgcn_amd.batch import HostBatch
+    from oracle import ctwin, ref_numpy as orc, ref_wireless
+    rng = np.random.default_rng(79)
+    if algo == "CGCN-RS-Seq":
+        from distgcn_amd.mwis_gdpg_call import DQNAgent
+        agent = DQNAgent(_flags(num_layer=3), seed=5)
+    else:
+        from distgcn_amd.mwis_dqn_call import DQNAgent
+        agent = DQNAgent(1, flags=_flags(num_layer=3))
+    layers = agent.model.layers
+    fn = _twin_scores_fn(layers)
+    adj_lists, traffics = [], []
+    for i, (nflows, n_ch, p) in enumerate([(30, 3, 0.1), (24, 1, 0.12), (40, 2, 0.05)]):
+        al = []
+        for c in range(n_ch):
+            indptr, indices = datagen.er_graph(nflows, p, rng)
+            al.append(sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(nflows, nflows)))
+        adj_lists.append(al)
+        traffics.append(wireless.make_traffic(nflows, 14, 0.05, n_ch=n_ch, seed=20 + i))
+
+    def greedy_fn(adj, w):
+        adj = sp.csr_matrix(adj); adj.sort_indices()
+        st, _ = orc.lgs_vectorised(adj.indptr, adj.indices, w)
+        return set(np.flatnonzero(st == 1).tolist())
+
+    def dgcn_fn(adj, w):  # all weights non-zero here: GCN, priority, local greedy
+        sub = sp.csr_matrix(adj); sub.sort_indices()
+        hb = HostBatch.from_csr_lists([sub.indptr.astype(np.int64)], [sub.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        prio = ctwin.forward(lap, layers, hb.num_nodes)[:, 0].astype(np.float64) * w
+        st, _ = orc.lgs_vectorised(sub.indptr, sub.indices, prio)
+        return set(np.flatnonzero(st == 1).tolist())
+
+    def rs_fn(adj, w):
+        return orc.solve_wrap(orc.solve_mwis_rollout, fn, sp.csr_matrix(adj), w, b=16)[0]
+
+    solve = {"LGS-Seq": greedy_fn, "DGCN-LGS-Seq": dgcn_fn, "CGCN-RS-Seq": rs_fn}[algo]
+    got = wireless.simulate_seq(adj_lists, traffics, algo=algo, agent=agent)
+    multi = 0
+    for i in range(len(adj_lists)):
+        want = ref_wireless.simulate_seq_one(adj_lists[i], traffics[i]["arrival_pkts"], traffics[i]["link_rates"], solve)
+        assert np.array_equal(got[i]["queue"], want["queue"]), i
+        assert np.array_equal(got[i]["depart"], want["depart"]), i
+        assert got[i]["depart"].sum() > 0
+        multi += int(got[i]["scheduled"].max() > traffics[i]["arrival_pkts"].shape[1] // 4)
+    assert multi > 0
+    with pytest.raises(ValueError, match="shapes disagree"):
+        wireless.simulate_seq([adj_lists[0][:2]], traffics[:1], algo=algo, agent=agent)
+
+
 def _example_inputs():
     """The inputs examples/solve_batch.cpp builds (same 64-bit LCG stream)."""
     from distgcn_amd.batch import HostBatch
