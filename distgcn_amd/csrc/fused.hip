@@ -76,7 +76,6 @@ struct FusedArgs {
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
-    int32_t lane_map;   // gather phase: 1 = lanes rotated by 4 inside each 16-lane row (two whole rows per ds_read_b128 bank group)
     int32_t flags_off;  // byte offset of the block-OR scratch words inside the dynamic LDS; a 128-byte zero row follows
     // residual-graph variant (k_fused<true>): `state` is in/out, vertices with state != 0 are not part of the graph
     int32_t feature_mode;  // 1: X[v][*] = (float)(w[v] / (max residual w + 1e-9)), computed here
@@ -233,18 +232,9 @@ struct RowBlocks {
     uint2 first[kMaxRowBlocks];  // record of entry kq of the row
 };
 
-// Where a lane finds entry j of the support: the global records, or - for a workgroup that has the CU (and its LDS
-// queue) to itself and whose values are in the LDS - the LDS arrays: ~100 cycles instead of an L2 round trip that a
-// lone workgroup has nothing to hide under.
-template <bool LDSMETA>
-__device__ __forceinline__ uint2 entry_record(const uint2* rec, const float* vals, const unsigned short* words, int j) {
-    if constexpr (LDSMETA) return make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
-    else return rec[j];
-}
-
-template <int BLOCK, bool LDSMETA>
+template <int BLOCK>
 __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                const uint2* rec, const float* vals, const unsigned short* words) {
+                                                const uint2* rec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     constexpr int kWaves = BLOCK / 64;
@@ -260,7 +250,7 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
             const int v = perm[slot];
             rb.v[k] = v;
             rb.ri[k] = rinfo[v];
-            rb.first[k] = entry_record<LDSMETA>(rec, vals, words, (int)(rb.ri[k] & 0xffff) + kq);
+            rb.first[k] = rec[(rb.ri[k] & 0xffff) + kq];
         }
     }
 }
@@ -273,11 +263,10 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-template <int BLOCK, int ACT, bool LDSMETA>
+template <int BLOCK, int ACT>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
-                                                 const uint2* rec, const float* vals, const unsigned short* words,
-                                                 unsigned zrow, int diag, unsigned long long* st) {
-    (void)diag; (void)st;
+                                                 const uint2* rec, unsigned zrow, unsigned long long* st) {
+    (void)st;
 #ifdef DGCN_DIAG
 #define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == BLOCK - 64) st[i] += _t - bt; bt = _t; } while (0)
     unsigned long long bt = 0;
@@ -338,7 +327,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
             }                                                                                                  \
         }
         for (; j + 4 <= re; j += 4) {
-            const uint2 nxt = entry_record<LDSMETA>(rec, vals, words, j + 4 + kq);  // next row's entry or slack: neutralised below
+            const uint2 nxt = rec[j + 4 + kq];  // may be the next row's entry or slack: neutralised below if so
             DGCN_TRIP(4)
             cur = nxt;
         }
@@ -370,15 +359,14 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 }
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
-template <int BLOCK, bool LDSMETA>
+template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
-                                                 const float* vals, const unsigned short* words, unsigned zrow,
-                                                 int diag = 0, unsigned long long* st = nullptr) {
+                                                 unsigned zrow, unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
-    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
-    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, LDSMETA>(bias, bufA, rb, rec, vals, words, zrow, diag, st);
+    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, bufA, rb, rec, zrow, st);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, rb, rec, zrow, st);
+    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, rb, rec, zrow, st);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
@@ -703,11 +691,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     __syncthreads();  // scratch (bufA, bufB) is dead from here on
     // (Tried: a lone 1024-thread workgroup taking its entry metadata from the LDS instead of the global records - 136.0 vs
     // 132.5 us for one graph, 448 vs 455 us for the C4 share: no clear winner, one code path kept.)
-    constexpr bool kLdsMeta = false;
     // (32-wide aggregations only: a one-layer model has none)
     const bool has_wide = !(MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN)) &&
                           (a.wide_passes > 1 || (a.num_layers > 1 && a.layers[0].cout == kHid));
-    if (has_wide && !kLdsMeta) {
+    if (has_wide) {
         // the support once more as 8-byte records in global memory (L2-resident: 19 layers re-read them)
         const unsigned rl = rinfo[ng - 1];
         const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
@@ -716,7 +703,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     }
     __syncthreads();
     RowBlocks rb;
-    row_blocks_init<BLOCK, kLdsMeta>(rb, has_wide ? ng : 0, rinfo, perm, rec, vals, words);
+    row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec);
     STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
@@ -738,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK, kLdsMeta>(a.layers[p], bufA, rb, rec, vals, words, zrow);
+            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow);
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -783,14 +770,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #endif
             if (a.prio_gather) set_prio(prio_base + a.prio_gather);
 #ifdef DGCN_DIAG
-            const unsigned wmask = (unsigned)a.diag;  // bit 4: gathers without FMAs, bit 5: FMAs without gathers (experiments)
+            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-            constexpr unsigned wmask = 0u;
-#endif
-            #ifdef DGCN_DIAG
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK, kLdsMeta>(L, bufA, rb, rec, vals, words, zrow, (int)wmask, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
-#else
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK, kLdsMeta>(L, bufA, rb, rec, vals, words, zrow);
+            hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
 #endif
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
@@ -1308,7 +1290,6 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
     a.prio_gather = getenv("DGCN_FUSED_PRIOG") ? atoi(getenv("DGCN_FUSED_PRIOG")) : 1;
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 5;
-    a.lane_map = getenv("DGCN_FUSED_LANEMAP") ? atoi(getenv("DGCN_FUSED_LANEMAP")) : 1;  // measured: 224.7 -> 218.8 us on C3
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
 #endif
