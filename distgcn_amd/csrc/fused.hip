@@ -268,7 +268,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
                                                  const uint2* rec, unsigned zrow, unsigned long long* st) {
     (void)st;
 #ifdef DGCN_DIAG
-#define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == BLOCK - 64) st[i] += _t - bt; bt = _t; } while (0)
+#define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) st[i] += _t - bt; bt = _t; } while (0)
     unsigned long long bt = 0;
 #else
 #define BSTAMP(i) do { } while (0)
@@ -296,6 +296,9 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         const unsigned ri = rb.ri[k];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+        // (Tried again with the 16-row map: the row's own Z0 chunks requested here instead of after the entry walk - their
+        // round trip behind everybody's gathers costs ~400 cycles per block - but the 8 registers held through the walk spill
+        // elsewhere: 209.7 vs 206.0 us per C3 step, 134.0 vs 131.1 us for one graph.)
         BSTAMP(0);
         // Entry metadata comes from GLOBAL memory, not from the LDS: the gather phase is paced by the LDS instruction
         // stream (an LDS round trip takes ~450 cycles there: 16 waves x 8 ds_read_b128 queued), and the two metadata
@@ -352,7 +355,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         *ownB = oB;
         BSTAMP(3);
 #ifdef DGCN_DIAG
-        if (st && threadIdx.x == BLOCK - 64) { st[4] += 1; st[5] += (unsigned long long)((re - rs) >> 2); }
+        if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) { st[4] += 1; st[5] += (unsigned long long)((re - rs) >> 2); }
 #endif
     }
 #undef BSTAMP
