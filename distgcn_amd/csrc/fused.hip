@@ -84,6 +84,14 @@ struct FusedArgs {
     int32_t beam;          // greedy_mode 2: number of candidates
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
+    // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_sync()
+    int32_t cluster;
+    int32_t epoch;      // progress words count from here: values a previous launch left behind (possibly still cached in
+                        // this XCD's L2, whatever a memset from elsewhere did to the memory) are always smaller
+    int32_t num_graphs;
+    float* xz;          // [num_graphs][2][max_nodes][32] Z1 rows on their way between the workgroups of a graph
+    float* xs;          // [num_graphs][2][max_nodes] last layer: z1 scalars, then scores
+    int32_t* xflag;     // G = num_graphs rounded up to 8: [G][8] workgroup progress words, then [G][8] XCC ids
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
     FusedLayer layers[kMaxFusedLayers];
@@ -227,6 +235,7 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 // block starts with its gathers instead of three dependent round trips (perm -> rinfo -> record).
 constexpr int kMaxRowBlocks = 4;  // 512 vertices / (16 rows x 8 waves)
 struct RowBlocks {
+    int trow[kMaxRowBlocks];     // cluster variant: row of lane & 15 in block k (the transform's lane map), -1 = none
     int v[kMaxRowBlocks];        // row of this lane's slot in block k, -1 = none
     unsigned ri[kMaxRowBlocks];  // rinfo of that row
     uint2 first[kMaxRowBlocks];  // record of entry kq of the row
@@ -234,15 +243,18 @@ struct RowBlocks {
 
 template <int BLOCK>
 __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                const uint2* rec) {
+                                                const uint2* rec, int K = 1, int cw = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     constexpr int kWaves = BLOCK / 64;
     const int blocks = (ng + 15) >> 4;
 #pragma unroll
     for (int k = 0; k < kMaxRowBlocks; ++k) {
-        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
+        // (cluster variant: workgroup cw of K owns blocks cw, cw + K, ...)
+        const int blk = (k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave)) * K + cw;
         const int slot = blk * 16 + s;
+        const int tslot = blk * 16 + (lane & 15);
+        rb.trow[k] = (blk < blocks && tslot < ng) ? (int)perm[tslot] : -1;
         rb.v[k] = -1;
         rb.ri[k] = 0u;
         rb.first[k] = make_uint2(0u, 0u);
@@ -254,6 +266,125 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
         }
     }
 }
+
+// ---- cluster variant: one graph on K workgroups (one CU each) --------------------------------------------------
+// A lone workgroup's layer is 4 096 MFMA cycles on the SIMD that holds four of an N = 200 graph's 13 tiles plus one row
+// block's chain of LDS round trips; neither shrinks inside one CU, and the reference calls its agent with ONE graph.  In
+// this variant every workgroup of a graph builds the whole LDS image, but transforms and aggregates only the row blocks
+// it owns (block index mod K: each of its waves has at most one tile and one block per layer).  What it has to share is
+// Z1: it writes its rows to a double-buffered global slice, publishes the layer number, waits for the other K - 1 and
+// pulls their rows into its own bufB.  The workgroups of a graph get block indices that are equal modulo 8, i.e. the
+// same XCD and the same L2 (round-robin dispatch; checked once through HW_REG_XCC_ID, fault bit otherwise), so that
+// "visible" only means "has left the CU": s_waitcnt on the writer, L1-bypassing loads on the reader - an agent-scope
+// release would write the L2 back (tools/micro/xchg.hip: 4 - 5 K cycles per exchange this way, 14 K - 200 K with
+// __threadfence()).  Spins are bounded: a workgroup that never arrives costs a fault bit, not the machine.
+// (load and wait are ONE asm statement: the compiler does not know that the result of an inline-asm load is still in
+// flight and would otherwise be free to copy the registers before the data has arrived)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_l2_x4(const float* p0, const float* p1, const float* p2, const float* p3, float4 (&out)[4]) {
+    f32x4_t v0, v1, v2, v3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+    out[0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    out[1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    out[2] = make_float4(v2[0], v2[1], v2[2], v2[3]);
+    out[3] = make_float4(v3[0], v3[1], v3[2], v3[3]);
+}
+__device__ __forceinline__ float load_l2_scalar(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// every store of this workgroup has left the CU -> publish `seq` -> wait until all K workgroups have published it
+template <int BLOCK>
+__device__ __forceinline__ void cluster_sync(int32_t* flags, int K, int cw, int seq, int32_t* status) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[cw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < K) {
+        int spins = 0;
+        while ((int)(__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 21)) {  // ~0.3 s: somebody is not coming
+                if (status) atomicOr(status, DGCN_FAULT_CLUSTER);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the other workgroups' Z1 rows: global slice (same swizzled 128-byte rows as bufB) -> bufB
+template <int BLOCK>
+__device__ __forceinline__ void cluster_pull_rows(const float* slice, float* bufB, const unsigned short* perm, int ng, int K, int cw) {
+    const int total = ng * 8;  // 16-byte chunks, in perm order: position p belongs to block p / 16
+    for (int base = threadIdx.x; base < total; base += 4 * BLOCK) {
+        float4 v[4];
+        int dst[4];
+        const float* src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * BLOCK;
+            dst[u] = -1;
+            src[u] = slice;  // lanes without work read the slice's first bytes and drop them
+            if (i < total && ((i >> 7) % K) != cw) {  // i >> 3 = position, >> 4 more = block
+                const int row = perm[i >> 3];
+                dst[u] = row * kHid + ((i & 7) << 2);
+                src[u] = slice + dst[u];
+            }
+        }
+        load_l2_x4(src[0], src[1], src[2], src[3], v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<float4*>(bufB + dst[u]) = v[u];
+    }
+}
+
+// hidden transform of the blocks this workgroup owns: rows in perm order, one tile per wave and k; Z1 goes to bufB AND
+// to the graph's exchange slice
+template <int BLOCK>
+__device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], const RowBlocks& rb, float* bufA, float* bufB,
+                                                       float* slice) {
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < kMaxRowBlocks; ++k) {
+        if (!__any(rb.trow[k] >= 0)) continue;
+        const int row = rb.trow[k] >= 0 ? rb.trow[k] : 0;  // lanes past the graph's end feed row 0 and write nothing
+        float av[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc[ct], 0, 0, 0);
+        if (rb.trow[k] >= 0) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int chunk = (ct & 1) * 4 + kq;
+                const float4 o = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+                if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
+                else {
+                    const int off = row * kHid + ((chunk ^ keyB(row)) << 2);
+                    *reinterpret_cast<float4*>(bufB + off) = o;
+                    *reinterpret_cast<float4*>(slice + off) = o;
+                }
+            }
+        }
+    }
+}
+
+// (Tried: one progress word per tile instead of per workgroup - a wave publishes its tile as soon as its stores have left
+// the CU, the readers' waves wait for and pull two foreign tiles at a time, no workgroup barrier around the hand-over:
+// 120 - 128 us against 117 - 123 us for one to eight N = 200 graphs.  Three dependent L2 round trips - store, poll, pull -
+// are what the hand-over costs either way.)
 
 // ---- aggregation at width 32: 4 lanes x 2 float4 per row, 16 rows per wave pass, rows in `perm` order (descending
 // entry count; only the processing order changes, never the arithmetic).  Per row: sequential fmaf chain over the
@@ -361,6 +492,105 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 #undef BSTAMP
 }
 
+// ---- cluster variant of the aggregation: 8 lanes x float4 per row, 8 rows per wave, 8 entries per trip.
+// A wave's walk over a row is a chain of ~500-cycle trips whatever the load on the LDS (measured: 553 cycles per 4-entry
+// trip with four waves on the CU, 504 with sixteen), so the phase is as long as the longest row block's chain.  With the
+// CU to itself and 256 VGPRs a workgroup spreads its <= 4 tiles over all 8 waves (half a tile each), takes 8 entries per
+// trip, and keeps the rows' records in registers for the whole layer loop (no L2 round trip inside the phase).  Same
+// per-row arithmetic: sequential fmaf chain over the entries, slot by slot.
+constexpr int kRecCache = 12;  // records per lane kept in registers: the first 48 entries of a row
+struct ClusterRows {
+    int v;                  // row of this lane's slot (lane / 8), -1 = none
+    unsigned ri;            // its rinfo
+    uint2 recs[kRecCache];  // entry 4i + (lane & 3) of the row
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const unsigned* rinfo, const unsigned short* perm,
+                                                  const uint2* rec, int K, int cw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = (wave >> 1) * K + cw;                      // tile `wave / 2` of this workgroup
+    const int slot = blk * 16 + (wave & 1) * 8 + (lane >> 3);  // its lower / upper half
+    const int blocks = (ng + 15) >> 4;
+    cr.v = -1;
+    cr.ri = 0u;
+#pragma unroll
+    for (int i = 0; i < kRecCache; ++i) cr.recs[i] = make_uint2(0u, 0u);
+    if (blk < blocks && slot < ng) {
+        cr.v = perm[slot];
+        cr.ri = rinfo[cr.v];
+        const int rs = (int)(cr.ri & 0xffff), cnt = (int)(cr.ri >> 16);
+#pragma unroll
+        for (int i = 0; i < kRecCache; ++i)
+            if (4 * i < cnt) cr.recs[i] = rec[rs + 4 * i + (lane & 3)];
+    }
+}
+
+template <int BLOCK, int ACT>
+__device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* bufA, const ClusterRows& cr, const uint2* rec,
+                                                 unsigned zrow) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane & 7, kq = lane & 3;
+    const unsigned cq = (unsigned)q << 4;
+    float4 bias = make_float4(-0.f, -0.f, -0.f, -0.f);  // x + (-0.0f) == x for every x
+    if (bias_ptr) bias = *reinterpret_cast<const float4*>(bias_ptr + 4 * q);
+    if (!__any(cr.v >= 0) || cr.v < 0) return;
+    const int v = cr.v;
+    const int rs = (int)(cr.ri & 0xffff), re = rs + (int)(cr.ri >> 16);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
+    const float4 y = *own;  // the row's Z0 chunk, requested ahead of the gathers (registers are plentiful here)
+    int j = rs;
+#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, false)
+#define DGCN_PICK(x, e) ((e) == 0 ? DGCN_QB(x, 0) : (e) == 1 ? DGCN_QB(x, 1) : (e) == 2 ? DGCN_QB(x, 2) : DGCN_QB(x, 3))
+    // one trip: entries 0..3 from record r0 (lane kq of the quad holds entry kq), 4..7 from r1
+#define DGCN_TRIP8C(r0, r1)                                                                          \
+    {                                                                                                \
+        float4 z[8];                                                                                 \
+        float av[8];                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                              \
+            const unsigned w = (unsigned)(e < 4 ? DGCN_PICK(r0.y, e & 3) : DGCN_PICK(r1.y, e & 3));   \
+            av[e] = __int_as_float(e < 4 ? DGCN_PICK(r0.x, e & 3) : DGCN_PICK(r1.x, e & 3));          \
+            z[e] = lds_chunk(w ^ cq);                                                                \
+        }                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) acc = fma4(av[e], z[e], acc);                  \
+    }
+    const uint2 nothing = make_uint2(0x80000000u, zrow);  // value -0.0f on the zero row: fmaf leaves acc as it is
+#pragma unroll
+    for (int i = 0; i < kRecCache; i += 2) {
+        if (!__any(j < re)) break;
+        if (j < re) {
+            uint2 r0 = cr.recs[i], r1 = cr.recs[i + 1];
+            if (j + kq >= re) r0 = nothing;       // past the row's end: neutralised in the lane that owns the entry
+            if (j + 4 + kq >= re) r1 = nothing;
+            DGCN_TRIP8C(r0, r1)
+            j += 8;
+        }
+    }
+    for (; j < re; j += 8) {  // rows of more than 48 entries: the rest from global memory
+        uint2 r0 = rec[j + kq], r1 = rec[j + 4 + kq];
+        if (j + kq >= re) r0 = nothing;
+        if (j + 4 + kq >= re) r1 = nothing;
+        DGCN_TRIP8C(r0, r1)
+    }
+#undef DGCN_TRIP8C
+#undef DGCN_PICK
+#undef DGCN_QB
+    float4 o = make_float4(y.x + acc.x, y.y + acc.y, y.z + acc.z, y.w + acc.w);
+    o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+    o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
+    *own = o;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bufA, const ClusterRows& cr, const uint2* rec, unsigned zrow) {
+    const float* bias = L.bias;
+    const int act = L.act;
+    if (act == DGCN_ACT_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_RELU>(bias, bufA, cr, rec, zrow);
+    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, cr, rec, zrow);
+    else aggregate_rows8c<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, cr, rec, zrow);
+}
+
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
 template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
@@ -462,11 +692,22 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
     return r;
 }
 
-template <bool MASKED, bool GVALS, int BLOCK>
+template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false>
 // (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_fused(FusedArgs a) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int g = blockIdx.x;
+    int g = blockIdx.x;
+    int cw = 0;                                  // cluster variant: which of the graph's K workgroups this is
+    const int K = CLUSTER ? a.cluster : 1;
+    if constexpr (CLUSTER) {
+        // graphs in groups of 8; the K workgroups of a graph have block indices equal modulo 8 (one XCD)
+        const int per = 8 * K, grp = blockIdx.x / per, rem = blockIdx.x % per;
+        cw = rem >> 3;
+        g = grp * 8 + (rem & 7);
+        if (g >= a.num_graphs) return;
+    }
+    int32_t* xfl = CLUSTER ? a.xflag + (size_t)g * 8 : nullptr;
+    if constexpr (CLUSTER) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing stale from earlier launches in this L1 / L2
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
     // bufB (Z1) sits at LDS byte offset 0 - the kernel has no static LDS - so a gather address is the
@@ -477,11 +718,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
     const unsigned zrow = (unsigned)a.flags_off + 128u;  // LDS byte address of 128 zero bytes
     if (threadIdx.x < 32) wflags[32 + threadIdx.x] = 0u;
-    uint2* rec = a.grec + (size_t)blockIdx.x * a.meta_cap;
+    uint2* rec = a.grec + (size_t)g * a.meta_cap;  // (cluster variant: every workgroup of the graph writes the same records)
     float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
     unsigned short* words = reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
     unsigned short* perm = words + a.meta_cap;
+    unsigned short* ipos = perm + a.max_nodes;  // position of a vertex in `perm`
     if (ng <= 0) {
         if (threadIdx.x == 0 && a.do_lgs) {
             if (a.rounds) a.rounds[g] = 0;
@@ -617,7 +859,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         __syncthreads();
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
-            perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
+            const int pos = atomicAdd(&hist[c], 1);
+            perm[pos] = (unsigned short)v;
+            ipos[v] = (unsigned short)pos;
         }
     } else {
     for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
@@ -685,9 +929,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             }
         }
         STAMP(a, g, 1, tclk);  // P0b: entries
+        if constexpr (CLUSTER) {
+            // every workgroup of the graph must arrive at the SAME row order (it decides who owns which rows): the
+            // position of a row is its rank under (entry count desc, index asc), not the order atomics happened to take
+            for (int v = threadIdx.x; v < ng; v += BLOCK) {
+                const unsigned cv = rinfo[v] >> 16;
+                int pos = 0;
+                for (int u0 = 0; u0 < ng; u0 += 8) {
+                    unsigned cu[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cu[k] = rinfo[min(u0 + k, ng - 1)] >> 16;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int u = u0 + k;
+                        pos += (u < ng) && (cu[k] > cv || (cu[k] == cv && u < v));
+                    }
+                }
+                perm[pos] = (unsigned short)v;
+                ipos[v] = (unsigned short)pos;
+            }
+        } else
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
-            perm[atomicAdd(&hist[c], 1)] = (unsigned short)v;
+            const int pos = atomicAdd(&hist[c], 1);
+            perm[pos] = (unsigned short)v;
+            ipos[v] = (unsigned short)pos;
         }
     }
     }
@@ -706,7 +972,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     }
     __syncthreads();
     RowBlocks rb;
-    row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec);
+    row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+    ClusterRows cr;
+    if constexpr (CLUSTER) cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+    if constexpr (CLUSTER) {
+        if (threadIdx.x == 0) {  // where this workgroup runs: compared after the first exchange
+            unsigned id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+            __hip_atomic_store(&xfl[(size_t)8 * ((a.num_graphs + 7) & ~7) + cw], (int)(id & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     STAMP(a, g, 2, tclk);  // P0c: row order
 
     // ------------------------------------------------------------ layers
@@ -760,7 +1035,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);
+            if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
+            else if constexpr (CLUSTER) {
+                float* slice = a.xz + ((size_t)g * 2 + (l & 1)) * a.max_nodes * kHid;
+                hidden_transform_owned<BLOCK>(bfrag, rb, bufA, bufB, slice);
+                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l, a.status);
+                if (l == 1 && (int)threadIdx.x < K) {  // all on one XCD?  (the cheap visibility rule above depends on it)
+                    const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
+                    if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                        __hip_atomic_load(&xcc[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        atomicOr(a.status, DGCN_FAULT_CLUSTER);
+                }
+                cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw);
+            }
             else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
@@ -772,11 +1059,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
             if (a.prio_gather) set_prio(prio_base + a.prio_gather);
+            if constexpr (CLUSTER) {
+                // with 256 VGPRs the next layer's weight fragments can be requested BEFORE the gather phase: their L2 round
+                // trip (~0.8 us, in front of every transform otherwise) hides under it
+                if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
+            }
+            if constexpr (CLUSTER) cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow);
+            else {
 #ifdef DGCN_DIAG
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-            hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
+                hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
 #endif
+            }
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -784,12 +1079,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
             // their 32 registers are not live during the gather phase
             // (both branches define bfrag: otherwise its 32 registers count as live through the gather of every layer)
-            if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
-            else {
+            if constexpr (!CLUSTER) {
+                if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
+                else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) bfrag[i][c] = 0.f;
+                        for (int c = 0; c < 4; ++c) bfrag[i][c] = 0.f;
+                }
             }
             __syncthreads();
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
@@ -798,7 +1095,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             // previous aggregation finished at the barrier above).
             const int v = threadIdx.x;
             float z0 = 0.f, z1 = 0.f;
-            if (v < ng) {
+            // (cluster variant: the last activations exist only for the rows this workgroup owns; the z1 scalars and
+            // then the scores go round through the graph's scalar exchange slots)
+            bool owned = v < ng;
+            if constexpr (CLUSTER) owned = v < ng && ((ipos[v] >> 4) % K) == cw;
+            float* xs0 = CLUSTER ? a.xs + (size_t)g * 2 * a.max_nodes : nullptr;
+            if (owned) {
                 if (P > 1) {  // chains already run block by block above
                     z0 = bufA[v];
                     z1 = bufB[v];
@@ -823,9 +1125,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                     }
                 }
                 bufB[v] = z1;
+                if constexpr (CLUSTER) xs0[v] = z1;
+            }
+            if constexpr (CLUSTER) {
+                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l, a.status);
+                if (v < ng && !owned) {
+                    bufB[v] = load_l2_scalar(xs0 + v);
+                }
             }
             __syncthreads();
-            if (v < ng) {
+            if (owned) {
                 const unsigned ri = rinfo[v];
                 const int rs = ri & 0xffff, re = rs + (ri >> 16);
                 float acc = 0.f;
@@ -844,6 +1153,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
                 if (a.scores) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;
+                if constexpr (CLUSTER) xs0[a.max_nodes + v] = score;
+            }
+            if constexpr (CLUSTER) {
+                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l + 1, a.status);
+                if (v < ng && !owned) {
+                    score = load_l2_scalar(xs0 + a.max_nodes + v);
+                }
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -1087,12 +1403,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 
 // ---------------------------------------------------------------------------------------------
 // entry slots: the entries themselves plus at most one padding slot per row (even row starts)
-static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 8 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
+static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 16 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
 
 static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
     const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
-    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 2 + 127) & ~(size_t)127) + 256;  // + block-OR flags (128 B) + a zero row (128 B)
+    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 4 + 127) & ~(size_t)127) + 256;  // + block-OR flags (128 B) + a zero row (128 B)
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -1102,6 +1418,18 @@ static int fused_variant(int max_nodes, int meta_cap) {
     if (fused_lds_bytes(max_nodes, meta_cap, false) <= kLdsLimit) return 0;
     if (fused_lds_bytes(max_nodes, meta_cap, true) <= kLdsLimit) return 1;
     return -1;
+}
+
+static int device_cus() {
+    static std::atomic<int> cu_count[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int ncu = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
+        cu_count[dev & 63].store(ncu, std::memory_order_relaxed);
+    }
+    return ncu;
 }
 
 constexpr int kMaxWidePasses = 4;
@@ -1173,9 +1501,39 @@ static size_t fused_pad_bytes(const DgcnModel* m) {
     return fused_needs_padding(m) ? (size_t)fused_virtual_layers(m) * kPadLayerFloats * sizeof(float) : 0;
 }
 
+// How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
+// Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
+// (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
+static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool masked) {
+    if (masked || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
+    if (fused_variant(max(b->max_nodes, 64), meta_cap) != 0) return 0;
+    const int blocks = (b->max_nodes + 15) / 16;
+    int K = min(8, (blocks + 3) / 4);
+    if (const char* e = getenv("DGCN_FUSED_CLUSTER")) {
+        const int want = atoi(e);
+        if (want <= 1) return 0;
+        K = min(8, want);
+    }
+    if (K < 2 || (blocks + K - 1) / K > kFusedBlock / 128) return 0;  // a tile per pair of waves
+    // measured (tools/cluster_check.py, 20 layers): N = 200: 117 vs 131 us for one graph, 122 vs 131 for 8, 129 vs 134 for
+    // 32, 137 vs 134 for 64; N = 120 (K = 2): 102 vs 80.  So: at least three workgroups' worth of tiles, and at most a
+    // quarter of the CUs (unless DGCN_FUSED_CLUSTER forces it: then only residency limits)
+    const int gpad = (b->num_graphs + 7) & ~7;
+    if ((long)gpad * K > device_cus()) return 0;
+    if (!getenv("DGCN_FUSED_CLUSTER") && (K < 3 || (long)gpad * K * 4 > device_cus())) return 0;
+    return K;
+}
+
+static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
+    if (K < 2) return 0;
+    const size_t gpad = (size_t)((b->num_graphs + 7) & ~7);
+    const size_t mn = (size_t)max(b->max_nodes, 64);
+    return 256 + gpad * 16 * sizeof(int32_t) + (size_t)b->num_graphs * 2 * mn * (kHid + 1) * sizeof(float) + 256;
+}
+
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
-                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream) {
+                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool masked = false) {
     if (!fused_shape_ok(m))
         return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 "
                     "(and two-layer stacks F->c->1 with c <= 128) only", who);
@@ -1245,6 +1603,32 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
             return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry records), got %zu", who, need,
                         workspace ? workspace_bytes : (size_t)0);
         a->grec = reinterpret_cast<uint2*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+        workspace = static_cast<char*>(workspace) + need;
+        workspace_bytes -= need;
+    }
+    a->num_graphs = b->num_graphs;
+    a->cluster = fused_cluster_k(b, m, a->meta_cap, masked);
+    if (a->cluster > 1) {
+        const size_t need = fused_cluster_bytes(b, a->cluster);
+        if (!workspace || workspace_bytes < need)
+            return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (exchange buffers), got %zu", who, need,
+                        workspace ? workspace_bytes : (size_t)0);
+        const size_t gpad = (size_t)((b->num_graphs + 7) & ~7);
+        char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+        a->xflag = reinterpret_cast<int32_t*>(p);
+        p += gpad * 16 * sizeof(int32_t);
+        a->xz = reinterpret_cast<float*>(p);
+        a->xs = a->xz + (size_t)b->num_graphs * 2 * a->max_nodes * kHid;
+        // a buffer this thread has not just used may hold anything: clear its progress words (what a previous launch of
+        // ours left there is harmless: older epochs)
+        static thread_local const void* last_flags = nullptr;
+        if (last_flags != a->xflag) {
+            if (hipMemsetAsync(a->xflag, 0, gpad * 16 * sizeof(int32_t), stream) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "%s: clearing the exchange flags failed", who);
+            last_flags = a->xflag;
+        }
+        static std::atomic<uint32_t> launches{1};
+        a->epoch = (int32_t)((launches.fetch_add(1, std::memory_order_relaxed) & 0x00ffffffu) << 6);  // 64 steps per launch
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
     a->flags_off = (int32_t)(*lds - 256);
@@ -1276,14 +1660,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
 template <bool MASKED, bool GVALS>
 static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     // ... and so does every graph of a batch that has no more graphs than the device has CUs
-    static std::atomic<int> cus[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int ncu = cus[dev & 63].load(std::memory_order_relaxed);
-    if (ncu == 0) {
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 1;
-        cus[dev & 63].store(ncu, std::memory_order_relaxed);
-    }
+    const int ncu = device_cus();
     bool big = (lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128;
     if (const char* e = getenv("DGCN_FUSED_BLOCK")) big = atoi(e) == kFusedBlockBig && a.max_nodes >= 128;
     return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig>(a, B, lds, family, s)
@@ -1300,6 +1677,20 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
+    if (a.cluster > 1 && !masked && !gvals) {
+        static std::atomic<size_t> reserved[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (lds > 64 * 1024 && lds > reserved[dev & 63].load(std::memory_order_relaxed)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<false, false, kFusedBlock, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+            reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
+        }
+        TimedLaunch t(family, s);
+        DGCN_LAUNCH(t, (k_fused<false, false, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
+        return check_launch("k_fused (cluster)");
+    }
     if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
     return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
 }
@@ -1310,6 +1701,7 @@ static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap
     size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
     need += (size_t)b->num_graphs * meta_cap * sizeof(uint2) + 256;  // entry records of the hidden aggregation
+    need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);  // (the residual solver never clusters)
     return need;
 }
 
@@ -1428,7 +1820,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.status = status;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream);
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream, true);
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals);
 }

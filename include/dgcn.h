@@ -42,7 +42,10 @@ enum {
     DGCN_FAULT_SELF_LOOP = 1,    /* adjacency has a diagonal entry (heuristics.py:94 would loop forever) */
     DGCN_FAULT_NAN_PRIORITY = 2, /* NaN priority (heuristics.py:103-111 never selects it: infinite loop) */
     DGCN_FAULT_DEGREE_RANGE = 4, /* vertex degree >= dinv_table length */
-    DGCN_FAULT_BAD_COLUMN = 8    /* column id outside the owning graph's node range */
+    DGCN_FAULT_BAD_COLUMN = 8,   /* column id outside the owning graph's node range */
+    DGCN_FAULT_CLUSTER = 16      /* small batches only (one graph on several workgroups): the workgroups of a graph did not
+                                    end up on one XCD, or one of them never arrived - results are not valid; rerun with the
+                                    environment variable DGCN_FUSED_CLUSTER=0 */
 };
 
 /* Block-diagonal adjacency of a batch (host struct holding device pointers). */

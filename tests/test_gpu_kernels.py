@@ -644,3 +644,50 @@ def test_layer_fused_with_next_transform(engine, golden):
     engine.torch.cuda.synchronize()
     engine.timing(False)
     assert engine.timing_read("layer")[1] == 4 and engine.timing_read("transform")[1] == 1 and engine.timing_read("spmm")[1] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers_n", [2, 3, 20])
+def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch):
+    """k_fused<.., CLUSTER>: one graph on K workgroups that hand their Z1 rows round through L2 every layer
+    (csrc/fused.hip, "cluster variant").  Forced on for K = 2, 3, 4, 8 over ragged small batches - graph sizes that do
+    not fill the last tile, single-tile graphs, an empty graph, biases, both activations - and compared bit for bit with
+    the ordinary one-workgroup-per-graph launch (which the rest of this file pins against the CPU twin); also the
+    automatic choice (small batch of N = 200 graphs) and repeated launches on the same buffers (progress words of
+    earlier launches must not satisfy later ones)."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    rng = np.random.default_rng(5 + layers_n)
+    layers = datagen.random_model(layers_n, 32)
+    for i, lyr in enumerate(layers):  # biases everywhere, relu on odd layers
+        lyr["bias"] = rng.uniform(-0.1, 0.1, np.asarray(lyr["weights"][0]).shape[1]).astype(np.float32)
+        if i < layers_n - 1 and i % 2:
+            lyr["act"] = "relu"
+    model = DeviceModel(layers, engine.device)
+    hbs = [datagen.er_batch(3, 200, 0.1, first_index=40), datagen.er_batch(1, 200, 0.1, first_index=41)]
+    parts = [datagen.er_batch(1, n, p, first_index=50 + n) for n, p in ((137, 0.08), (16, 0.3), (33, 0.2), (512, 0.01), (64, 0.1))]
+    ps, cs, ws = [np.zeros(1, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0)]  # an empty graph first
+    for hb in parts:
+        ps.append(hb.row_ptr.astype(np.int32)); cs.append(hb.col_idx.astype(np.int32)); ws.append(hb.weights)
+    hbs.append(HostBatch.from_csr_lists(ps, cs, ws))
+    for hb in hbs:
+        db = engine.upload(hb)
+        ref = None
+        for force in ("0", "2", "3", "4", "8", None):
+            if force is None:
+                monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
+            else:
+                monkeypatch.setenv("DGCN_FUSED_CLUSTER", force)
+            out = engine.solve_buffers(db, True)
+            for _ in range(3):
+                engine.solve_fused(db, model, out=out, want_scores=True)
+            torch.cuda.synchronize()
+            got = {k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")}
+            assert int(got["status"][0]) == 0
+            if ref is None:
+                ref = got
+                continue
+            for k in ref:
+                assert np.array_equal(ref[k].view(np.uint8), got[k].view(np.uint8)), (force, k, hb.num_graphs)

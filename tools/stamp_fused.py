@@ -43,11 +43,11 @@ print("launch time of this build: %.1f us" % (ev0.elapsed_time(ev1) * 1e3 / 50))
 raw = st.cpu().numpy().reshape(-1, 64)
 print("timeline of co-resident workgroups (block b and b + 256 share a CU), microseconds from the first stamp;")
 print("per hidden layer: transform start-end | gather start-end")
-for b in (27, 31, 61):
-    if b + 256 >= hb.num_graphs:
+for b in (0, 27, 31, 61):
+    if b >= hb.num_graphs:
         continue
-    t0 = min(raw[b, 16], raw[b + 256, 16])
-    for blk in (b, b + 256):
+    t0 = raw[b, 16] if b + 256 >= hb.num_graphs else min(raw[b, 16], raw[b + 256, 16])
+    for blk in ((b,) if b + 256 >= hb.num_graphs else (b, b + 256)):
         cells = []
         for l in range(6):
             ts = [(raw[blk, 16 + 4 * l + k] - t0) / 100.0 for k in range(4)]
