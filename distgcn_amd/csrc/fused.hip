@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
                     if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
                         __hip_atomic_load(&xcc[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        atomicOr(a.status, DGCN_FAULT_CLUSTER);
+                        if (a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
                 }
                 cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw);
             }
@@ -1533,7 +1533,7 @@ static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
-                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool masked = false) {
+                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool no_cluster = false) {
     if (!fused_shape_ok(m))
         return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 "
                     "(and two-layer stacks F->c->1 with c <= 128) only", who);
@@ -1607,7 +1607,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace_bytes -= need;
     }
     a->num_graphs = b->num_graphs;
-    a->cluster = fused_cluster_k(b, m, a->meta_cap, masked);
+    a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
     if (a->cluster > 1) {
         const size_t need = fused_cluster_bytes(b, a->cluster);
         if (!workspace || workspace_bytes < need)
@@ -1723,7 +1723,8 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     args.do_lgs = 0;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)", workspace, workspace_bytes, &gvals, s);
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_gcn_forward_batch(mode 1)", workspace, workspace_bytes, &gvals, s,
+                           true);  // (no status word on this entry point: no cluster variant, whose placement check reports through it)
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_forward", s, false, gvals);
 }
