@@ -20,7 +20,7 @@ FAULT_NAMES = {
     FAULT_NAN_PRIORITY: "NaN priority (heuristics.py:103-111 would never terminate)",
     FAULT_DEGREE_RANGE: "vertex degree outside the d^-1/2 table",
     FAULT_BAD_COLUMN: "column index outside its graph's vertex range",
-    16: "the workgroups of a graph lost each other (cluster variant of the fused kernel): rerun with DGCN_FUSED_CLUSTER=0",
+    16: "the workgroups of a graph lost each other (cluster variant of the fused kernel; now switched off for this process: call again)",
 }
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all

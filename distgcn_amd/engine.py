@@ -141,6 +141,11 @@ class Engine:
 
     @staticmethod
     def check_status_bits(bits: int) -> None:
+        if bits & 16:
+            # the cluster variant of the fused kernel relies on a placement that this device / partition mode does not give:
+            # switch it off for the rest of the process, so that a retry (and every later call) takes the ordinary launch
+            import os
+            os.environ["DGCN_FUSED_CLUSTER"] = "0"
         if bits:
             raise _lib.DgcnError("device-side validation failed: " + _lib.fault_text(bits))
 
