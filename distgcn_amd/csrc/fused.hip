@@ -1628,7 +1628,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
             last_flags = a->xflag;
         }
         static std::atomic<uint32_t> launches{1};
-        a->epoch = (int32_t)((launches.fetch_add(1, std::memory_order_relaxed) & 0x00ffffffu) << 6);  // 64 steps per launch
+        a->epoch = (int32_t)(launches.fetch_add(1, std::memory_order_relaxed) << 6);  // 64 steps per launch; compared modulo 2^32
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
     a->flags_off = (int32_t)(*lds - 256);
