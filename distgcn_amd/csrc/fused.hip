@@ -233,7 +233,7 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
 // What a lane needs to start on its (up to four) row blocks of the aggregation: the row, its entry range and the record
 // of its first entry.  None of it changes from layer to layer, so it is read once per graph and stays in registers: a
 // block starts with its gathers instead of three dependent round trips (perm -> rinfo -> record).
-constexpr int kMaxRowBlocks = 4;  // 512 vertices / (16 rows x 8 waves)
+constexpr int kMaxRowBlocks = 2;  // per wave: 256 vertices on 8 waves, 512 on 16 (larger graphs never get 512-thread workgroups)
 struct RowBlocks {
     int trow[kMaxRowBlocks];     // cluster variant: row of lane & 15 in block k (the transform's lane map), -1 = none
     int v[kMaxRowBlocks];        // row of this lane's slot in block k, -1 = none
@@ -1661,8 +1661,9 @@ template <bool MASKED, bool GVALS>
 static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     // ... and so does every graph of a batch that has no more graphs than the device has CUs
     const int ncu = device_cus();
-    bool big = (lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128;
-    if (const char* e = getenv("DGCN_FUSED_BLOCK")) big = atoi(e) == kFusedBlockBig && a.max_nodes >= 128;
+    bool big = ((lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
+    if (const char* e = getenv("DGCN_FUSED_BLOCK"))
+        big = (atoi(e) == kFusedBlockBig && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
     return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig>(a, B, lds, family, s)
                : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
 }
