@@ -427,9 +427,11 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         const unsigned ri = rb.ri[k];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-        // (Tried again with the 16-row map: the row's own Z0 chunks requested here instead of after the entry walk - their
-        // round trip behind everybody's gathers costs ~400 cycles per block - but the 8 registers held through the walk spill
-        // elsewhere: 209.7 vs 206.0 us per C3 step, 134.0 vs 131.1 us for one graph.)
+        // (the row's own Z0 chunks are requested ahead of the gathers: while four row blocks' worth of state lived through
+        // the layer loop these 8 registers spilled elsewhere and cost 2 %; with two it is 0.5 % the other way)
+        float4* ownA = reinterpret_cast<float4*>(bufA + v * kHid + ((cfirst ^ (v & 7)) << 2));
+        float4* ownB = reinterpret_cast<float4*>(bufA + v * kHid + ((csecond ^ (v & 7)) << 2));
+        const float4 yA = *ownA, yB = *ownB;  // the row's own Z0 chunks, requested ahead of the gathers
         BSTAMP(0);
         // Entry metadata comes from GLOBAL memory, not from the LDS: the gather phase is paced by the LDS instruction
         // stream (an LDS round trip takes ~450 cycles there: 16 waves x 8 ds_read_b128 queued), and the two metadata
@@ -473,9 +475,6 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 #undef DGCN_TRIP
 #undef DGCN_QB
         BSTAMP(2);
-        float4* ownA = reinterpret_cast<float4*>(bufA + v * kHid + ((cfirst ^ (v & 7)) << 2));
-        float4* ownB = reinterpret_cast<float4*>(bufA + v * kHid + ((csecond ^ (v & 7)) << 2));
-        const float4 yA = *ownA, yB = *ownB;
         float4 oA = make_float4(yA.x + accA.x, yA.y + accA.y, yA.z + accA.z, yA.w + accA.w);
         float4 oB = make_float4(yB.x + accB.x, yB.y + accB.y, yB.z + accB.z, yB.w + accB.w);
         oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
