@@ -394,7 +394,7 @@ __device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], c
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-template <int BLOCK, int ACT>
+template <int BLOCK, int ACT, bool BIAS>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
                                                  const uint2* rec, unsigned zrow, unsigned long long* st) {
     (void)st;
@@ -410,8 +410,10 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
     const int cfirst = kq | (((s >> 1) & 1) << 2), csecond = cfirst ^ 4;  // logical chunks of this lane
     const unsigned cA = (unsigned)cfirst << 4, cB = (unsigned)csecond << 4;
     constexpr int kWaves = BLOCK / 64;
-    float4 biasA = make_float4(-0.f, -0.f, -0.f, -0.f), biasB = biasA;  // x + (-0.0f) == x for every x
-    if (bias_ptr) {
+    // (a template argument, like the activation: the reference's GCN_DQN layers have no bias, and eight registers of
+    // -0.0f carried through the entry walk are eight too many on this kernel's register budget)
+    float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA;
+    if constexpr (BIAS) {
         biasA = *reinterpret_cast<const float4*>(bias_ptr + 4 * cfirst);
         biasB = *reinterpret_cast<const float4*>(bias_ptr + 4 * csecond);
     }
@@ -477,8 +479,10 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         BSTAMP(2);
         float4 oA = make_float4(yA.x + accA.x, yA.y + accA.y, yA.z + accA.z, yA.w + accA.w);
         float4 oB = make_float4(yB.x + accB.x, yB.y + accB.y, yB.z + accB.z, yB.w + accB.w);
-        oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
-        oB.x += biasB.x; oB.y += biasB.y; oB.z += biasB.z; oB.w += biasB.w;
+        if constexpr (BIAS) {
+            oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
+            oB.x += biasB.x; oB.y += biasB.y; oB.z += biasB.z; oB.w += biasB.w;
+        }
         oA.x = apply_act(oA.x, ACT); oA.y = apply_act(oA.y, ACT); oA.z = apply_act(oA.z, ACT); oA.w = apply_act(oA.w, ACT);
         oB.x = apply_act(oB.x, ACT); oB.y = apply_act(oB.y, ACT); oB.z = apply_act(oB.z, ACT); oB.w = apply_act(oB.w, ACT);
         *ownA = oA;
@@ -596,9 +600,15 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* buf
                                                  unsigned zrow, unsigned long long* st = nullptr) {
     const float* bias = L.bias;
     const int act = L.act;
-    if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU>(bias, bufA, rb, rec, zrow, st);
-    else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, rb, rec, zrow, st);
-    else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, rb, rec, zrow, st);
+    if (bias) {
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, zrow, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, zrow, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, zrow, st);
+    } else {
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, zrow, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, zrow, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, zrow, st);
+    }
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
