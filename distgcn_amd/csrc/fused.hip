@@ -901,38 +901,47 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     STAMP(a, g, 0, tclk);  // P0a: row pointers, degree table
     {
         const int total = e1 - e0;
-        constexpr int kP0 = 8;  // column loads in flight per thread
-        for (int base = threadIdx.x; base < total; base += BLOCK * kP0) {
+        constexpr int kP0 = 8;  // up to eight consecutive entries per thread: loads in flight, ONE bisection for their row
+        const int chunk = min(kP0, max(1, (total + BLOCK - 1) / BLOCK));  // (small graphs: fewer per thread, all threads busy)
+        for (int base = threadIdx.x * chunk; base < total; base += BLOCK * chunk) {
             int c[kP0];
             float gv[kP0];
 #pragma unroll
             for (int i = 0; i < kP0; ++i) {
-                const int j = base + i * BLOCK;
+                const int j = base + i;
                 c[i] = 0;
                 gv[i] = 0.f;
-                if (j < total) {
+                if (i < chunk && j < total) {
                     c[i] = a.col_idx[e0 + j];
                     if (!a.from_adj) gv[i] = a.vals[e0 + j];
                 }
             }
+            int lo = 0, hi = ng;  // last row whose start is <= base (rows without entries are stepped over below)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rowstart[mid] <= base) lo = mid; else hi = mid;
+            }
+            int v = lo;
+            int vend = rowstart[v + 1];  // rowstart[ng] = total
+            int vslot = (int)(rinfo[v] & 0xffff) + extra - rowstart[v];
+            double dv = a.from_adj ? dinv[v] : 0.0;
 #pragma unroll
             for (int i = 0; i < kP0; ++i) {
-                const int j = base + i * BLOCK;
-                if (j >= total) continue;
-                int lo = 0, hi = ng;  // last row whose start is <= j
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (rowstart[mid] <= j) lo = mid; else hi = mid;
+                const int j = base + i;
+                if (i >= chunk || j >= total) break;
+                if (j >= vend) {  // next row(s)
+                    do { ++v; vend = rowstart[v + 1]; } while (j >= vend);
+                    vslot = (int)(rinfo[v] & 0xffff) + extra - rowstart[v];
+                    if (a.from_adj) dv = dinv[v];
                 }
-                const int v = lo;
                 int u = c[i] - n0;
                 float val = gv[i];
                 if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0; val = 0.f; }
                 else if (a.from_adj) {
                     if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
-                    val = (float)(-(dinv[u] * dinv[v]));
+                    val = (float)(-(dinv[u] * dv));
                 }
-                const int slot = (int)(rinfo[v] & 0xffff) + extra + (j - rowstart[v]);
+                const int slot = vslot + j;
                 words[slot] = enc_word(u);
                 vals[slot] = val;
             }
