@@ -37,7 +37,7 @@ F32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default: ~0.25 s of timed region on C3)")
+    ap.add_argument("--steps", type=int, default=1500, help="timed steps (default: ~0.3 s of timed region on C3)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU (weak scaling) or in the whole job (strong)")
     ap.add_argument("--nodes", type=int, default=200)
