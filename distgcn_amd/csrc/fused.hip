@@ -84,7 +84,7 @@ struct FusedArgs {
     int32_t beam;          // greedy_mode 2: number of candidates
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
-    // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_sync()
+    // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
     int32_t cluster;
     int32_t epoch;      // progress words count from here: values a previous launch left behind (possibly still cached in
                         // this XCD's L2, whatever a memset from elsewhere did to the memory) are always smaller
@@ -272,12 +272,12 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
 // block's chain of LDS round trips; neither shrinks inside one CU, and the reference calls its agent with ONE graph.  In
 // this variant every workgroup of a graph builds the whole LDS image, but transforms and aggregates only the row blocks
 // it owns (block index mod K: each of its waves has at most one tile and one block per layer).  What it has to share is
-// Z1: it writes its rows to a double-buffered global slice, publishes the layer number, waits for the other K - 1 and
-// pulls their rows into its own bufB.  The workgroups of a graph get block indices that are equal modulo 8, i.e. the
-// same XCD and the same L2 (round-robin dispatch; checked once through HW_REG_XCC_ID, fault bit otherwise), so that
+// Z1: it writes its rows to a global slice and pulls the other K - 1 workgroups' rows from there into its own bufB as
+// soon as they show up (cluster_pull_rows).  The workgroups of a graph get block indices that are equal modulo 8, i.e.
+// the same XCD and the same L2 (round-robin dispatch; checked once through HW_REG_XCC_ID, fault bit otherwise), so that
 // "visible" only means "has left the CU": s_waitcnt on the writer, L1-bypassing loads on the reader - an agent-scope
-// release would write the L2 back (tools/micro/xchg.hip: 4 - 5 K cycles per exchange this way, 14 K - 200 K with
-// __threadfence()).  Spins are bounded: a workgroup that never arrives costs a fault bit, not the machine.
+// release would write the L2 back (tools/micro/xchg.hip: 4 - 5 K cycles per exchange through a progress word this way,
+// 14 K - 200 K with __threadfence()).  Spins are bounded: a workgroup that never arrives costs a fault bit, not the machine.
 // (load and wait are ONE asm statement: the compiler does not know that the result of an inline-asm load is still in
 // flight and would otherwise be free to copy the registers before the data has arrived)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -299,12 +299,28 @@ __device__ __forceinline__ float load_l2_scalar(const float* p) {
     return v;
 }
 
-// every store of this workgroup has left the CU -> publish `seq` -> wait until all K workgroups have published it
+constexpr unsigned kUnwritten = 0xffffffffu;  // see cluster_pull_rows
+__device__ __forceinline__ float poll_l2_scalar(const float* p, int32_t* status) {
+    for (int spins = 0;; ++spins) {
+        const float v = load_l2_scalar(p);
+        if (__float_as_uint(v) != kUnwritten) return v;
+        if (spins > (1 << 19)) {
+            if (status) atomicOr(status, DGCN_FAULT_CLUSTER);
+            return v;
+        }
+    }
+}
+
+// every store of this workgroup has left the CU -> publish `seq`
 template <int BLOCK>
-__device__ __forceinline__ void cluster_sync(int32_t* flags, int K, int cw, int seq, int32_t* status) {
+__device__ __forceinline__ void cluster_publish(int32_t* flags, int cw, int seq) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&flags[cw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until all K workgroups have published `seq`
+template <int BLOCK>
+__device__ __forceinline__ void cluster_wait(int32_t* flags, int K, int seq, int32_t* status) {
     if ((int)threadIdx.x < K) {
         int spins = 0;
         while ((int)(__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
@@ -317,10 +333,29 @@ __device__ __forceinline__ void cluster_sync(int32_t* flags, int K, int cw, int 
     }
     __syncthreads();
 }
-
-// the other workgroups' Z1 rows: global slice (same swizzled 128-byte rows as bufB) -> bufB
+// A chunk of the exchange slice that has not been written yet holds four of these (a NaN no arithmetic produces); the
+// reader pulls the DATA until no chunk shows it, so a hand-over is two L2 round trips - the writer's store, the
+// reader's load - instead of three (store, progress word, load).  Three slices per graph, used in turn: after a workgroup
+// has pulled layer l (=> every other workgroup has published l and is therefore done reading l - 1) it marks its own rows
+// in the slice of layer l + 2 (= that of l - 1) unwritten again; s_waitcnt + the barrier after the gather phase put those
+// marks into L2 before its next layer's rows leave, and nobody polls for l + 2 before having seen those.
 template <int BLOCK>
-__device__ __forceinline__ void cluster_pull_rows(const float* slice, float* bufB, const unsigned short* perm, int ng, int K, int cw) {
+__device__ __forceinline__ void cluster_mark_unwritten(const RowBlocks& rb, float* slice) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const float u = __uint_as_float(kUnwritten);
+#pragma unroll
+    for (int k = 0; k < kMaxRowBlocks; ++k) {
+        if (rb.trow[k] < 0) continue;
+        float* row = slice + rb.trow[k] * kHid;
+        *reinterpret_cast<float4*>(row + (kq << 2)) = make_float4(u, u, u, u);
+        *reinterpret_cast<float4*>(row + ((kq + 4) << 2)) = make_float4(u, u, u, u);
+    }
+}
+
+// the other workgroups' Z1 rows: global slice (same swizzled 128-byte rows as bufB) -> bufB, as soon as they are there
+template <int BLOCK>
+__device__ __forceinline__ void cluster_pull_rows(const float* slice, float* bufB, const unsigned short* perm, int ng, int K, int cw,
+                                                  int32_t* status) {
     const int total = ng * 8;  // 16-byte chunks, in perm order: position p belongs to block p / 16
     for (int base = threadIdx.x; base < total; base += 4 * BLOCK) {
         float4 v[4];
@@ -337,7 +372,21 @@ __device__ __forceinline__ void cluster_pull_rows(const float* slice, float* buf
                 src[u] = slice + dst[u];
             }
         }
-        load_l2_x4(src[0], src[1], src[2], src[3], v);
+        int spins = 0;
+        while (true) {
+            load_l2_x4(src[0], src[1], src[2], src[3], v);
+            bool ready = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0 && (__float_as_uint(v[u].x) == kUnwritten || __float_as_uint(v[u].y) == kUnwritten ||
+                                    __float_as_uint(v[u].z) == kUnwritten || __float_as_uint(v[u].w) == kUnwritten))
+                    ready = false;
+            if (ready) break;
+            if (++spins > (1 << 19)) {  // ~0.3 s: somebody is not coming (or a row really holds that NaN)
+                if (status) atomicOr(status, DGCN_FAULT_CLUSTER);
+                break;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (dst[u] >= 0) *reinterpret_cast<float4*>(bufB + dst[u]) = v[u];
@@ -714,9 +763,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         cw = rem >> 3;
         g = grp * 8 + (rem & 7);
         if (g >= a.num_graphs) return;
+#ifdef DGCN_DIAG
+        if (cw != 0) a.stamps = nullptr;  // phase clocks of the graph's first workgroup only
+#endif
     }
     int32_t* xfl = CLUSTER ? a.xflag + (size_t)g * 8 : nullptr;
-    if constexpr (CLUSTER) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing stale from earlier launches in this L1 / L2
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
     // bufB (Z1) sits at LDS byte offset 0 - the kernel has no static LDS - so a gather address is the
@@ -950,19 +1001,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if constexpr (CLUSTER) {
             // every workgroup of the graph must arrive at the SAME row order (it decides who owns which rows): the
             // position of a row is its rank under (entry count desc, index asc), not the order atomics happened to take
-            for (int v = threadIdx.x; v < ng; v += BLOCK) {
-                const unsigned cv = rinfo[v] >> 16;
-                int pos = 0;
-                for (int u0 = 0; u0 < ng; u0 += 8) {
-                    unsigned cu[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) cu[k] = rinfo[min(u0 + k, ng - 1)] >> 16;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int u = u0 + k;
-                        pos += (u < ng) && (cu[k] > cv || (cu[k] == cv && u < v));
-                    }
+            // (keys = count << 16 | ~index in LDS, four per ds_read_b128, the vertices' scans split over 1, 2 or 4 lanes)
+            unsigned* key = reinterpret_cast<unsigned*>(rowstart + 520);
+            const int ng4 = (ng + 3) & ~3;
+            for (int v = threadIdx.x; v < ng4; v += BLOCK) key[v] = v < ng ? ((rinfo[v] >> 16) << 16) | (0xffffu - (unsigned)v) : 0u;
+            __syncthreads();
+            const int lp_log = (ng * 4 <= BLOCK) ? 2 : (ng * 2 <= BLOCK) ? 1 : 0;
+            const int v = threadIdx.x >> lp_log, part = threadIdx.x & ((1 << lp_log) - 1);
+            int pos = 0;
+            if (v < ng) {
+                const unsigned kv = key[v];
+                for (int u0 = part * 4; u0 < ng4; u0 += 4 << lp_log) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(key + u0);
+                    pos += (q.x > kv) + (q.y > kv) + (q.z > kv) + (q.w > kv);
                 }
+            }
+            if (lp_log >= 1) pos += __shfl_xor(pos, 1);
+            if (lp_log >= 2) pos += __shfl_xor(pos, 2);
+            if (v < ng && part == 0) {
                 perm[pos] = (unsigned short)v;
                 ipos[v] = (unsigned short)pos;
             }
@@ -999,6 +1055,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
             __hip_atomic_store(&xfl[(size_t)8 * ((a.num_graphs + 7) & ~7) + cw], (int)(id & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // whatever an earlier launch left in the exchange slices: this workgroup's rows read "unwritten" from here on,
+        // and the others learn through the progress word that they do (waited for in front of the first pull)
+        for (int t = 0; t < 3; ++t) cluster_mark_unwritten<BLOCK>(rb, a.xz + ((size_t)g * 3 + t) * a.max_nodes * kHid);
+        if ((int)threadIdx.x < ng && ((ipos[threadIdx.x] >> 4) % K) == cw) {  // the last layer's scalars likewise
+            float* xs0 = a.xs + (size_t)g * 2 * a.max_nodes;
+            xs0[threadIdx.x] = __uint_as_float(kUnwritten);
+            xs0[a.max_nodes + threadIdx.x] = __uint_as_float(kUnwritten);
+        }
+        cluster_publish<BLOCK>(xfl, cw, a.epoch);
     }
     STAMP(a, g, 2, tclk);  // P0c: row order
 
@@ -1049,22 +1114,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         // instructions per LDS round trip) and drop it for the MFMA-paced transform.
         const int prio_base = (second && a.prio_second && (l & 7) < a.prio_second) ? 1 : 0;
         if (a.prio_second || a.prio_gather) set_prio(prio_base);
+        if constexpr (CLUSTER) {
+            if (l == 1) {  // before the first pull: every workgroup of the graph has marked its exchange rows
+                cluster_wait<BLOCK>(xfl, K, a.epoch, a.status);
+                if ((int)threadIdx.x < K) {  // all on one XCD?  (the cheap visibility rule above depends on it)
+                    const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
+                    if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                        __hip_atomic_load(&xcc[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        if (a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
+                }
+            }
+        }
         if (L.cout == kHid) {
 #ifdef DGCN_DIAG
             if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
             if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
             else if constexpr (CLUSTER) {
-                float* slice = a.xz + ((size_t)g * 2 + (l & 1)) * a.max_nodes * kHid;
+                float* xz0 = a.xz + (size_t)g * 3 * a.max_nodes * kHid;
+                float* slice = xz0 + (size_t)(l % 3) * a.max_nodes * kHid;
                 hidden_transform_owned<BLOCK>(bfrag, rb, bufA, bufB, slice);
-                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l, a.status);
-                if (l == 1 && (int)threadIdx.x < K) {  // all on one XCD?  (the cheap visibility rule above depends on it)
-                    const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
-                    if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-                        __hip_atomic_load(&xcc[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        if (a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
-                }
-                cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw);
+                cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw, a.status);
+                cluster_mark_unwritten<BLOCK>(rb, xz0 + (size_t)((l + 2) % 3) * a.max_nodes * kHid);
             }
             else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
@@ -1082,8 +1153,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 // trip (~0.8 us, in front of every transform otherwise) hides under it
                 if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
             }
-            if constexpr (CLUSTER) cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow);
-            else {
+            if constexpr (CLUSTER) {
+                cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
+            } else {
 #ifdef DGCN_DIAG
                 if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
@@ -1146,10 +1219,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 if constexpr (CLUSTER) xs0[v] = z1;
             }
             if constexpr (CLUSTER) {
-                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l, a.status);
-                if (v < ng && !owned) {
-                    bufB[v] = load_l2_scalar(xs0 + v);
-                }
+                if (v < ng && !owned) bufB[v] = poll_l2_scalar(xs0 + v, a.status);
             }
             __syncthreads();
             if (owned) {
@@ -1174,10 +1244,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 if constexpr (CLUSTER) xs0[a.max_nodes + v] = score;
             }
             if constexpr (CLUSTER) {
-                cluster_sync<BLOCK>(xfl, K, cw, a.epoch + l + 1, a.status);
-                if (v < ng && !owned) {
-                    score = load_l2_scalar(xs0 + a.max_nodes + v);
+                // the greedy search is the first workgroup's alone: the others have handed in their scores and are done
+                if (cw != 0 || !a.do_lgs) {
+                    if (fault && a.status) atomicOr(a.status, fault);
+                    return;
                 }
+                if (v < ng && !owned) score = poll_l2_scalar(xs0 + a.max_nodes + v, a.status);
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -1546,7 +1618,7 @@ static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
     if (K < 2) return 0;
     const size_t gpad = (size_t)((b->num_graphs + 7) & ~7);
     const size_t mn = (size_t)max(b->max_nodes, 64);
-    return 256 + gpad * 16 * sizeof(int32_t) + (size_t)b->num_graphs * 2 * mn * (kHid + 1) * sizeof(float) + 256;
+    return 256 + gpad * 16 * sizeof(int32_t) + (size_t)b->num_graphs * mn * (3 * kHid + 2) * sizeof(float) + 256;
 }
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
@@ -1636,7 +1708,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         a->xflag = reinterpret_cast<int32_t*>(p);
         p += gpad * 16 * sizeof(int32_t);
         a->xz = reinterpret_cast<float*>(p);
-        a->xs = a->xz + (size_t)b->num_graphs * 2 * a->max_nodes * kHid;
+        a->xs = a->xz + (size_t)b->num_graphs * 3 * a->max_nodes * kHid;
         // a buffer this thread has not just used may hold anything: clear its progress words (what a previous launch of
         // ours left there is harmless: older epochs)
         static thread_local const void* last_flags = nullptr;
