@@ -103,7 +103,7 @@ struct FusedArgs {
 #define STAMP(a, g, i, t0)                                                                    \
     do {                                                                                      \
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
-        if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(g) * 64 + (i)] += _t - (t0); \
+        if ((a).stamps && stamp_wg && threadIdx.x == 0) (a).stamps[(size_t)(g) * 64 + (i)] += _t - (t0); \
         (t0) = _t;                                                                            \
     } while (0)
 #else
@@ -763,11 +763,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         cw = rem >> 3;
         g = grp * 8 + (rem & 7);
         if (g >= a.num_graphs) return;
-#ifdef DGCN_DIAG
-        if (cw != 0) a.stamps = nullptr;  // phase clocks of the graph's first workgroup only
-#endif
     }
     int32_t* xfl = CLUSTER ? a.xflag + (size_t)g * 8 : nullptr;
+    const bool stamp_wg = !CLUSTER || cw == 0;  // (DGCN_DIAG builds: phase clocks of the graph's first workgroup only)
+    (void)stamp_wg;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
     // bufB (Z1) sits at LDS byte offset 0 - the kernel has no static LDS - so a gather address is the
@@ -805,7 +804,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 #endif
     (void)tclk;
 #ifdef DGCN_DIAG
-    if (a.stamps && threadIdx.x == 0) {
+    if (a.stamps && stamp_wg && threadIdx.x == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1127,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         }
         if (L.cout == kHid) {
 #ifdef DGCN_DIAG
-            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
             if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
             else if constexpr (CLUSTER) {
@@ -1139,13 +1138,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             }
             else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
-            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, l == 0 ? 3 : 5, tclk);  // transform body (wave 0)
             __syncthreads();
             STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
 #ifdef DGCN_DIAG
-            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
             if (a.prio_gather) set_prio(prio_base + a.prio_gather);
             if constexpr (CLUSTER) {
@@ -1164,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 #endif
             }
 #ifdef DGCN_DIAG
-            if (a.stamps && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
@@ -1439,9 +1438,55 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     // bytes and one barrier per round, ranks with eight reads in flight.  14 -> 8.5 us when the phase runs alone, but the
     // C3 launch did not move (the co-resident workgroup's gathers keep the LDS queue full: every dependent access costs
     // ~500 cycles either way) and the one-layer configurations lost 10 % to the set-up.)
-    __syncthreads();
     int rounds = 0;
     const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
+    if constexpr (CLUSTER) {
+        // One graph (or a few) with the CU to itself: nothing hides a dependent LDS access here, so the rounds keep every
+        // lane's first kNb neighbours in registers (one round trip per round with all reads in flight instead of two
+        // dependent ones per four entries); entries past kNb * lpv go through the table as below.  Same rounds, same sets.
+        constexpr int kNb = 20;
+        const int dummy = (3 * a.max_nodes + 1) / 2 + 2;  // a rank slot nobody owns: always "removed"
+        int nb[kNb];
+#pragma unroll
+        for (int i = 0; i < kNb; ++i) {
+            const int j = rs + sub + i * lpv;
+            const int u = j < re ? (int)(words[j] >> 7) : vv;
+            nb[i] = (j < re && u != vv) ? u : dummy;
+        }
+        if (threadIdx.x == 0) key[dummy] = (unsigned short)kDead;
+        __syncthreads();
+        while (true) {
+            const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
+            const bool live = mykey != kDead;
+            unsigned k[kNb];
+#pragma unroll
+            for (int i = 0; i < kNb; ++i) k[i] = key[nb[i]];
+            unsigned m = kDead;
+#pragma unroll
+            for (int i = 0; i < kNb; ++i) m = min(m, k[i]);
+            if (live)
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+                    const int u = words[j] >> 7;
+                    const unsigned kk = key[u];
+                    if (u != vv) m = min(m, kk);
+                }
+            for (int off = 1; off < lpv; off <<= 1) m = min(m, (unsigned)__shfl_xor((int)m, off));
+            const bool won = live && mykey < m;
+            if (!block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every rank read before the kills below
+            ++rounds;
+            if (won) {
+#pragma unroll
+                for (int i = 0; i < kNb; ++i) { key[nb[i]] = (unsigned short)kDead; st[nb[i]] = 2; }  // (the nobody-slot takes its share)
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+                    const int u = words[j] >> 7;
+                    if (u != vv) { key[u] = (unsigned short)kDead; st[u] = 2; }
+                }
+                if (sub == 0) { key[vv] = (unsigned short)kDead; st[vv] = 1; }
+            }
+            __syncthreads();
+        }
+    } else {
+    __syncthreads();
     while (!DIAG_ON(a, 2)) {
         const unsigned mykey = mine ? (unsigned)key[vv] : kDead;
         const bool live = mykey != kDead;
@@ -1475,6 +1520,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (sub == 0) { key[vv] = (unsigned short)kDead; st[vv] = 1; }
         }
         __syncthreads();
+    }
     }
     STAMP(a, g, 10, tclk);  // priorities, ranks, greedy rounds
     const int tv = threadIdx.x;
@@ -1598,19 +1644,22 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     if (masked || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) != 0) return 0;
     const int blocks = (b->max_nodes + 15) / 16;
-    int K = min(8, (blocks + 3) / 4);
+    const int gpad = (b->num_graphs + 7) & ~7;
+    // every workgroup of every graph must be resident at once; two tiles per workgroup is as fine as it pays
+    int K = min(min(8, device_cus() / max(gpad, 1)), (blocks + 1) / 2);
+    bool forced = false;
     if (const char* e = getenv("DGCN_FUSED_CLUSTER")) {
         const int want = atoi(e);
         if (want <= 1) return 0;
         K = min(8, want);
+        forced = true;
     }
-    if (K < 2 || (blocks + K - 1) / K > kFusedBlock / 128) return 0;  // a tile per pair of waves
-    // measured (tools/cluster_check.py, 20 layers): N = 200: 117 vs 131 us for one graph, 122 vs 131 for 8, 129 vs 134 for
-    // 32, 137 vs 134 for 64; N = 120 (K = 2): 102 vs 80.  So: at least three workgroups' worth of tiles, and at most a
-    // quarter of the CUs (unless DGCN_FUSED_CLUSTER forces it: then only residency limits)
-    const int gpad = (b->num_graphs + 7) & ~7;
-    if ((long)gpad * K > device_cus()) return 0;
-    if (!getenv("DGCN_FUSED_CLUSTER") && (K < 3 || (long)gpad * K * 4 > device_cus())) return 0;
+    if (K < 2 || (long)gpad * K > device_cus() || (blocks + K - 1) / K > kFusedBlock / 128) return 0;  // a tile per pair of waves
+    // measured (tools/cluster_check.py, 20 layers, one workgroup per graph vs cluster): N = 200: 127 vs 92 us for 1 - 16
+    // graphs (K = 6 - 8; 97 with K = 4, 95 with K = 5), 129 vs 94 for 32 (K = 8), 130 vs 100 for 64 (K = 4); N = 300
+    // (K = 5+): 126 vs 112; N = 150: 94 vs 82; N = 120: 74 vs 72; N = 77: 61 vs 65.  The fixed cost (every workgroup
+    // builds the image, 512 threads for the greedy rounds) is ~9 us, the gain ~2 us per hidden layer.
+    if (!forced && (K < 3 || blocks < 8 || m->num_layers < 8)) return 0;
     return K;
 }
 

@@ -8,9 +8,11 @@
 //     dgcn_host_solver_submit  = dgcn_pack_batch into pinned memory -> 1 hipMemcpyAsync -> dgcn_solve_batch
 //                                -> 1 hipMemcpyAsync back -> event           (returns at once)
 //     dgcn_host_solver_result  = wait for the slot's event -> pointers into its pinned result
+// (a batch of a few KB skips both copies: the kernel works on the pinned buffers directly)
 // with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
 // consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
 // DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -22,9 +24,11 @@ struct DgcnHostSolver {
         hipEvent_t done = nullptr;
         hipEvent_t copied = nullptr;  // the batch has arrived on the device (recorded on the shared copy stream)
         void* in_host = nullptr;   // pinned: the packed batch
+        void* in_host_dev = nullptr;  // the same bytes as the device addresses them (small batches are read in place)
         void* in_dev = nullptr;
         size_t in_cap = 0;
         void* out_host = nullptr;  // pinned: totals | rounds | status | state
+        void* out_host_dev = nullptr;
         void* out_dev = nullptr;
         size_t out_cap = 0;
         int cap_nodes = 0, cap_graphs = 0;
@@ -33,6 +37,7 @@ struct DgcnHostSolver {
         size_t off_totals = 0, off_scores = 0, off_rounds = 0, off_status = 0, off_state = 0, out_bytes = 0;
         int num_nodes = 0, num_graphs = 0;
         bool busy = false;
+        bool direct = false;  // this batch: the kernel reads / writes the pinned host buffers itself
     };
     bool lgs_only = false;  // no model: priority = weight, the plain local greedy search (heuristics.py:77-116)
     DgcnModel model;
@@ -69,14 +74,14 @@ struct DeviceScope {
 static void free_in(DgcnHostSolver::Slot& s) {
     if (s.in_host) (void)hipHostFree(s.in_host);
     if (s.in_dev) (void)hipFree(s.in_dev);
-    s.in_host = s.in_dev = nullptr;
+    s.in_host = s.in_dev = s.in_host_dev = nullptr;
     s.in_cap = 0;
 }
 
 static void free_out(DgcnHostSolver::Slot& s) {
     if (s.out_host) (void)hipHostFree(s.out_host);
     if (s.out_dev) (void)hipFree(s.out_dev);
-    s.out_host = s.out_dev = nullptr;
+    s.out_host = s.out_dev = s.out_host_dev = nullptr;
     s.out_cap = 0;
 }
 
@@ -85,7 +90,8 @@ static int ensure_in(DgcnHostSolver::Slot& s, size_t bytes) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     free_in(s);
     const size_t cap = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(&s.in_host, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&s.in_dev, cap) != hipSuccess) {
+    if (hipHostMalloc(&s.in_host, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&s.in_dev, cap) != hipSuccess ||
+        hipHostGetDevicePointer(&s.in_host_dev, s.in_host, 0) != hipSuccess) {
         free_in(s);
         return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of staging memory", cap);
     }
@@ -107,7 +113,7 @@ static int ensure_out(DgcnHostSolver::Slot& s, int nodes, int graphs, bool want_
     s.off_state = s.off_status + 16;
     s.out_bytes = s.off_state + align16((size_t)cn);
     if (hipHostMalloc(&s.out_host, s.out_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc(&s.out_dev, s.out_bytes) != hipSuccess) {
+        hipMalloc(&s.out_dev, s.out_bytes) != hipSuccess || hipHostGetDevicePointer(&s.out_host_dev, s.out_host, 0) != hipSuccess) {
         free_out(s);
         return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of result memory", s.out_bytes);
     }
@@ -211,7 +217,12 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     if (!h->lgs_only && info.max_degree >= h->table_len)
         return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: vertex degree %d beyond the d^-1/2 table (%d entries)", info.max_degree,
                     h->table_len);
-    char* base = static_cast<char*>(s.in_dev);
+    // A batch of a few graphs is a few KB: the kernel reads it where the packer left it and writes its results where the
+    // caller reads them (pinned memory is device-addressable) - two copy commands and the gaps around them cost more
+    // than a handful of PCIe round trips inside the kernel (DGCN_HOST_DIRECT_BYTES: largest batch handled this way).
+    static const size_t direct_bytes = [] { const char* e = getenv("DGCN_HOST_DIRECT_BYTES"); return e ? (size_t)atol(e) : (size_t)(96 << 10); }();
+    const bool direct = (size_t)info.total_bytes <= direct_bytes;
+    char* base = static_cast<char*>(direct ? s.in_host_dev : s.in_dev);
     DgcnBatch b;
     b.num_graphs = info.num_graphs;
     b.num_nodes = info.num_nodes;
@@ -230,15 +241,18 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     }
     s.num_nodes = info.num_nodes;
     s.num_graphs = info.num_graphs;
+    s.direct = direct;
     if (info.num_graphs > 0 && info.num_nodes > 0) {
-        if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
+        if (direct) {
+            *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
+        } else if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
             if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
         } else if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
                    hipEventRecord(s.copied, h->copy_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess) {
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
         }
-        char* ob = static_cast<char*>(s.out_dev);
+        char* ob = static_cast<char*>(direct ? s.out_host_dev : s.out_dev);
         const double* wdev = info.off_weights >= 0 ? reinterpret_cast<const double*>(base + info.off_weights) : nullptr;
         if (h->lgs_only)
             rc = dgcn_lgs_batch(&b, wdev, nullptr, nullptr, 0, reinterpret_cast<uint8_t*>(ob + s.off_state),
@@ -254,7 +268,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
         if (rc) return rc;
         // one copy back: everything up to the end of the used part of `state`
         const size_t used = s.off_state + (size_t)info.num_nodes;
-        if (hipMemcpyAsync(s.out_host, s.out_dev, used, hipMemcpyDeviceToHost, s.stream) != hipSuccess)
+        if (!direct && hipMemcpyAsync(s.out_host, s.out_dev, used, hipMemcpyDeviceToHost, s.stream) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: device-to-host copy failed");
     } else {  // nothing to launch: graphs without vertices have total 0 after 0 rounds
         std::memset(s.out_host, 0, s.off_state);
@@ -283,7 +297,7 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
     if (status_bits) *status_bits = bits;
     if (num_nodes) *num_nodes = s.num_nodes;
     if (num_graphs) *num_graphs = s.num_graphs;
-    if (bits) {  // the status word accumulates: clear it for the slot's next batch
+    if (bits && !s.direct) {  // the status word accumulates: clear it for the slot's next batch
         (void)hipMemsetAsync(static_cast<char*>(s.out_dev) + s.off_status, 0, 4, s.stream);
     }
     return DGCN_OK;

@@ -29,8 +29,8 @@ def _run_native(eng, adj, w):
     a = as_csr(adj)
     if a.shape[0] != w.size:
         raise ValueError("adjacency has %d vertices, weights %d" % (a.shape[0], w.size))
-    h = hs.solve([a.indptr], [a.indices], [w], copy=False)
-    state = h["state"].copy()  # the pinned result buffer is re-used by the next call
+    h = hs.solve([a.indptr], [a.indices], [w])
+    state = h["state"]
     return {"state": state, "mwis": set(np.flatnonzero(state == 1).tolist()), "total": np.float64(h["totals"][0]),
             "rounds": int(h["rounds"][0])}
 

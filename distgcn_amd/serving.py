@@ -211,6 +211,11 @@ class HostSolver:
         self.depth = int(depth)
         self._p = [C.c_void_p() for _ in range(4)]
         self._i = [C.c_int32() for _ in range(3)]
+        # one-call path of the CPython helper (csrc/pyptr.c): submit + result without the interpreter in between
+        from .batch import _pyptr
+        helper = _pyptr()
+        self._solve_lists = getattr(helper, "solve_lists", None)
+        self._fn = (C.cast(self.lib.dgcn_host_solver_submit, C.c_void_p).value, C.cast(self.lib.dgcn_host_solver_result, C.c_void_p).value)
 
     def close(self):
         if self.handle:
@@ -272,6 +277,18 @@ class HostSolver:
         return out
 
     def solve(self, indptrs, indices, weights, copy: bool = True):
+        if self._solve_lists is not None and copy and len(indptrs) <= 64:
+            r = self._solve_lists(self._fn[0], self._fn[1], self.handle.value, indptrs, indices, weights)
+            if isinstance(r, int):
+                _lib.check(r, "dgcn_host_solver_submit")
+            state, totals, rounds, scores, bits, nn = r
+            Engine.check_status_bits(bits)
+            self._nn = np.frombuffer(nn, np.int32)
+            out = {"state": np.frombuffer(state, np.uint8), "totals": np.frombuffer(totals, np.float64),
+                   "rounds": np.frombuffer(rounds, np.int32)}
+            if self.want_scores:
+                out["scores"] = np.frombuffer(scores, np.float32) if scores is not None else np.zeros(0, np.float32)
+            return out
         return self.result(self.submit(indptrs, indices, weights), copy)
 
     def solve_many(self, batches, copy: bool = True, depth: Optional[int] = None):

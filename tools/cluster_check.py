@@ -6,14 +6,15 @@ import numpy as np, torch
 from distgcn_amd import datagen
 from distgcn_amd.engine import Engine, DeviceModel
 eng = Engine("cuda:0")
-for layers in (20, 3, 2):
+for layers in ((20,) if len(sys.argv) > 1 else (20, 3, 2)):
     model = DeviceModel(datagen.random_model(layers, 32), "cuda:0")
-    for B, n in ((1, 200), (3, 200), (8, 200), (20, 120), (32, 200), (64, 200), (5, 500), (2, 77)):
+    for B, n in ((1, 200), (3, 200), (8, 200), (16, 200), (20, 120), (32, 200), (64, 200), (5, 500), (2, 77), (4, 300), (8, 150)):
         hb = datagen.er_batch(B, n, 0.1 if n <= 200 else 0.02)
         db = eng.upload(hb)
         res = {}
         for mode in ("0", "auto"):
             if mode == "0": os.environ["DGCN_FUSED_CLUSTER"] = "0"
+            elif len(sys.argv) > 1: os.environ["DGCN_FUSED_CLUSTER"] = sys.argv[1]
             else: os.environ.pop("DGCN_FUSED_CLUSTER", None)
             out = eng.solve_buffers(db, True)
             for _ in range(20): eng.solve_fused(db, model, out=out, want_scores=True)
