@@ -339,17 +339,35 @@ __device__ __forceinline__ void cluster_wait(int32_t* flags, int K, int seq, int
 // has pulled layer l (=> every other workgroup has published l and is therefore done reading l - 1) it marks its own rows
 // in the slice of layer l + 2 (= that of l - 1) unwritten again; s_waitcnt + the barrier after the gather phase put those
 // marks into L2 before its next layer's rows leave, and nobody polls for l + 2 before having seen those.
+// A workgroup's <= 4 tiles on its 8 waves: with one or two tiles a tile's four 16-column blocks go to four waves (8 MFMAs
+// each instead of 32 in a row on one SIMD), with three or four to two waves.  Every output element still sees the same
+// eight MFMAs in the same order.
+struct ClusterTile {
+    int trow;      // row of lane & 15 in this wave's tile, -1 = none
+    int ct0, nct;  // this wave's column blocks [ct0, ct0 + nct) of the tile's four (Z0: 0, 1; Z1: 2, 3)
+};
 template <int BLOCK>
-__device__ __forceinline__ void cluster_mark_unwritten(const RowBlocks& rb, float* slice) {
+__device__ __forceinline__ void cluster_tile_init(ClusterTile& ct, int ng, const unsigned short* perm, int K, int cw) {
+    static_assert(BLOCK == 512, "eight waves");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blocks = (ng + 15) >> 4;
+    const int owned = blocks > cw ? (blocks - cw + K - 1) / K : 0;
+    const int wpt = owned <= 2 ? 4 : 2;  // waves per tile
+    const int blk = (wave / wpt) * K + cw;
+    const int tslot = blk * 16 + (lane & 15);
+    ct.trow = (blk < blocks && tslot < ng) ? (int)perm[tslot] : -1;
+    ct.nct = 4 / wpt;
+    ct.ct0 = (wave % wpt) * ct.nct;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void cluster_mark_unwritten(const ClusterTile& t, float* slice) {
     const int kq = (threadIdx.x & 63) >> 4;
     const float u = __uint_as_float(kUnwritten);
-#pragma unroll
-    for (int k = 0; k < kMaxRowBlocks; ++k) {
-        if (rb.trow[k] < 0) continue;
-        float* row = slice + rb.trow[k] * kHid;
-        *reinterpret_cast<float4*>(row + (kq << 2)) = make_float4(u, u, u, u);
-        *reinterpret_cast<float4*>(row + ((kq + 4) << 2)) = make_float4(u, u, u, u);
-    }
+    if (t.trow < 0 || t.ct0 != 0) return;  // one wave per tile
+    float* row = slice + t.trow * kHid;
+    *reinterpret_cast<float4*>(row + (kq << 2)) = make_float4(u, u, u, u);
+    *reinterpret_cast<float4*>(row + ((kq + 4) << 2)) = make_float4(u, u, u, u);
 }
 
 // the other workgroups' Z1 rows: global slice (same swizzled 128-byte rows as bufB) -> bufB, as soon as they are there
@@ -393,38 +411,33 @@ __device__ __forceinline__ void cluster_pull_rows(const float* slice, float* buf
     }
 }
 
-// hidden transform of the blocks this workgroup owns: rows in perm order, one tile per wave and k; Z1 goes to bufB AND
-// to the graph's exchange slice
+// hidden transform of the tiles this workgroup owns (rows in perm order); Z1 goes to bufB AND to the graph's exchange
+// slice.  Z0 replaces the tile's rows of H in bufA, and several waves read those: barrier between the reads and the writes.
 template <int BLOCK>
-__device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], const RowBlocks& rb, float* bufA, float* bufB,
+__device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], const ClusterTile& t, float* bufA, float* bufB,
                                                        float* slice) {
     const int lane = threadIdx.x & 63;
     const int kq = lane >> 4;
+    const int row = t.trow >= 0 ? t.trow : 0;  // lanes past the graph's end feed row 0 and write nothing
+    float av[8];
 #pragma unroll
-    for (int k = 0; k < kMaxRowBlocks; ++k) {
-        if (!__any(rb.trow[k] >= 0)) continue;
-        const int row = rb.trow[k] >= 0 ? rb.trow[k] : 0;  // lanes past the graph's end feed row 0 and write nothing
-        float av[8];
+    for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
+    __syncthreads();
+    if (!__any(t.trow >= 0)) return;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
-        f32x4 acc[4];
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < t.ct0 || ct >= t.ct0 + t.nct) continue;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc[ct], 0, 0, 0);
-        if (rb.trow[k] >= 0) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int chunk = (ct & 1) * 4 + kq;
-                const float4 o = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
-                if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
-                else {
-                    const int off = row * kHid + ((chunk ^ keyB(row)) << 2);
-                    *reinterpret_cast<float4*>(bufB + off) = o;
-                    *reinterpret_cast<float4*>(slice + off) = o;
-                }
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc, 0, 0, 0);
+        if (t.trow >= 0) {
+            const int chunk = (ct & 1) * 4 + kq;
+            const float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
+            else {
+                const int off = row * kHid + ((chunk ^ keyB(row)) << 2);
+                *reinterpret_cast<float4*>(bufB + off) = o;
+                *reinterpret_cast<float4*>(slice + off) = o;
             }
         }
     }
@@ -1047,7 +1060,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     RowBlocks rb;
     row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
     ClusterRows cr;
-    if constexpr (CLUSTER) cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+    ClusterTile ctile;
+    if constexpr (CLUSTER) {
+        cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+        cluster_tile_init<BLOCK>(ctile, has_wide ? ng : 0, perm, K, cw);
+    }
     if constexpr (CLUSTER) {
         if (threadIdx.x == 0) {  // where this workgroup runs: compared after the first exchange
             unsigned id;
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         }
         // whatever an earlier launch left in the exchange slices: this workgroup's rows read "unwritten" from here on,
         // and the others learn through the progress word that they do (waited for in front of the first pull)
-        for (int t = 0; t < 3; ++t) cluster_mark_unwritten<BLOCK>(rb, a.xz + ((size_t)g * 3 + t) * a.max_nodes * kHid);
+        for (int t = 0; t < 3; ++t) cluster_mark_unwritten<BLOCK>(ctile, a.xz + ((size_t)g * 3 + t) * a.max_nodes * kHid);
         if ((int)threadIdx.x < ng && ((ipos[threadIdx.x] >> 4) % K) == cw) {  // the last layer's scalars likewise
             float* xs0 = a.xs + (size_t)g * 2 * a.max_nodes;
             xs0[threadIdx.x] = __uint_as_float(kUnwritten);
@@ -1132,9 +1149,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             else if constexpr (CLUSTER) {
                 float* xz0 = a.xz + (size_t)g * 3 * a.max_nodes * kHid;
                 float* slice = xz0 + (size_t)(l % 3) * a.max_nodes * kHid;
-                hidden_transform_owned<BLOCK>(bfrag, rb, bufA, bufB, slice);
+                hidden_transform_owned<BLOCK>(bfrag, ctile, bufA, bufB, slice);
                 cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw, a.status);
-                cluster_mark_unwritten<BLOCK>(rb, xz0 + (size_t)((l + 2) % 3) * a.max_nodes * kHid);
+                cluster_mark_unwritten<BLOCK>(ctile, xz0 + (size_t)((l + 2) % 3) * a.max_nodes * kHid);
             }
             else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
