@@ -572,7 +572,7 @@ struct ClusterRows {
 
 template <int BLOCK>
 __device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                  const uint2* rec, int K, int cw) {
+                                                  const float* vals, const unsigned short* words, int K, int cw) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = (wave >> 1) * K + cw;                      // tile `wave / 2` of this workgroup
     const int slot = blk * 16 + (wave & 1) * 8 + (lane >> 3);  // its lower / upper half
@@ -587,7 +587,10 @@ __device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const
         const int rs = (int)(cr.ri & 0xffff), cnt = (int)(cr.ri >> 16);
 #pragma unroll
         for (int i = 0; i < kRecCache; ++i)
-            if (4 * i < cnt) cr.recs[i] = rec[rs + 4 * i + (lane & 3)];
+            if (4 * i < cnt) {  // (straight from the LDS image: same bits as the global records, no L2 round trip)
+                const int e = rs + 4 * i + (lane & 3);
+                cr.recs[i] = make_uint2(__float_as_uint(vals[e]), (unsigned)words[e]);
+            }
     }
 }
 
@@ -1049,7 +1052,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     // (32-wide aggregations only: a one-layer model has none)
     const bool has_wide = !(MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN)) &&
                           (a.wide_passes > 1 || (a.num_layers > 1 && a.layers[0].cout == kHid));
-    if (has_wide) {
+    // (cluster variant: the first 4 * kRecCache entries of every row stay in registers; rows are in descending entry
+    // order, so the global copy is needed only if the first one is longer than that)
+    bool want_rec = has_wide;
+    if constexpr (CLUSTER) want_rec = has_wide && (int)(rinfo[perm[0]] >> 16) > 4 * kRecCache;
+    if (want_rec) {
         // the support once more as 8-byte records in global memory (L2-resident: 19 layers re-read them)
         const unsigned rl = rinfo[ng - 1];
         const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
@@ -1058,11 +1065,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     }
     __syncthreads();
     RowBlocks rb;
-    row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
     ClusterRows cr;
     ClusterTile ctile;
+    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
     if constexpr (CLUSTER) {
-        cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+        cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
         cluster_tile_init<BLOCK>(ctile, has_wide ? ng : 0, perm, K, cw);
     }
     if constexpr (CLUSTER) {
