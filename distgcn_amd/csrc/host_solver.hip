@@ -220,7 +220,8 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     // A batch of a few graphs is a few KB: the kernel reads it where the packer left it and writes its results where the
     // caller reads them (pinned memory is device-addressable) - two copy commands and the gaps around them cost more
     // than a handful of PCIe round trips inside the kernel (DGCN_HOST_DIRECT_BYTES: largest batch handled this way).
-    static const size_t direct_bytes = [] { const char* e = getenv("DGCN_HOST_DIRECT_BYTES"); return e ? (size_t)atol(e) : (size_t)(96 << 10); }();
+    const char* direct_env = getenv("DGCN_HOST_DIRECT_BYTES");
+    const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(96 << 10);
     const bool direct = (size_t)info.total_bytes <= direct_bytes;
     char* base = static_cast<char*>(direct ? s.in_host_dev : s.in_dev);
     DgcnBatch b;

@@ -966,6 +966,23 @@ def test_native_host_solver(engine, golden):
     assert g["state"].size == 0 and g["totals"].tolist() == [0.0] and g["rounds"].tolist() == [0]
     with pytest.raises(ValueError, match="does not match"):
         hs.submit([batches[1][0][0]], [batches[1][1][0][:-2]], [batches[1][2][0]])
+    with pytest.raises(ValueError, match="does not match"):  # the one-call path of the CPython helper checks the same
+        hs.solve([batches[1][0][0]], [batches[1][1][0][:-2]], [batches[1][2][0]])
+    with pytest.raises(TypeError):
+        hs.solve([batches[1][0][0].astype(np.float32)], [batches[1][1][0]], [batches[1][2][0]])
+    # small batches are read in place from the pinned staging memory and write their results there; larger ones (or
+    # DGCN_HOST_DIRECT_BYTES=0) take the two copies: same answers, through both the one-call and the two-call path
+    import os
+    for direct in ("0", None):
+        if direct is None:
+            os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
+        else:
+            os.environ["DGCN_HOST_DIRECT_BYTES"] = direct
+        for b, r in zip(batches, refs):
+            for g in (hs.solve(*b), hs.result(hs.submit(*b))):
+                assert np.array_equal(g["state"], r["state"]) and np.array_equal(g["rounds"], r["rounds"])
+                assert np.allclose(g["totals"], r["totals"], rtol=1e-12, atol=0)
+                assert np.array_equal(g["scores"].view(np.uint32), np.asarray(r["scores"], np.float32).ravel().view(np.uint32))
     hs.close()
 
 

@@ -691,3 +691,37 @@ def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch)
                 continue
             for k in ref:
                 assert np.array_equal(ref[k].view(np.uint8), got[k].view(np.uint8)), (force, k, hb.num_graphs)
+
+
+@pytest.mark.gpu
+def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch):
+    """The cluster variant's readers poll the exchange slices themselves (a chunk that still reads "unwritten" is not
+    there yet), so what a previous launch - of any kind - left in the workspace must never look like data: every workgroup
+    marks its rows at kernel start and the others wait for that once.  Alternate cluster launches of different batch
+    shapes with ordinary launches that scribble over the same workspace, many times, automatic K (1, 8, 32 and 64
+    graphs: the variant now runs whenever every workgroup is resident); always bit-identical to the ordinary launch."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    model = DeviceModel(datagen.random_model(20, 32), engine.device)
+    shapes = [(1, 200), (32, 200), (8, 150), (64, 200), (4, 300), (1, 200)]
+    dbs = [engine.upload(datagen.er_batch(b, n, 0.1 if n <= 200 else 0.05, first_index=900 + 7 * i)) for i, (b, n) in enumerate(shapes)]
+    big = engine.upload(datagen.er_batch(300, 120, 0.1, first_index=990))  # far too many graphs to cluster: an ordinary launch
+    refs = []
+    monkeypatch.setenv("DGCN_FUSED_CLUSTER", "0")
+    for db in dbs:
+        out = engine.solve_buffers(db, True)
+        engine.solve_fused(db, model, out=out, want_scores=True)
+        refs.append({k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")})
+    monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
+    for rep in range(4):
+        for db, ref in zip(dbs, refs):
+            out = engine.solve_buffers(db, True)
+            for _ in range(1 + rep):
+                engine.solve_fused(db, model, out=out, want_scores=True)
+            got = {k: out[k].cpu().numpy().copy() for k in ref}
+            assert int(got["status"][0]) == 0
+            for k in ref:
+                assert np.array_equal(ref[k].view(np.uint8), got[k].view(np.uint8)), (rep, k, db.num_graphs)
+            engine.solve_fused(big, model, out=engine.solve_buffers(big, True))  # same workspace, other layout
+    torch.cuda.synchronize()

@@ -260,3 +260,32 @@ def test_native_pack_survives_fork():
         time.sleep(0.05)
     os.kill(pid, 9)
     raise AssertionError("forked child hung in dgcn_pack_batch")
+
+
+def test_one_call_helper_checks_its_arguments_before_calling_anything():
+    """csrc/pyptr.c solve_lists(): the per-graph API's one interpreter call around dgcn_host_solver_submit/_result.  Its
+    argument checks run before either entry point is touched (the addresses below are 0), with the interpreter path's
+    error types: TypeError for index / weight dtypes the native packer does not take (callers fall back on those),
+    ValueError for lengths that do not fit together."""
+    from distgcn_amd.batch import _pyptr
+    m = _pyptr()
+    assert m is not None and hasattr(m, "solve_lists"), "the CPython helper has not been built (__graft_entry__.build)"
+    ip, ix, w = np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), np.ones(2)
+    with pytest.raises(ValueError, match="indices array does not match"):
+        m.solve_lists(0, 0, 0, [ip], [ix[:1]], [w])
+    with pytest.raises(ValueError, match="weights array does not match"):
+        m.solve_lists(0, 0, 0, [ip], [ix], [np.ones(3)])
+    with pytest.raises(ValueError, match="differ in length"):
+        m.solve_lists(0, 0, 0, [ip, ip], [ix], None)
+    with pytest.raises(ValueError, match="empty"):
+        m.solve_lists(0, 0, 0, [np.zeros(0, np.int32)], [np.zeros(0, np.int32)], None)
+    with pytest.raises(TypeError, match="int32 or int64"):
+        m.solve_lists(0, 0, 0, [ip.astype(np.int64)], [ix], [w])  # two widths in one call
+    with pytest.raises(TypeError, match="int32 or int64"):
+        m.solve_lists(0, 0, 0, [ip.astype(np.float64)], [ix], [w])
+    with pytest.raises(TypeError, match="float64"):
+        m.solve_lists(0, 0, 0, [ip], [ix], [w.astype(np.float32)])
+    with pytest.raises((ValueError, BufferError)):
+        m.solve_lists(0, 0, 0, [np.arange(6, dtype=np.int32)[::2]], [ix], [w])  # not contiguous
+    with pytest.raises(ValueError, match="more than 64"):
+        m.solve_lists(0, 0, 0, [ip] * 65, [ix] * 65, None)
