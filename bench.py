@@ -424,6 +424,44 @@ def e2e_probe(args, wl, reference_state):
             "pack_ms_per_batch": pack_ms, "results_equal_resident_step": same}
 
 
+def single_graph_probe(args, wl):
+    """The reference's own call pattern - ONE graph per call (mwis_dqn_call.py:140-143, once per slot in the wireless
+    loop): host CSR arrays of one graph of this batch -> its set, total and rounds in host memory through a one-slot
+    HostSolver (one interpreter call around dgcn_host_solver_submit / _result), and the kernel alone on a resident
+    one-graph batch.  Latency, reported beside ``value``."""
+    import torch
+    from distgcn_amd.serving import HostSolver
+    hb = wl.hb
+    graphs = []
+    for n0, n1 in list(hb.graph_slices())[:8]:
+        e0, e1 = int(hb.row_ptr[n0]), int(hb.row_ptr[n1])
+        graphs.append(([np.ascontiguousarray(hb.row_ptr[n0:n1 + 1] - e0, dtype=np.int32)],
+                       [np.ascontiguousarray(hb.col_idx[e0:e1] - n0, dtype=np.int32)], [np.ascontiguousarray(hb.weights[n0:n1])]))
+    hs = HostSolver(wl.eng, wl.model, depth=1)
+    calls = 400
+    for i in range(40):
+        hs.solve(*graphs[i % len(graphs)])
+    t0 = time.perf_counter()
+    for i in range(calls):
+        hs.solve(*graphs[i % len(graphs)])
+    call_us = (time.perf_counter() - t0) / calls * 1e6
+    hs.close()
+    db = wl.eng.upload(hb.subset(0, 1))
+    out = wl.eng.solve_buffers(db, False)
+    for _ in range(40):
+        wl.eng.solve_fused(db, wl.model, out=out)
+    torch.cuda.synchronize()
+    wl.eng.timing(True)
+    for _ in range(200):
+        wl.eng.solve_fused(db, wl.model, out=out)
+    torch.cuda.synchronize()
+    wl.eng.timing(False)
+    ms, n = wl.eng.timing_read("fused_solve")
+    return {"call_us": call_us, "kernel_us": ms / max(n, 1) * 1e3, "calls": calls,
+            "path": "HostSolver(depth=1).solve on one graph of the batch: native pack into pinned memory, k_fused reading it in "
+                    "place (several workgroups per graph on one XCD when the stack is deep enough), results written to pinned memory"}
+
+
 def margin_probe(wl):
     """how many of this batch's selected sets could a score error flip?  For delta = 2 x the score
     tolerance (1e-5) and 2 x the error measured against the float32 restatement for this model
@@ -579,6 +617,10 @@ def main(argv=None, workload_factory=None):
     if rank == 0 and world == 1 and not args.no_e2e and isinstance(wl, GpuWorkload) and wl.ring is not None:
         e2e = e2e_probe(args, wl, res["state"].cpu().numpy())
 
+    single = None
+    if rank == 0 and world == 1 and not args.no_e2e and isinstance(wl, GpuWorkload) and wl.ring is not None:
+        single = single_graph_probe(args, wl)
+
     if rank == 0:
         per_gpu = args.graphs if args.scaling == "weak" else None
         out = {
@@ -605,6 +647,7 @@ def main(argv=None, workload_factory=None):
                        "forward_mode": getattr(wl, "mode_name", "?"), "graphs_per_gpu": per_gpu, "job_graphs": wl.job_graphs,
                        "parallelism": "graph-sharded x%d" % world},
             "e2e": e2e,
+            "single_graph": single,
             "margin_risk": margin,
             "dist": dist_report,
             "roofline": roofline,
