@@ -1666,7 +1666,7 @@ static size_t fused_pad_bytes(const DgcnModel* m) {
 // (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
 static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool masked) {
     if (masked || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
-    if (fused_variant(max(b->max_nodes, 64), meta_cap) != 0) return 0;
+    if (fused_variant(max(b->max_nodes, 64), meta_cap) < 0 || b->max_nodes > kFusedBlock) return 0;  // (a vertex per thread in the last layer)
     const int blocks = (b->max_nodes + 15) / 16;
     const int gpad = (b->num_graphs + 7) & ~7;
     // every workgroup of every graph must be resident at once; two tiles per workgroup is as fine as it pays
@@ -1831,6 +1831,22 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
                : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
 }
 
+template <bool GVALS>
+static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    static std::atomic<size_t> reserved[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 64 * 1024 && lds > reserved[dev & 63].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<false, GVALS, kFusedBlock, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
+        reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
+    }
+    TimedLaunch t(family, s);
+    DGCN_LAUNCH(t, (k_fused<false, GVALS, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
+    return check_launch("k_fused (cluster)");
+}
+
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
     a.prio_gather = getenv("DGCN_FUSED_PRIOG") ? atoi(getenv("DGCN_FUSED_PRIOG")) : 1;
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 5;
@@ -1841,20 +1857,7 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
-    if (a.cluster > 1 && !masked && !gvals) {
-        static std::atomic<size_t> reserved[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (lds > 64 * 1024 && lds > reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<false, false, kFusedBlock, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
-                return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
-            reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
-        }
-        TimedLaunch t(family, s);
-        DGCN_LAUNCH(t, (k_fused<false, false, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
-        return check_launch("k_fused (cluster)");
-    }
+    if (a.cluster > 1 && !masked) return gvals ? fused_launch_cluster<true>(a, B, lds, family, s) : fused_launch_cluster<false>(a, B, lds, family, s);
     if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
     return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
 }

@@ -704,8 +704,9 @@ def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch
     from distgcn_amd import datagen
     from distgcn_amd.engine import DeviceModel
     model = DeviceModel(datagen.random_model(20, 32), engine.device)
-    shapes = [(1, 200), (32, 200), (8, 150), (64, 200), (4, 300), (1, 200)]
-    dbs = [engine.upload(datagen.er_batch(b, n, 0.1 if n <= 200 else 0.05, first_index=900 + 7 * i)) for i, (b, n) in enumerate(shapes)]
+    shapes = [(1, 200), (32, 200), (8, 150), (64, 200), (4, 300), (3, 500), (1, 200)]  # N = 500: entry values in global memory
+    dbs = [engine.upload(datagen.er_batch(b, n, 0.1 if n <= 200 else (0.05 if n <= 300 else 0.02), first_index=900 + 7 * i))
+           for i, (b, n) in enumerate(shapes)]
     big = engine.upload(datagen.er_batch(300, 120, 0.1, first_index=990))  # far too many graphs to cluster: an ordinary launch
     refs = []
     monkeypatch.setenv("DGCN_FUSED_CLUSTER", "0")
