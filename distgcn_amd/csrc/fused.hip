@@ -86,6 +86,7 @@ struct FusedArgs {
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
     // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
     int32_t cluster;
+    int32_t cluster_inject;  // test hook (DGCN_FUSED_CLUSTER_INJECT_FAULT=1): report a placement fault although there is none
     int32_t epoch;      // progress words count from here: values a previous launch left behind (possibly still cached in
                         // this XCD's L2, whatever a memset from elsewhere did to the memory) are always smaller
     int32_t num_graphs;
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if constexpr (CLUSTER) {
             if (l == 1) {  // before the first pull: every workgroup of the graph has marked its exchange rows
                 cluster_wait<BLOCK>(xfl, K, a.epoch, a.status);
+                if (a.cluster_inject && threadIdx.x == 0 && a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
                 if ((int)threadIdx.x < K) {  // all on one XCD?  (the cheap visibility rule above depends on it)
                     const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
                     if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
@@ -1771,6 +1773,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     }
     a->num_graphs = b->num_graphs;
     a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
+    a->cluster_inject = getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT") ? atoi(getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT")) : 0;
     if (a->cluster > 1) {
         const size_t need = fused_cluster_bytes(b, a->cluster);
         if (!workspace || workspace_bytes < need)

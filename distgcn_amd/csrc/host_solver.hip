@@ -38,6 +38,8 @@ struct DgcnHostSolver {
         int num_nodes = 0, num_graphs = 0;
         bool busy = false;
         bool direct = false;  // this batch: the kernel reads / writes the pinned host buffers itself
+        DgcnBatch batch;      // what was launched (pointers into in_dev or in_host_dev): kept for a relaunch
+        long long off_weights = -1;
     };
     bool lgs_only = false;  // no model: priority = weight, the plain local greedy search (heuristics.py:77-116)
     DgcnModel model;
@@ -133,6 +135,31 @@ static int ensure_ws(DgcnHostSolver::Slot& s, size_t bytes) {
     const size_t cap = bytes + bytes / 4 + 256;
     if (hipMalloc(&s.ws, cap) != hipSuccess) return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes of scratch", cap);
     s.ws_cap = cap;
+    return DGCN_OK;
+}
+
+// kernel(s) + copy back of the batch a slot holds, on the slot's stream
+static int launch_slot(DgcnHostSolver* h, DgcnHostSolver::Slot& s) {
+    const DgcnBatch& b = s.batch;
+    char* base = static_cast<char*>(s.direct ? s.in_host_dev : s.in_dev);
+    char* ob = static_cast<char*>(s.direct ? s.out_host_dev : s.out_dev);
+    const double* wdev = s.off_weights >= 0 ? reinterpret_cast<const double*>(base + s.off_weights) : nullptr;
+    int rc;
+    if (h->lgs_only)
+        rc = dgcn_lgs_batch(&b, wdev, nullptr, nullptr, 0, reinterpret_cast<uint8_t*>(ob + s.off_state),
+                            reinterpret_cast<int32_t*>(ob + s.off_rounds), nullptr, nullptr, wdev,
+                            reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.stream);
+    else
+        rc = dgcn_solve_batch(&b, &h->model, h->table, h->table_len, nullptr, h->x_const, wdev, h->predict_mwis,
+                              h->want_scores ? reinterpret_cast<float*>(ob + s.off_scores) : nullptr,
+                              reinterpret_cast<uint8_t*>(ob + s.off_state), reinterpret_cast<int32_t*>(ob + s.off_rounds),
+                              reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.ws,
+                              s.ws_cap, s.stream);
+    if (rc) return rc;
+    // one copy back: everything up to the end of the used part of `state`
+    const size_t used = s.off_state + (size_t)s.num_nodes;
+    if (!s.direct && hipMemcpyAsync(s.out_host, s.out_dev, used, hipMemcpyDeviceToHost, s.stream) != hipSuccess)
+        return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver: device-to-host copy failed");
     return DGCN_OK;
 }
 
@@ -243,6 +270,8 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     s.num_nodes = info.num_nodes;
     s.num_graphs = info.num_graphs;
     s.direct = direct;
+    s.batch = b;
+    s.off_weights = info.off_weights;
     if (info.num_graphs > 0 && info.num_nodes > 0) {
         if (direct) {
             *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
@@ -253,24 +282,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
                    hipEventRecord(s.copied, h->copy_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess) {
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
         }
-        char* ob = static_cast<char*>(direct ? s.out_host_dev : s.out_dev);
-        const double* wdev = info.off_weights >= 0 ? reinterpret_cast<const double*>(base + info.off_weights) : nullptr;
-        if (h->lgs_only)
-            rc = dgcn_lgs_batch(&b, wdev, nullptr, nullptr, 0, reinterpret_cast<uint8_t*>(ob + s.off_state),
-                                reinterpret_cast<int32_t*>(ob + s.off_rounds), nullptr, nullptr, wdev,
-                                reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.stream);
-        else
-        rc = dgcn_solve_batch(&b, &h->model, h->table, h->table_len, nullptr, h->x_const,
-                              info.off_weights >= 0 ? reinterpret_cast<const double*>(base + info.off_weights) : nullptr,
-                              h->predict_mwis, h->want_scores ? reinterpret_cast<float*>(ob + s.off_scores) : nullptr,
-                              reinterpret_cast<uint8_t*>(ob + s.off_state),
-                              reinterpret_cast<int32_t*>(ob + s.off_rounds), reinterpret_cast<double*>(ob + s.off_totals),
-                              reinterpret_cast<int32_t*>(ob + s.off_status), s.ws, s.ws_cap, s.stream);
-        if (rc) return rc;
-        // one copy back: everything up to the end of the used part of `state`
-        const size_t used = s.off_state + (size_t)info.num_nodes;
-        if (!direct && hipMemcpyAsync(s.out_host, s.out_dev, used, hipMemcpyDeviceToHost, s.stream) != hipSuccess)
-            return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: device-to-host copy failed");
+        if ((rc = launch_slot(h, s))) return rc;
     } else {  // nothing to launch: graphs without vertices have total 0 after 0 rounds
         std::memset(s.out_host, 0, s.off_state);
     }
@@ -290,7 +302,20 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
     if (hipEventSynchronize(s.done) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
     s.busy = false;
     const char* oh = static_cast<const char*>(s.out_host);
-    const int32_t bits = *reinterpret_cast<const int32_t*>(oh + s.off_status);
+    int32_t bits = *reinterpret_cast<const int32_t*>(oh + s.off_status);
+    if ((bits & DGCN_FAULT_CLUSTER) && !h->lgs_only && s.num_nodes > 0) {
+        // The several-workgroups-per-graph variant of the fused kernel found its workgroups on different XCDs (a partition
+        // mode with another dispatch order) or lost one: its results cannot be trusted.  Switch the variant off for the
+        // rest of the process and solve the batch again - it is still where the packer put it.
+        setenv("DGCN_FUSED_CLUSTER", "0", 1);
+        if (s.direct) *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
+        else if (hipMemsetAsync(static_cast<char*>(s.out_dev) + s.off_status, 0, 4, s.stream) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: clearing the status word failed");
+        int rc = launch_slot(h, s);
+        if (rc) return rc;
+        if (hipStreamSynchronize(s.stream) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
+        bits = *reinterpret_cast<const int32_t*>(oh + s.off_status);
+    }
     if (state) *state = reinterpret_cast<const uint8_t*>(oh + s.off_state);
     if (totals) *totals = reinterpret_cast<const double*>(oh + s.off_totals);
     if (rounds) *rounds = reinterpret_cast<const int32_t*>(oh + s.off_rounds);

@@ -984,6 +984,36 @@ def test_native_host_solver(engine, golden):
                 assert np.allclose(g["totals"], r["totals"], rtol=1e-12, atol=0)
                 assert np.array_equal(g["scores"].view(np.uint32), np.asarray(r["scores"], np.float32).ravel().view(np.uint32))
     hs.close()
+    # A placement fault of the several-workgroups-per-graph kernel (injected: DGCN_FUSED_CLUSTER_INJECT_FAULT) is not the
+    # caller's problem: the object switches the variant off for the process, solves the batch again and hands out that.
+    import ctypes
+    c_getenv = ctypes.CDLL(None).getenv
+    c_getenv.restype, c_getenv.argtypes = ctypes.c_char_p, [ctypes.c_char_p]
+    saved = os.environ.get("DGCN_FUSED_CLUSTER")
+    os.environ.pop("DGCN_FUSED_CLUSTER", None)
+    os.environ["DGCN_FUSED_CLUSTER_INJECT_FAULT"] = "1"
+    try:
+        for direct in ("0", None):
+            if direct is None:
+                os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
+            else:
+                os.environ["DGCN_HOST_DIRECT_BYTES"] = direct
+            os.environ.pop("DGCN_FUSED_CLUSTER", None)
+            os.unsetenv("DGCN_FUSED_CLUSTER")  # (the library's setenv is invisible to os.environ)
+            one = HostSolver(engine, dm, depth=1, want_scores=True)
+            g = one.solve(*batches[1])  # one N = 200 graph, 20 layers: the cluster variant's case
+            assert c_getenv(b"DGCN_FUSED_CLUSTER") == b"0"
+            assert np.array_equal(g["state"], refs[1]["state"]) and np.array_equal(g["rounds"], refs[1]["rounds"])
+            assert np.array_equal(g["scores"].view(np.uint32), np.asarray(refs[1]["scores"], np.float32).ravel().view(np.uint32))
+            one.close()
+    finally:
+        os.environ.pop("DGCN_FUSED_CLUSTER_INJECT_FAULT", None)
+        os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
+        os.unsetenv("DGCN_FUSED_CLUSTER")
+        if saved is None:
+            os.environ.pop("DGCN_FUSED_CLUSTER", None)
+        else:
+            os.environ["DGCN_FUSED_CLUSTER"] = saved
 
 
 def _ref_exec():
