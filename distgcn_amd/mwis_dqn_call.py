@@ -229,11 +229,18 @@ def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str
     use_fused = fused_ok if mode == "auto" else (mode == "fused")
     from .engine import MODE_FUSED, MODE_LAYERED
     if use_fused and hb.num_nodes > 0:  # one launch, one device-to-host copy
-        out = eng.solve_buffers(db, True)
-        eng.solve_fused(db, dm, predict=predict, X=X, out=out)
-        res = eng.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
-        eng.check_status_bits(res.pop("status"))
-        return res
+        for attempt in (0, 1):
+            out = eng.solve_buffers(db, True)
+            eng.solve_fused(db, dm, predict=predict, X=X, out=out)
+            res = eng.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
+            bits = int(res.pop("status"))
+            if bits == 16 and attempt == 0:  # placement fault of the cluster variant: it is off now, once more
+                try:
+                    eng.check_status_bits(bits)
+                except _lib.DgcnError:
+                    continue
+            eng.check_status_bits(bits)
+            return res
     res = eng.solve(db, dm, predict=predict, mode=MODE_FUSED if use_fused else MODE_LAYERED, X=X)
     eng.check_status(res["status"])
     return {"state": res["state"].cpu().numpy(), "totals": res["totals"].cpu().numpy(),
