@@ -50,6 +50,17 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     return x;
 }
 
+// Completion word for the one-graph latency path (host_solver.hip -> fused.hip): the next dgcn_solve_batch of this thread
+// makes every graph's finishing workgroup count itself in `count` (device memory) once its outputs have left the CU, and the
+// one that reaches `target` stores it to `flag` (pinned host memory) - the host can stop waiting some microseconds before
+// the queue's own end-of-kernel signal arrives.  Consumed (cleared) by that call.
+struct DoneHook {
+    int32_t* flag = nullptr;
+    uint32_t* count = nullptr;
+    uint32_t target = 0;
+};
+extern thread_local DoneHook g_done_hook;
+
 // dgcn_pack_batch with one more check for callers whose kernel cannot report it (pack.hip)
 int pack_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
                const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host,

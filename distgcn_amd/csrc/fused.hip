@@ -86,6 +86,9 @@ struct FusedArgs {
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
     // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
     int32_t cluster;
+    int32_t* done_flag;    // see DoneHook (common.h); null = no completion word
+    uint32_t* done_count;
+    uint32_t done_target;
     int32_t cluster_inject;  // test hook (DGCN_FUSED_CLUSTER_INJECT_FAULT=1): report a placement fault although there is none
     int32_t epoch;      // progress words count from here: values a previous launch left behind (possibly still cached in
                         // this XCD's L2, whatever a memset from elsewhere did to the memory) are always smaller
@@ -767,6 +770,18 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
     return r;
 }
 
+// this graph is done and its outputs have left the CU: count it, the last one tells the host (DoneHook, common.h)
+__device__ __forceinline__ void signal_done(const FusedArgs& a) {
+    if (!a.done_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();  // outputs may still sit in this XCD's L2: write them back before anybody is told
+        const unsigned prev = atomicAdd(a.done_count, 1u);
+        if (prev + 1u == a.done_target) __hip_atomic_store(a.done_flag, (int32_t)a.done_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false>
 // (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
@@ -805,6 +820,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (a.rounds) a.rounds[g] = 0;
             if (a.totals) a.totals[g] = 0.0;
         }
+        if (!MASKED && cw == 0 && a.do_lgs) signal_done(a);
         return;
     }
     // Two workgroups share a CU and the hardware favours the older one: measured, the first-dispatched
@@ -1265,7 +1281,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 float o = z0 + acc;
                 if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
-                if (a.scores) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;
+                if (a.scores && !(CLUSTER && a.do_lgs)) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;  // (cluster + search: below)
                 if constexpr (CLUSTER) xs0[a.max_nodes + v] = score;
             }
             if constexpr (CLUSTER) {
@@ -1275,6 +1291,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     return;
                 }
                 if (v < ng && !owned) score = poll_l2_scalar(xs0 + a.max_nodes + v, a.status);
+                // every output of the graph leaves from this workgroup: one place to wait for before telling the host
+                if (a.scores && v < ng) a.scores[n0 + v] = score;
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -1440,6 +1458,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (a.totals) a.totals[g] = 0.0;
         }
         if ((int)threadIdx.x < ng) a.state[n0 + threadIdx.x] = 0;
+        signal_done(a);
         return;
     }
     int lsh = 0;  // lanes per vertex = 1 << lsh, as many as the block affords (<= 8)
@@ -1559,6 +1578,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (threadIdx.x == 0) a.totals[g] = tot;
     }
     if (fault) atomicOr(a.status, fault);
+    signal_done(a);
     STAMP(a, g, 11, tclk);  // totals, output
     }
 }
@@ -1919,6 +1939,8 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
                                 const float* X, float x_const, const double* weights, int32_t predict_mwis,
                                 float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status,
                                 void* workspace, size_t workspace_bytes, void* stream) {
+    const DoneHook hook = g_done_hook;  // (host_solver.hip's completion word: this call's, whatever becomes of it)
+    g_done_hook = DoneHook{};
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
@@ -1945,6 +1967,9 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     bool gvals = false;
     int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream);
     if (rc) return rc;
+    args.done_flag = hook.flag;
+    args.done_count = hook.count;
+    args.done_target = hook.target;
     return fused_launch(args, b->num_graphs, lds, "fused_solve", (hipStream_t)stream, false, gvals);
 }
 

@@ -12,6 +12,7 @@
 // with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
 // consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
 // DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -40,6 +41,9 @@ struct DgcnHostSolver {
         bool direct = false;  // this batch: the kernel reads / writes the pinned host buffers itself
         DgcnBatch batch;      // what was launched (pointers into in_dev or in_host_dev): kept for a relaunch
         long long off_weights = -1;
+        uint32_t* done_count = nullptr;  // device: graphs finished, all batches of this slot (DoneHook, common.h)
+        uint32_t done_total = 0;         // what it reads once the current batch is through (0 = no completion word in use)
+        uint32_t done_base = 0;          // graphs launched with a completion word so far
     };
     bool lgs_only = false;  // no model: priority = weight, the plain local greedy search (heuristics.py:77-116)
     DgcnModel model;
@@ -149,12 +153,18 @@ static int launch_slot(DgcnHostSolver* h, DgcnHostSolver::Slot& s) {
         rc = dgcn_lgs_batch(&b, wdev, nullptr, nullptr, 0, reinterpret_cast<uint8_t*>(ob + s.off_state),
                             reinterpret_cast<int32_t*>(ob + s.off_rounds), nullptr, nullptr, wdev,
                             reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.stream);
-    else
+    else {
+        if (s.done_total) {  // the finishing workgroups count themselves; the last one writes the word beside the status
+            g_done_hook.flag = reinterpret_cast<int32_t*>(ob + s.off_status + 8);
+            g_done_hook.count = s.done_count;
+            g_done_hook.target = s.done_total;
+        }
         rc = dgcn_solve_batch(&b, &h->model, h->table, h->table_len, nullptr, h->x_const, wdev, h->predict_mwis,
                               h->want_scores ? reinterpret_cast<float*>(ob + s.off_scores) : nullptr,
                               reinterpret_cast<uint8_t*>(ob + s.off_state), reinterpret_cast<int32_t*>(ob + s.off_rounds),
                               reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.ws,
                               s.ws_cap, s.stream);
+    }
     if (rc) return rc;
     // one copy back: everything up to the end of the used part of `state`
     const size_t used = s.off_state + (size_t)s.num_nodes;
@@ -194,6 +204,9 @@ int dgcn_host_solver_create(const DgcnModel* model, const double* dinv_table, in
         return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver_create: cannot create a stream");
     }
     for (auto& s : h->slots) {
+        void* cnt = nullptr;
+        if (hipMalloc(&cnt, 256) == hipSuccess && hipMemset(cnt, 0, 256) == hipSuccess) s.done_count = static_cast<uint32_t*>(cnt);
+        else if (cnt) (void)hipFree(cnt);
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
@@ -213,6 +226,7 @@ void dgcn_host_solver_destroy(DgcnHostSolver* h) {
         free_in(s);
         free_out(s);
         if (s.ws) (void)hipFree(s.ws);
+        if (s.done_count) (void)hipFree(s.done_count);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -272,9 +286,18 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     s.direct = direct;
     s.batch = b;
     s.off_weights = info.off_weights;
+    s.done_total = 0;
     if (info.num_graphs > 0 && info.num_nodes > 0) {
         if (direct) {
-            *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
+            int32_t* st = reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status);
+            st[0] = 0;
+            // the latency path (one slot, nothing else to do meanwhile): a completion word written by the kernel itself
+            static const bool word_ok = [] { const char* e = getenv("DGCN_HOST_DONE_WORD"); return !e || atoi(e) != 0; }();
+            if (word_ok && h->slots.size() == 1 && !h->lgs_only && s.done_count) {
+                s.done_base += (uint32_t)info.num_graphs;
+                s.done_total = s.done_base;
+                st[2] = 0;
+            }
         } else if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
             if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
@@ -299,7 +322,17 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
     DgcnHostSolver::Slot& s = h->slots[slot];
     if (!s.busy) return fail(DGCN_ERR_ARG, "dgcn_host_solver_result: slot %d holds no result", slot);
     DeviceScope on_device(h->device);
-    if (hipEventSynchronize(s.done) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
+    bool seen = false;
+    if (s.done_total) {  // the kernel's own word first; the event as well now and then (a fault path may not count itself)
+        volatile const int32_t* word = reinterpret_cast<volatile const int32_t*>(static_cast<const char*>(s.out_host) + s.off_status + 8);
+        for (unsigned spins = 1;; ++spins) {
+            if ((uint32_t)*word == s.done_total) { seen = true; break; }
+            if ((spins & 255u) == 0 && hipEventQuery(s.done) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen && hipEventSynchronize(s.done) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");
     s.busy = false;
     const char* oh = static_cast<const char*>(s.out_host);
     int32_t bits = *reinterpret_cast<const int32_t*>(oh + s.off_status);
@@ -311,6 +344,7 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
         if (s.direct) *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
         else if (hipMemsetAsync(static_cast<char*>(s.out_dev) + s.off_status, 0, 4, s.stream) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: clearing the status word failed");
+        s.done_total = 0;  // (no completion word for the second run: the first one has already counted its graphs)
         int rc = launch_slot(h, s);
         if (rc) return rc;
         if (hipStreamSynchronize(s.stream) != hipSuccess) return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: waiting for the batch failed");

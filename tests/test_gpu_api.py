@@ -984,6 +984,20 @@ def test_native_host_solver(engine, golden):
                 assert np.allclose(g["totals"], r["totals"], rtol=1e-12, atol=0)
                 assert np.array_equal(g["scores"].view(np.uint32), np.asarray(r["scores"], np.float32).ravel().view(np.uint32))
     hs.close()
+    # The one-slot object's kernel tells the host itself when a batch is through (a word in pinned memory, written after the
+    # outputs have been written back; DGCN_HOST_DONE_WORD=0 = wait for the event only): 400 single-graph calls in a row,
+    # every result complete when it is handed out.
+    one = HostSolver(engine, dm, depth=1, want_scores=True)
+    ps, cs, ws = batches[0]
+    gp = np.concatenate([[0], np.cumsum([p.size - 1 for p in ps])])
+    sc0 = np.asarray(refs[0]["scores"], np.float32).ravel()
+    for i in range(400):
+        k = (7 * i) % len(ps)
+        g = one.solve([ps[k]], [cs[k]], [ws[k]])
+        assert np.array_equal(g["state"], refs[0]["state"][gp[k]:gp[k + 1]]) and g["rounds"][0] == refs[0]["rounds"][k], i
+        assert np.array_equal(g["scores"].view(np.uint32), sc0[gp[k]:gp[k + 1]].view(np.uint32)), i
+        assert abs(g["totals"][0] - refs[0]["totals"][k]) <= 1e-12 * abs(refs[0]["totals"][k]), i
+    one.close()
     # A placement fault of the several-workgroups-per-graph kernel (injected: DGCN_FUSED_CLUSTER_INJECT_FAULT) is not the
     # caller's problem: the object switches the variant off for the process, solves the batch again and hands out that.
     import ctypes
