@@ -84,16 +84,16 @@ struct FusedArgs {
     int32_t beam;          // greedy_mode 2: number of candidates
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
-    // cluster variant (k_fused<false, false, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
-    int32_t cluster;
     int32_t* done_flag;    // see DoneHook (common.h); null = no completion word
     uint32_t* done_count;
     uint32_t done_target;
+    // cluster variant (k_fused<false, *, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
+    int32_t cluster;
     int32_t cluster_inject;  // test hook (DGCN_FUSED_CLUSTER_INJECT_FAULT=1): report a placement fault although there is none
-    int32_t epoch;      // progress words count from here: values a previous launch left behind (possibly still cached in
-                        // this XCD's L2, whatever a memset from elsewhere did to the memory) are always smaller
+    int32_t epoch;      // this launch's value of the progress words ("my exchange rows are marked unwritten"): what a
+                        // previous launch left behind (possibly still cached in this XCD's L2) is always smaller
     int32_t num_graphs;
-    float* xz;          // [num_graphs][2][max_nodes][32] Z1 rows on their way between the workgroups of a graph
+    float* xz;          // [num_graphs][3][max_nodes][32] Z1 rows on their way between the workgroups of a graph (slice l % 3)
     float* xs;          // [num_graphs][2][max_nodes] last layer: z1 scalars, then scores
     int32_t* xflag;     // G = num_graphs rounded up to 8: [G][8] workgroup progress words, then [G][8] XCC ids
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
