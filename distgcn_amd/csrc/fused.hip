@@ -84,6 +84,7 @@ struct FusedArgs {
     int32_t beam;          // greedy_mode 2: number of candidates
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
+    const int32_t* order;  // null, or the graph of workgroup i (largest graphs first: k_graph_rank)
     int32_t* done_flag;    // see DoneHook (common.h); null = no completion word
     uint32_t* done_count;
     uint32_t done_target;
@@ -787,6 +788,7 @@ template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int g = blockIdx.x;
+    if (!CLUSTER && a.order) g = a.order[g];
     int cw = 0;                                  // cluster variant: which of the graph's K workgroups this is
     const int K = CLUSTER ? a.cluster : 1;
     if constexpr (CLUSTER) {
@@ -1683,6 +1685,47 @@ static size_t fused_pad_bytes(const DgcnModel* m) {
     return fused_needs_padding(m) ? (size_t)fused_virtual_layers(m) * kPadLayerFloats * sizeof(float) : 0;
 }
 
+// ---- largest graphs first ---------------------------------------------------------------------
+// Workgroups are dispatched in block order and a graph's time grows with its size (transform ~ vertices, aggregation ~
+// entries).  A mixed batch that needs more than one round of workgroups (BA test2 mix: 100..300 vertices, 392..11 200
+// entries) ends with whatever large graph happened to come late: 418 us per 500-graph launch as the graphs come, 301 us
+// largest first, 358 us smallest first (tools/order_probe.py).  One tiny launch turns sizes into a dispatch order:
+// key = entries + 16 * vertices (the ratio of the two phases' costs), position = rank under (key desc, index asc).
+__device__ __forceinline__ int graph_key(const int32_t* graph_ptr, const int32_t* row_ptr, int g) {
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    return (row_ptr[n1] - row_ptr[n0]) + 16 * (n1 - n0);
+}
+
+__global__ __launch_bounds__(256) void k_graph_rank(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr, int B,
+                                                    int32_t* __restrict__ order) {
+    __shared__ int32_t tile[1024];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int kg = g < B ? graph_key(graph_ptr, row_ptr, g) : 0;
+    int pos = 0;
+    for (int base = 0; base < B; base += 1024) {  // (every workgroup works out all keys itself: one launch, not two)
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256) tile[i] = base + i < B ? graph_key(graph_ptr, row_ptr, base + i) : INT32_MIN;
+        __syncthreads();
+        const int m = min(1024, B - base);
+        for (int u = 0; u < m; u += 4) {  // (the tile is padded with keys nobody beats)
+            const int4 q = *reinterpret_cast<const int4*>(tile + u);
+            pos += (q.x > kg) || (q.x == kg && base + u < g);
+            pos += (q.y > kg) || (q.y == kg && base + u + 1 < g);
+            pos += (q.z > kg) || (q.z == kg && base + u + 2 < g);
+            pos += (q.w > kg) || (q.w == kg && base + u + 3 < g);
+        }
+    }
+    if (g < B) order[pos] = g;
+}
+
+// worth it?  only the host-side shape is known here: more graphs than CUs (several rounds) and a largest graph well above the mean
+static bool fused_wants_order(const DgcnBatch* b) {
+    if (const char* e = getenv("DGCN_FUSED_ORDER")) return atoi(e) != 0 && b->num_graphs > 1;
+    if (b->num_graphs <= device_cus()) return false;
+    return (double)b->max_nodes * b->num_graphs > 1.25 * (double)b->num_nodes ||
+           (double)b->max_graph_edges * b->num_graphs > 1.25 * (double)b->num_edges;
+}
+
 // How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
 // Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
 // (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
@@ -1792,7 +1835,22 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace_bytes -= need;
     }
     a->num_graphs = b->num_graphs;
+    a->order = nullptr;
+    if (fused_wants_order(b)) {
+        const size_t need = (size_t)b->num_graphs * sizeof(int32_t) + 256;
+        if (!workspace || workspace_bytes < need)
+            return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (dispatch order), got %zu", who, need,
+                        workspace ? workspace_bytes : (size_t)0);
+        int32_t* order = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+        const int blocks = (b->num_graphs + 255) / 256;
+        hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(256), 0, stream, b->graph_ptr, a->row_ptr, b->num_graphs, order);
+        if (int rc = check_launch("k_graph_rank")) return rc;
+        a->order = order;
+        workspace = static_cast<char*>(workspace) + need;
+        workspace_bytes -= need;
+    }
     a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
+    if (a->cluster > 1) a->order = nullptr;
     a->cluster_inject = getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT") ? atoi(getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT")) : 0;
     if (a->cluster > 1) {
         const size_t need = fused_cluster_bytes(b, a->cluster);
@@ -1891,6 +1949,7 @@ static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap
     size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
     need += (size_t)b->num_graphs * meta_cap * sizeof(uint2) + 256;  // entry records of the hidden aggregation
+    need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
     need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);  // (the residual solver never clusters)
     return need;
 }

@@ -726,3 +726,37 @@ def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch
                 assert np.array_equal(ref[k].view(np.uint8), got[k].view(np.uint8)), (rep, k, db.num_graphs)
             engine.solve_fused(big, model, out=engine.solve_buffers(big, True))  # same workspace, other layout
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatch):
+    """k_graph_rank (csrc/fused.hip): a mixed batch that needs several rounds of workgroups is dealt
+    largest graph first.  Only the assignment of graphs to workgroups changes: scores, sets, rounds and totals are the
+    same bits with the order forced on (ragged batch with empty and single-vertex graphs; the BA mix, where the library
+    switches it on by itself) and off."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    parts = [datagen.er_batch(1, n, p, first_index=700 + n) for n, p in ((137, 0.08), (1, 0.5), (16, 0.3), (300, 0.05), (33, 0.2), (64, 0.1))]
+    ps, cs, ws = [np.zeros(1, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0)]  # an empty graph first
+    for hb in parts * 3:
+        ps.append(hb.row_ptr.astype(np.int32)); cs.append(hb.col_idx.astype(np.int32)); ws.append(hb.weights)
+    ragged = HostBatch.from_csr_lists(ps, cs, ws)
+    for layers_n, hb in ((20, datagen.ba_test2_batch(300)), (3, ragged), (1, ragged)):
+        model = DeviceModel(datagen.random_model(layers_n, 32), engine.device)
+        db = engine.upload(hb)
+        got = {}
+        for order in ("0", "1", None):
+            if order is None:
+                monkeypatch.delenv("DGCN_FUSED_ORDER", raising=False)
+            else:
+                monkeypatch.setenv("DGCN_FUSED_ORDER", order)
+            out = engine.solve_buffers(db, True)
+            engine.solve_fused(db, model, out=out, want_scores=True)
+            torch.cuda.synchronize()
+            got[order] = {k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")}
+            assert int(got[order]["status"][0]) == 0
+        for order in ("1", None):
+            for k in got["0"]:
+                assert np.array_equal(got["0"][k].view(np.uint8), got[order][k].view(np.uint8)), (layers_n, order, k)
