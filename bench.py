@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step result gather at N>1")
     ap.add_argument("--no-spmm-probe", action="store_true", help="skip the stand-alone SpMM kernel measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (ingest + solve + fetch) measurement")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time the step issued alternately on two HIP streams (side figure; its overlapping launches would "
+                         "blur a kernel trace of the run, so it is not part of the default command)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
     return ap.parse_args(argv)
 
@@ -649,7 +652,8 @@ def main(argv=None, workload_factory=None):
     single = two = None
     if rank == 0 and world == 1 and not args.no_e2e and isinstance(wl, GpuWorkload) and wl.ring is not None:
         single = single_graph_probe(args, wl)
-        two = two_stream_probe(args, wl, res["state"].cpu().numpy()[:wl.hb.num_nodes])
+        if args.two_streams:
+            two = two_stream_probe(args, wl, res["state"].cpu().numpy()[:wl.hb.num_nodes])
 
     if rank == 0:
         per_gpu = args.graphs if args.scaling == "weak" else None

@@ -1691,35 +1691,52 @@ static size_t fused_pad_bytes(const DgcnModel* m) {
 // entries) ends with whatever large graph happened to come late: 418 us per 500-graph launch as the graphs come, 301 us
 // largest first, 358 us smallest first (tools/order_probe.py).  One tiny launch turns sizes into a dispatch order:
 // key = entries + 16 * vertices (the ratio of the two phases' costs), position = rank under (key desc, index asc).
-__device__ __forceinline__ int graph_key(const int32_t* graph_ptr, const int32_t* row_ptr, int g) {
+// key and index in one word, larger = earlier: (entries + 16 * vertices) << gbits | (all ones - index)
+__device__ __forceinline__ unsigned graph_key(const int32_t* graph_ptr, const int32_t* row_ptr, int g, int gbits, unsigned kmax) {
     const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
-    return (row_ptr[n1] - row_ptr[n0]) + 16 * (n1 - n0);
+    // (clamped to what the batch descriptor promises: whatever the data, the result is a permutation)
+    const unsigned key = min((unsigned)(row_ptr[n1] - row_ptr[n0]) + 16u * (unsigned)(n1 - n0), kmax);
+    return (key << gbits) | (((1u << gbits) - 1u) - (unsigned)g);
 }
 
-__global__ __launch_bounds__(256) void k_graph_rank(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr, int B,
-                                                    int32_t* __restrict__ order) {
-    __shared__ int32_t tile[1024];
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int kg = g < B ? graph_key(graph_ptr, row_ptr, g) : 0;
+constexpr int kRankBlock = 256, kRankTile = 1024;
+__global__ __launch_bounds__(kRankBlock) void k_graph_rank(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr,
+                                                            int B, int gbits, unsigned kmax, int32_t* __restrict__ order) {
+    __shared__ unsigned tile[kRankTile];
+    const int g = blockIdx.x * kRankBlock + threadIdx.x;
+    const unsigned kg = g < B ? graph_key(graph_ptr, row_ptr, g, gbits, kmax) : 0u;
     int pos = 0;
-    for (int base = 0; base < B; base += 1024) {  // (every workgroup works out all keys itself: one launch, not two)
+    for (int base = 0; base < B; base += kRankTile) {  // (every workgroup works out all keys itself: one launch, not two)
+        unsigned ku[kRankTile / kRankBlock];
+#pragma unroll
+        for (int i = 0; i < kRankTile / kRankBlock; ++i) {  // independent loads: two dependent round trips for the whole tile
+            const int u = base + i * kRankBlock + threadIdx.x;
+            ku[i] = u < B ? graph_key(graph_ptr, row_ptr, u, gbits, kmax) : 0u;  // (padding: a key nobody is behind)
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < 1024; i += 256) tile[i] = base + i < B ? graph_key(graph_ptr, row_ptr, base + i) : INT32_MIN;
+#pragma unroll
+        for (int i = 0; i < kRankTile / kRankBlock; ++i) tile[i * kRankBlock + threadIdx.x] = ku[i];
         __syncthreads();
-        const int m = min(1024, B - base);
-        for (int u = 0; u < m; u += 4) {  // (the tile is padded with keys nobody beats)
-            const int4 q = *reinterpret_cast<const int4*>(tile + u);
-            pos += (q.x > kg) || (q.x == kg && base + u < g);
-            pos += (q.y > kg) || (q.y == kg && base + u + 1 < g);
-            pos += (q.z > kg) || (q.z == kg && base + u + 2 < g);
-            pos += (q.w > kg) || (q.w == kg && base + u + 3 < g);
+        const int m = min(kRankTile, B - base);
+        for (int u = 0; u < m; u += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(tile + u);
+            pos += (q.x > kg) + (q.y > kg) + (q.z > kg) + (q.w > kg);
         }
     }
     if (g < B) order[pos] = g;
 }
 
+// bits for the graph index in the packed key, or -1 if key and index do not fit one word
+static int fused_order_bits(const DgcnBatch* b) {
+    int gbits = 1;
+    while ((1L << gbits) < b->num_graphs) ++gbits;
+    const long key_max = (long)b->max_graph_edges + 16L * b->max_nodes;
+    return (key_max << gbits) < (1L << 32) ? gbits : -1;
+}
+
 // worth it?  only the host-side shape is known here: more graphs than CUs (several rounds) and a largest graph well above the mean
 static bool fused_wants_order(const DgcnBatch* b) {
+    if (fused_order_bits(b) < 0) return false;
     if (const char* e = getenv("DGCN_FUSED_ORDER")) return atoi(e) != 0 && b->num_graphs > 1;
     if (b->num_graphs <= device_cus()) return false;
     return (double)b->max_nodes * b->num_graphs > 1.25 * (double)b->num_nodes ||
@@ -1842,8 +1859,9 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
             return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (dispatch order), got %zu", who, need,
                         workspace ? workspace_bytes : (size_t)0);
         int32_t* order = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-        const int blocks = (b->num_graphs + 255) / 256;
-        hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(256), 0, stream, b->graph_ptr, a->row_ptr, b->num_graphs, order);
+        const int blocks = (b->num_graphs + kRankBlock - 1) / kRankBlock;
+        hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(kRankBlock), 0, stream, b->graph_ptr, a->row_ptr, b->num_graphs,
+                           fused_order_bits(b), (unsigned)(b->max_graph_edges + 16 * b->max_nodes), order);
         if (int rc = check_launch("k_graph_rank")) return rc;
         a->order = order;
         workspace = static_cast<char*>(workspace) + need;

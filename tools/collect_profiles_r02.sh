@@ -16,6 +16,7 @@ prof bench_c2      $R/bench.py --nodes 100 --layers 1 --steps 500 --warmup 5 --c
 prof bench_c4_l1   $R/bench.py --family ba --layers 1 --steps 500 --warmup 5 --cpu-seconds 0 --no-spmm-probe
 prof bench_c4_l20  $R/bench.py --family ba --layers 20 --steps 300 --warmup 5 --cpu-seconds 0 --no-spmm-probe
 prof c5_iterative  $R/tools/run_iterative.py --graphs 64 --host 0
+python3 $R/bench.py --two-streams --cpu-seconds 0 --no-spmm-probe > "$O/bench_two_streams.json" 2> /dev/null  # (no trace: side figure only)
 prof spmm_cache    $R/tools/run_spmm.py er 30 1
 prof spmm_rot8     $R/tools/run_spmm.py er 6 8
 prof spmm_one4000  $R/tools/run_spmm.py er 6 -8

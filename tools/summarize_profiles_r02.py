@@ -28,7 +28,7 @@ def keep_stats(name):
 
 
 for name in ("bench_fused", "bench_layered", "bench_c2", "bench_c4_l1", "bench_c4_l20", "c5_iterative", "spmm_cache", "spmm_rot8",
-             "spmm_one4000"):
+             "spmm_one4000", "bench_two_streams"):
     keep_stats(name)
 
 
