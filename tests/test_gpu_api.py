@@ -997,6 +997,15 @@ def test_native_host_solver(engine, golden):
         assert np.array_equal(g["state"], refs[0]["state"][gp[k]:gp[k + 1]]) and g["rounds"][0] == refs[0]["rounds"][k], i
         assert np.array_equal(g["scores"].view(np.uint32), sc0[gp[k]:gp[k + 1]].view(np.uint32)), i
         assert abs(g["totals"][0] - refs[0]["totals"][k]) <= 1e-12 * abs(refs[0]["totals"][k]), i
+    # the paths that leave the kernel early count themselves too: an empty graph beside a real one, a NaN weight
+    g = one.solve([empty[0], ps[3]], [empty[1], cs[3]], [empty[2], ws[3]])
+    assert g["totals"][0] == 0.0 and g["rounds"][0] == 0 and np.array_equal(g["state"], refs[0]["state"][gp[3]:gp[4]])
+    wbad = ws[5].copy(); wbad[0] = np.nan
+    with pytest.raises(DgcnError, match="NaN"):
+        one.solve([ps[5]], [cs[5]], [wbad])
+    for k in (5, 6, 5):
+        g = one.solve([ps[k]], [cs[k]], [ws[k]])
+        assert np.array_equal(g["state"], refs[0]["state"][gp[k]:gp[k + 1]])
     one.close()
     # A placement fault of the several-workgroups-per-graph kernel (injected: DGCN_FUSED_CLUSTER_INJECT_FAULT) is not the
     # caller's problem: the object switches the variant off for the process, solves the batch again and hands out that.
