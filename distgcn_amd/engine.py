@@ -432,23 +432,32 @@ class Engine:
             if scores is None:
                 raise ValueError("options & SCORES_GIVEN needs scores")
             out = dict(out, scores=scores)
-        progress = t.zeros(1, dtype=t.int32, device=self.device)
         p = lambda x: x.data_ptr() if x is not None else None
         need = int(self.lib.dgcn_solve_workspace(C.byref(b.c), C.byref(model.c)))
         ws = self._workspace(need)
         steps = 0
         limit = max_steps if max_steps is not None else max(b.host.max_nodes, 1) + 1
-        while n > 0 and steps < limit:
-            progress.zero_()
-            _lib.check(self.lib.dgcn_solve_residual_batch(
-                C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
-                1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
-                int(max_rounds), int(beam), int(options), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
-                progress.data_ptr(), out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
-                "dgcn_solve_residual_batch")
-            if int(progress.item()) == 0:
-                break
-            steps += 1
+        # Steps are launched a few at a time, each with its own progress word, and the words are read back together: a
+        # step that decides nothing leaves the state as it is, so every later step of the group decides nothing either
+        # (and costs next to nothing: a graph with nothing left returns at once) - one host round trip per group, not per step.
+        group = 4
+        done = n == 0
+        while not done and steps < limit:
+            k = min(group, limit - steps)
+            progress = t.zeros(k, dtype=t.int32, device=self.device)
+            for i in range(k):
+                _lib.check(self.lib.dgcn_solve_residual_batch(
+                    C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
+                    1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
+                    int(max_rounds), int(beam), int(options), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
+                    progress.data_ptr() + 4 * i, out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
+                    "dgcn_solve_residual_batch")
+            for v in progress.cpu().tolist():
+                if v == 0:
+                    done = True
+                    break
+                steps += 1
+            group = 8
         return {"state": state, "steps": steps, "status": out["status"],
                 "scores": None if out["scores"] is None else out["scores"][:n]}
 
