@@ -452,6 +452,9 @@ class Engine:
                     int(max_rounds), int(beam), int(options), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
                     progress.data_ptr() + 4 * i, out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
                     "dgcn_solve_residual_batch")
+            if max_steps == 1:  # a caller that asks for exactly one step does not need to know whether it decided anything
+                steps = 1
+                break
             for v in progress.cpu().tolist():
                 if v == 0:
                     done = True

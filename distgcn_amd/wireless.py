@@ -110,7 +110,9 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
                                          for i, tr in enumerate(traffics)], axis=1).astype(np.float64)).to(eng.device)  # [T, batch positions]
     vflow_d = t.from_numpy(vflow).to(eng.device)
     vinst_d = t.from_numpy(vinst).to(eng.device)
-    ch_masks = [t.from_numpy(vch == c).to(eng.device) for c in range(max(chans))]
+    # per channel: batch positions of its vertices and their flows (a flow has at most one vertex per channel)
+    ch_pos = [t.from_numpy(np.flatnonzero(vch == c)).to(eng.device) for c in range(max(chans))]
+    ch_flow = [vflow_d[p] for p in ch_pos]
     F, I = int(foff[-1]), len(flows)
     q = t.zeros(F, dtype=t.float64, device=eng.device)
     queue_out = t.zeros((T, F), dtype=t.float64, device=eng.device)
@@ -122,6 +124,7 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
         raise NotImplementedError("conflict graphs / model outside the fused kernel (<= 512 vertices, hidden <= 32)")
     out = eng.solve_buffers(db, False) if dm is not None else None
     state = t.zeros(max(hb.num_nodes, 1), dtype=t.uint8, device=eng.device)
+    zero_w = t.zeros(hb.num_nodes, dtype=t.float64, device=eng.device)
     for ts in range(1, T):
         q += arr[ts]
         w = slot_weights(q[vflow_d], rates[ts], wt_sel)
@@ -144,17 +147,17 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
                                      greedy=eng.GREEDY_ROUNDS if algo == "DGCN-LGS-it" else eng.GREEDY_ROLLOUT,
                                      max_rounds=1, beam=16, weight_features=agent.flags.predict != "mwis", out=out)
             st, status = state[:hb.num_nodes], res["status"]
+        # (dense selects instead of boolean-mask indexing: nothing here waits for the device)
         sel = st == 1
         cap = t.zeros(F, dtype=t.float64, device=eng.device)
-        for m in ch_masks:  # ascending channel: the highest scheduled channel of a flow sets its capacity
-            mm = sel & m
-            cap[vflow_d[mm]] = rates[ts][mm]
+        for pos, fl in zip(ch_pos, ch_flow):  # ascending channel: the highest scheduled channel of a flow sets its capacity
+            cap[fl] = t.where(sel[pos], rates[ts][pos], cap[fl])
         dep = t.minimum(q, cap)
         q -= dep
         queue_out[ts] = q
         dep_out[ts] = dep
-        tot_out[ts].index_add_(0, vinst_d[sel], w[sel])
-        cnt_out[ts].index_add_(0, vinst_d[sel], t.ones_like(w[sel]))
+        tot_out[ts].index_add_(0, vinst_d, t.where(sel, w, zero_w))
+        cnt_out[ts].index_add_(0, vinst_d, sel.to(t.float64))
     eng.check_status(status)
     queue_h, dep_h, tot_h, cnt_h = (x.cpu().numpy() for x in (queue_out, dep_out, tot_out, cnt_out))
     return [{"queue": queue_h[:, foff[i]:foff[i + 1]], "depart": dep_h[:, foff[i]:foff[i + 1]], "total_wt": tot_h[:, i],
