@@ -25,9 +25,9 @@ namespace dgcn {
 
 // ---- a small persistent worker pool (thread creation costs more than packing a C3 batch)
 // A C3 batch packs in ~0.15 ms and the next one follows within a fraction of a millisecond, so a worker that has just
-// finished keeps polling for the next region for a while (kSpin polls) before it sleeps on the condition variable:
-// waking fifteen sleepers through one mutex cost a third of the packing time itself.  Parts are handed out with an
-// atomic counter; a worker that arrives late finds none left (or helps with the region that has started since).
+// finished keeps polling for the next region for a while (kSpin polls) before it sleeps on the condition variable, and
+// parts are handed out with a compare-and-swap instead of under the mutex (0.156 ms per C3 batch on 16 threads, 0.16 -
+// 0.20 ms with sleeping workers).  A worker that arrives late finds no part left (its region number is stale).
 class Pool {
 public:
     static Pool& get() {
