@@ -1764,8 +1764,11 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // measured (tools/cluster_check.py, 20 layers, one workgroup per graph vs cluster): N = 200: 127 vs 92 us for 1 - 16
     // graphs (K = 6 - 8; 97 with K = 4, 95 with K = 5), 129 vs 94 for 32 (K = 8), 130 vs 100 for 64 (K = 4); N = 300
     // (K = 5+): 126 vs 112; N = 150: 94 vs 82; N = 120: 74 vs 72; N = 77: 61 vs 65.  The fixed cost (every workgroup
-    // builds the image, 512 threads for the greedy rounds) is ~9 us, the gain ~2 us per hidden layer.
-    if (!forced && (K < 3 || blocks < 8 || m->num_layers < 8)) return 0;
+    // builds the image, 512 threads for the greedy rounds) is a few us, the gain ~2 us per hidden layer.
+    // (tools/cluster_layers.py: N = 200 gains from 4 layers on - 44.6 vs 38.8 us at 5, 59.9 vs 47.5 at 8 -, N = 128 and
+    // N = 300 from 7 - 8 on)
+    const int min_layers = (blocks >= 10 && blocks <= 16) ? 5 : 8;
+    if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers)) return 0;
     return K;
 }
 
