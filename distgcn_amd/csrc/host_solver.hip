@@ -8,7 +8,7 @@
 //     dgcn_host_solver_submit  = dgcn_pack_batch into pinned memory -> 1 hipMemcpyAsync -> dgcn_solve_batch
 //                                -> 1 hipMemcpyAsync back -> event           (returns at once)
 //     dgcn_host_solver_result  = wait for the slot's event -> pointers into its pinned result
-// (a batch of a few KB skips both copies: the kernel works on the pinned buffers directly)
+// (a batch of up to 2 MB skips both copies: the kernel works on the pinned buffers directly)
 // with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
 // consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
 // DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
@@ -258,11 +258,12 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     if (!h->lgs_only && info.max_degree >= h->table_len)
         return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: vertex degree %d beyond the d^-1/2 table (%d entries)", info.max_degree,
                     h->table_len);
-    // A batch of a few graphs is a few KB: the kernel reads it where the packer left it and writes its results where the
+    // A batch of up to a few dozen graphs: the kernel reads it where the packer left it and writes its results where the
     // caller reads them (pinned memory is device-addressable) - two copy commands and the gaps around them cost more
-    // than a handful of PCIe round trips inside the kernel (DGCN_HOST_DIRECT_BYTES: largest batch handled this way).
+    // than PCIe round trips inside the kernel (tools/direct_probe.py: 101 vs 110 us for one N = 200 graph, 150 vs 170 us
+    // for 63 of them = 1.1 MB; DGCN_HOST_DIRECT_BYTES: largest batch handled this way, default 2 MB).
     const char* direct_env = getenv("DGCN_HOST_DIRECT_BYTES");
-    const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(96 << 10);
+    const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(2 << 20);
     const bool direct = (size_t)info.total_bytes <= direct_bytes;
     char* base = static_cast<char*>(direct ? s.in_host_dev : s.in_dev);
     DgcnBatch b;

@@ -295,7 +295,7 @@ int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, co
  * directory.  A DgcnHostSolver keeps `depth` slots of pinned staging memory, device buffers, a stream and an event:
  *   submit: dgcn_pack_batch into the slot's pinned memory -> one host-to-device copy -> dgcn_solve_batch -> one
  *           device-to-host copy, all asynchronous; returns the slot index (>= 0) or a DGCN_ERR_* code (< 0)
- *           (a packed batch of at most DGCN_HOST_DIRECT_BYTES, default 96 KB, is not copied: the kernel reads the pinned
+ *           (a packed batch of at most DGCN_HOST_DIRECT_BYTES, default 2 MB, is not copied: the kernel reads the pinned
  *           staging memory and writes the pinned result memory itself)
  *   result: waits for that slot; hands out pointers into its pinned result memory (valid until the slot's next submit):
  *           state[num_nodes] (0 undecided / 1 in the set / 2 excluded), totals[num_graphs], rounds[num_graphs],
