@@ -54,3 +54,41 @@ def test_random_shapes_match_the_twin(engine):
         assert np.array_equal(got["scores"].ravel().view(np.uint32), np.asarray(want["scores"], np.float32).ravel().view(np.uint32)), tag
         assert np.array_equal(got["state"], want["state"]) and np.array_equal(got["rounds"], want["rounds"]), tag
         assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), tag
+
+
+def test_random_calls_through_the_host_solver_match_the_twin(engine):
+    """The per-call path (one-slot HostSolver: packed batch read in place, completion word, cluster variant where it fits):
+    random small batches, call after call on the same object, against the twin."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.serving import HostSolver
+    from oracle import ctwin
+    calls = int(os.environ.get("DGCN_FUZZ_CASES", "16")) * 4
+    rng = np.random.default_rng(77)
+    solvers = {}
+    for call in range(calls):
+        layers_n = int(rng.choice([1, 3, 12, 20]))
+        if layers_n not in solvers:
+            layers = datagen.random_model(layers_n, 32, bias=True, seed=layers_n)
+            solvers[layers_n] = (layers, HostSolver(engine, DeviceModel(layers, engine.device), depth=1, want_scores=True))
+        layers, hs = solvers[layers_n]
+        ps, cs, ws = [], [], []
+        for _ in range(int(rng.integers(1, 9))):
+            n = int(rng.choice([0, 1, 30, 128, 200, 200, 200, 300, 500]))
+            if n == 0:
+                ps.append(np.zeros(1, np.int32)); cs.append(np.zeros(0, np.int32)); ws.append(np.zeros(0))
+                continue
+            g = datagen.er_batch(1, n, min(0.9, 10.0 / max(n, 2)), first_index=int(rng.integers(1 << 20)))
+            ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
+        hb = HostBatch.from_csr_lists(ps, cs, ws)
+        got = hs.solve(ps, cs, ws)
+        if hb.num_nodes == 0:
+            assert got["state"].size == 0
+            continue
+        want = ctwin.solve(hb, layers)
+        assert np.array_equal(got["state"], want["state"]) and np.array_equal(got["rounds"], want["rounds"]), (call, layers_n)
+        assert np.array_equal(got["scores"].view(np.uint32), np.asarray(want["scores"], np.float32).ravel().view(np.uint32)), (call, layers_n)
+        assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), (call, layers_n)
+    for _, hs in solvers.values():
+        hs.close()
