@@ -771,6 +771,33 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
     return r;
 }
 
+// Row order of the cluster variant: every workgroup of a graph must arrive at the SAME order (it decides who owns which
+// rows), so the position of a row is its rank under (entry count desc, index asc), not the order atomics happened to
+// take.  Keys = count << 16 | ~index in LDS (`key`: scratch for ng rounded up to 4 words), four per ds_read_b128, the
+// vertices' scans split over 1, 2 or 4 lanes.  ng <= BLOCK.
+template <int BLOCK>
+__device__ __forceinline__ void rank_rows(int ng, const unsigned* rinfo, unsigned short* perm, unsigned short* ipos, unsigned* key) {
+    const int ng4 = (ng + 3) & ~3;
+    for (int v = threadIdx.x; v < ng4; v += BLOCK) key[v] = v < ng ? ((rinfo[v] >> 16) << 16) | (0xffffu - (unsigned)v) : 0u;
+    __syncthreads();
+    const int lp_log = (ng * 4 <= BLOCK) ? 2 : (ng * 2 <= BLOCK) ? 1 : 0;
+    const int v = threadIdx.x >> lp_log, part = threadIdx.x & ((1 << lp_log) - 1);
+    int pos = 0;
+    if (v < ng) {
+        const unsigned kv = key[v];
+        for (int u0 = part * 4; u0 < ng4; u0 += 4 << lp_log) {
+            const uint4 q = *reinterpret_cast<const uint4*>(key + u0);
+            pos += (q.x > kv) + (q.y > kv) + (q.z > kv) + (q.w > kv);
+        }
+    }
+    if (lp_log >= 1) pos += __shfl_xor(pos, 1);
+    if (lp_log >= 2) pos += __shfl_xor(pos, 2);
+    if (v < ng && part == 0) {
+        perm[pos] = (unsigned short)v;
+        ipos[v] = (unsigned short)pos;
+    }
+}
+
 // this graph is done and its outputs have left the CU: count it, the last one tells the host (DoneHook, common.h)
 __device__ __forceinline__ void signal_done(const FusedArgs& a) {
     if (!a.done_flag) return;
@@ -951,6 +978,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             }
         }
         __syncthreads();
+        if constexpr (CLUSTER) rank_rows<BLOCK>(ng, rinfo, perm, ipos, reinterpret_cast<unsigned*>(rowstart + 520 + 512));  // (behind al / acount)
+        else
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
             const int pos = atomicAdd(&hist[c], 1);
@@ -1035,27 +1064,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if constexpr (CLUSTER) {
             // every workgroup of the graph must arrive at the SAME row order (it decides who owns which rows): the
             // position of a row is its rank under (entry count desc, index asc), not the order atomics happened to take
-            // (keys = count << 16 | ~index in LDS, four per ds_read_b128, the vertices' scans split over 1, 2 or 4 lanes)
-            unsigned* key = reinterpret_cast<unsigned*>(rowstart + 520);
-            const int ng4 = (ng + 3) & ~3;
-            for (int v = threadIdx.x; v < ng4; v += BLOCK) key[v] = v < ng ? ((rinfo[v] >> 16) << 16) | (0xffffu - (unsigned)v) : 0u;
-            __syncthreads();
-            const int lp_log = (ng * 4 <= BLOCK) ? 2 : (ng * 2 <= BLOCK) ? 1 : 0;
-            const int v = threadIdx.x >> lp_log, part = threadIdx.x & ((1 << lp_log) - 1);
-            int pos = 0;
-            if (v < ng) {
-                const unsigned kv = key[v];
-                for (int u0 = part * 4; u0 < ng4; u0 += 4 << lp_log) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(key + u0);
-                    pos += (q.x > kv) + (q.y > kv) + (q.z > kv) + (q.w > kv);
-                }
-            }
-            if (lp_log >= 1) pos += __shfl_xor(pos, 1);
-            if (lp_log >= 2) pos += __shfl_xor(pos, 2);
-            if (v < ng && part == 0) {
-                perm[pos] = (unsigned short)v;
-                ipos[v] = (unsigned short)pos;
-            }
+            rank_rows<BLOCK>(ng, rinfo, perm, ipos, reinterpret_cast<unsigned*>(rowstart + 520));
         } else
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
@@ -1294,7 +1303,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 }
                 if (v < ng && !owned) score = poll_l2_scalar(xs0 + a.max_nodes + v, a.status);
                 // every output of the graph leaves from this workgroup: one place to wait for before telling the host
-                if (a.scores && v < ng) a.scores[n0 + v] = score;
+                if (a.scores && v < ng) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -1746,8 +1755,8 @@ static bool fused_wants_order(const DgcnBatch* b) {
 // How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
 // Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
 // (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
-static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool masked) {
-    if (masked || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
+static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool off) {
+    if (off || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) < 0 || b->max_nodes > kFusedBlock) return 0;  // (a vertex per thread in the last layer)
     const int blocks = (b->max_nodes + 15) / 16;
     const int gpad = (b->num_graphs + 7) & ~7;
@@ -1933,19 +1942,19 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
                : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
 }
 
-template <bool GVALS>
+template <bool MASKED, bool GVALS>
 static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     static std::atomic<size_t> reserved[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 64 * 1024 && lds > reserved[dev & 63].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<false, GVALS, kFusedBlock, true>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, kFusedBlock, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
         reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_fused<false, GVALS, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
     return check_launch("k_fused (cluster)");
 }
 
@@ -1959,7 +1968,10 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
-    if (a.cluster > 1 && !masked) return gvals ? fused_launch_cluster<true>(a, B, lds, family, s) : fused_launch_cluster<false>(a, B, lds, family, s);
+    if (a.cluster > 1) {
+        if (masked) return gvals ? fused_launch_cluster<true, true>(a, B, lds, family, s) : fused_launch_cluster<true, false>(a, B, lds, family, s);
+        return gvals ? fused_launch_cluster<false, true>(a, B, lds, family, s) : fused_launch_cluster<false, false>(a, B, lds, family, s);
+    }
     if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
     return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
 }
@@ -1971,7 +1983,7 @@ static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
     need += (size_t)b->num_graphs * meta_cap * sizeof(uint2) + 256;  // entry records of the hidden aggregation
     need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
-    need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);  // (the residual solver never clusters)
+    need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);
     return need;
 }
 
@@ -2096,7 +2108,9 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.status = status;
     size_t lds = 0;
     bool gvals = false;
-    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream, true);
+    // (with given scores no layer runs: nothing for a second workgroup to do)
+    int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream,
+                           (options & DGCN_RESIDUAL_SCORES_GIVEN) != 0);
     if (rc) return rc;
     return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals);
 }

@@ -1164,3 +1164,27 @@ def test_c4_full_batch_and_its_eight_shards(engine, golden):
         assert np.array_equal(r["state"].cpu().numpy(), state[n0:n1]) and np.array_equal(r["totals"].cpu().numpy(), totals[a:b])
     one = parallel.solve_sharded_device(engine, dm, hb)
     assert np.array_equal(one["state"], state) and np.array_equal(one["totals"], totals) and np.array_equal(one["rounds"], rounds)
+
+
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout", "rollout1"])
+def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkeypatch):
+    """The residual-graph kernel also runs as several workgroups per graph (small batches of deep stacks): same sets and
+    totals as with one workgroup per graph, for graphs that fill several tiles, a 12-layer stack, weight features."""
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=12), seed=4)
+    agent.device_iterative = True
+    hb = datagen.er_batch(3, 200, 0.06, first_index=4400)
+    adjs = [hb.scipy_graph(g) for g in range(3)]
+    ws = [hb.weights[n0:n1] for n0, n1 in hb.graph_slices()]
+    got = {}
+    for mode in ("0", "8", None):
+        if mode is None:
+            monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
+        else:
+            monkeypatch.setenv("DGCN_FUSED_CLUSTER", mode)
+        got[mode] = agent.solve_iterative_batch(adjs, ws, which, b=8)
+        assert got[mode] is not None
+    for mode in ("8", None):
+        for a, b in zip(got["0"], got[mode]):
+            assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), (which, mode)
