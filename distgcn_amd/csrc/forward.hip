@@ -12,6 +12,10 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
                   const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s);
 int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                        int ldz, hipStream_t s);
+int spmm_f64acc_dispatch(const DgcnCsr* S, const float* Z, int ldz, int C, const float* Y0, int ldy0, const float* bias, int act,
+                         float* Y, int ldy, hipStream_t s);
+int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
+                              int ldz, hipStream_t s);
 int layer32_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, const float* bias, int act,
                      const float* Wn, int ctot_next, float* Zn, hipStream_t s);
 size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m);
@@ -178,11 +182,15 @@ static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const 
         const int ctot = K * L.out_dim;
         // K2/K3: Z[:, i*out:(i+1)*out] = H.W_i  (weights stored [support][in][out] -> the host shim passes
         // them pre-concatenated as [in][K*out]; see distgcn_amd/gcn/models.py)
-        int rc = z_ready ? DGCN_OK : transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
+        // (the library's arithmetic contract: the transform of layer index 1 and the aggregation of layer index 0 carry
+        // their chains in double, see include/dgcn.h; everything else is float32 fmaf chains)
+        int rc = z_ready ? DGCN_OK
+                 : l == 1 ? transform_f64acc_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s)
+                          : transform_dispatch(H, ldh, x_const, b->num_nodes, L.in_dim, L.weights, ctot, Zbuf, ctot, s);
         if (rc) return rc;
         z_ready = false;
         const bool last = l == m->num_layers - 1;
-        if (K == 2 && !last && L.out_dim == 32) {
+        if (K == 2 && !last && L.out_dim == 32 && l >= 1) {  // (layer 0 and layer 1's transform run apart: the precise kernels)
             // layer l's aggregation + layer l+1's transform in one launch (layer.hip): H' never leaves the LDS
             const DgcnLayer& N = m->layers_host[l + 1];
             rc = layer32_dispatch(sup[0], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf, L.bias, L.act, N.weights, K * N.out_dim,
@@ -201,8 +209,10 @@ static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const 
             const bool fin = i == K - 1;
             float* dst = fin ? out : Tbuf;
             // K4-K7: dst = run + T_i.Z_i, and on the last support: act(. + b)
-            rc = spmm_dispatch(sup[i - 1], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + i * L.out_dim, ctot, L.out_dim,
-                               run, ldrun, fin ? L.bias : nullptr, fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s);
+            rc = l == 0 ? spmm_f64acc_dispatch(sup[i - 1], Zbuf + i * L.out_dim, ctot, L.out_dim, run, ldrun, fin ? L.bias : nullptr,
+                                               fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s)
+                        : spmm_dispatch(sup[i - 1], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + i * L.out_dim, ctot, L.out_dim,
+                                        run, ldrun, fin ? L.bias : nullptr, fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s);
             if (rc) return rc;
             run = dst;
             ldrun = L.out_dim;

@@ -25,7 +25,9 @@
 //
 // Arithmetic is the library-wide contract (include/dgcn.h): transform = k-ordered fmaf chain (fp32 MFMA
 // 16x16x4 is exactly that), aggregate = fmaf chain in entry order from 0, then Z0 + sum, + bias,
-// activation.  Scores are therefore bit-identical to mode 0 and to oracle/dgcn_oracle.c.
+// activation; the aggregation of layer index 0 and the transform of layer index 1 carry their chains in
+// double and round once (v_mfma_f64_16x16x4_f64 is exactly the ascending fma chain: tools/micro/mfma_f64.hip).
+// Scores are therefore bit-identical to mode 0 and to oracle/dgcn_oracle.c.
 //
 // Shapes handled here: first layer any width -> 32 (VALU), hidden layers 32 -> 32 (MFMA), last layer
 // -> 1; or a single layer F -> 1.  Anything else returns DGCN_ERR_UNSUPPORTED and the caller uses mode 0.
@@ -167,7 +169,10 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
 // C/D: col = l & 15, row = 4 * (l >> 4) + reg.  Z0 overwrites the tile's own rows of bufA.
 // The B fragments of a layer are fetched one layer ahead (load_bfrag) so that their global-memory
 // latency hides under the previous layer's gather phase.
-__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4], int skip = 0) {
+// `f64map`: fragments for hidden_transform_f64 - the f64 MFMA returns rows 4 * reg + (lane >> 4) where the f32 one
+// returns 4 * (lane >> 4) + reg, so lane r feeds column 4 * (r & 3) + (r >> 2) of the tile and the accumulator again
+// holds four CONSECUTIVE features per lane.
+__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4], int skip = 0, bool f64map = false) {
     const int lane = threadIdx.x & 63;
 #ifdef DGCN_DIAG
     if (skip) {  // experiment: no weight fetch
@@ -179,7 +184,8 @@ __device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4], int
     }
 #endif
     (void)skip;
-    const int r = lane & 15, kq = lane >> 4;
+    const int r0 = lane & 15, kq = lane >> 4;
+    const int r = f64map ? 4 * (r0 & 3) + (r0 >> 2) : r0;
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -218,6 +224,47 @@ __device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng,
                 const float4 o = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
                 if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
                 else *reinterpret_cast<float4*>(bufB + row * kHid + ((chunk ^ keyB(row)) << 2)) = o;
+            }
+        }
+    }
+}
+
+// The same product with every chain carried in double and rounded once (layer index 1): v_mfma_f64_16x16x4_f64, which
+// on gfx950 is exactly fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, c)))) per element (tools/micro/mfma_f64.hip: 0 of
+// 5.1 M outputs differ from the CPU's chain, cancellation included).  Fragments from load_bfrag(.., f64map = true).
+// Column tiles in pairs: 16 accumulator registers live at a time.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+template <int BLOCK>
+__device__ __forceinline__ void hidden_transform_f64(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    constexpr int kWaves = BLOCK / 64;
+    const int tiles = (ng + 15) >> 4;
+    for (int t = wave; t < tiles; t += kWaves) {
+        const int row = t * 16 + r;
+        float av[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                // (opaque copies: otherwise the 32 conversions of b are hoisted out of the tile loop and their 64 registers
+                // push the row-block state of the aggregation into scratch memory)
+                float b0 = b[s][2 * cp], b1 = b[s][2 * cp + 1], a0 = av[s];
+                asm volatile("" : "+v"(b0), "+v"(b1), "+v"(a0));
+                const double ad = (double)a0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b0, ad, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b1, ad, acc1, 0, 0, 0);
+            }
+            if (row < ng) {
+                const float4 o0 = make_float4((float)acc0[0], (float)acc0[1], (float)acc0[2], (float)acc0[3]);
+                const float4 o1 = make_float4((float)acc1[0], (float)acc1[1], (float)acc1[2], (float)acc1[3]);
+                float* dst = cp == 0 ? bufA : bufB;
+                const int key = cp == 0 ? (row & 7) : keyB(row);
+                *reinterpret_cast<float4*>(dst + row * kHid + ((kq ^ key) << 2)) = o0;
+                *reinterpret_cast<float4*>(dst + row * kHid + (((4 + kq) ^ key) << 2)) = o1;
             }
         }
     }
@@ -448,10 +495,71 @@ __device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], c
     }
 }
 
+// ... and with the chains in double (layer index 1; fragments from load_bfrag(.., f64map = true), see hidden_transform_f64)
+template <int BLOCK>
+__device__ __forceinline__ void hidden_transform_owned_f64(const float (&b)[8][4], const ClusterTile& t, float* bufA, float* bufB,
+                                                           float* slice) {
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4;
+    const int row = t.trow >= 0 ? t.trow : 0;
+    float av[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
+    __syncthreads();
+    if (!__any(t.trow >= 0)) return;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < t.ct0 || ct >= t.ct0 + t.nct) continue;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b[s][ct], (double)av[s], acc, 0, 0, 0);
+        if (t.trow >= 0) {
+            const int chunk = (ct & 1) * 4 + kq;
+            const float4 o = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+            if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
+            else {
+                const int off = row * kHid + ((chunk ^ keyB(row)) << 2);
+                *reinterpret_cast<float4*>(bufB + off) = o;
+                *reinterpret_cast<float4*>(slice + off) = o;
+            }
+        }
+    }
+}
+
 // (Tried: one progress word per tile instead of per workgroup - a wave publishes its tile as soon as its stores have left
 // the CU, the readers' waves wait for and pull two foreign tiles at a time, no workgroup barrier around the hand-over:
 // 120 - 128 us against 117 - 123 us for one to eight N = 200 graphs.  Three dependent L2 round trips - store, poll, pull -
 // are what the hand-over costs either way.)
+
+// A row's four-feature accumulator: float32 fmaf chain, or (F64: layer index 0) one fma chain in double that is rounded
+// once after "+ Z0 (+ bias)".  In both, an entry of value -0.0f on the zero row leaves the chain as it is.
+template <bool F64> struct RowAcc;
+template <> struct RowAcc<false> {
+    float4 v;
+    __device__ __forceinline__ void clear() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void add(float a, float4 z) { v = fma4(a, z, v); }
+    template <bool BIAS> __device__ __forceinline__ float4 finish(float4 y, float4 b) const {
+        float4 o = make_float4(y.x + v.x, y.y + v.y, y.z + v.z, y.w + v.w);
+        if constexpr (BIAS) { o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+        return o;
+    }
+};
+template <> struct RowAcc<true> {
+    double x, y, z, w;
+    __device__ __forceinline__ void clear() { x = y = z = w = 0.0; }
+    __device__ __forceinline__ void add(float a, float4 q) {
+        const double ad = (double)a;
+        x = fma(ad, (double)q.x, x); y = fma(ad, (double)q.y, y); z = fma(ad, (double)q.z, z); w = fma(ad, (double)q.w, w);
+    }
+    __device__ __forceinline__ void add_d(double ad, const double (&q)[4]) {
+        x = fma(ad, q[0], x); y = fma(ad, q[1], y); z = fma(ad, q[2], z); w = fma(ad, q[3], w);
+    }
+    template <bool BIAS> __device__ __forceinline__ float4 finish(float4 y0, float4 b) const {
+        double ox = (double)y0.x + x, oy = (double)y0.y + y, oz = (double)y0.z + z, ow = (double)y0.w + w;
+        if constexpr (BIAS) { ox += (double)b.x; oy += (double)b.y; oz += (double)b.z; ow += (double)b.w; }
+        return make_float4((float)ox, (float)oy, (float)oz, (float)ow);
+    }
+};
 
 // ---- aggregation at width 32: 4 lanes x 2 float4 per row, 16 rows per wave pass, rows in `perm` order (descending
 // entry count; only the processing order changes, never the arithmetic).  Per row: sequential fmaf chain over the
@@ -461,9 +569,9 @@ __device__ __forceinline__ void hidden_transform_owned(const float (&b)[8][4], c
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-template <int BLOCK, int ACT, bool BIAS>
+template <int BLOCK, int ACT, bool BIAS, bool F64 = false>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
-                                                 const uint2* rec, unsigned zrow, unsigned long long* st) {
+                                                 const uint2* rec, unsigned zrow, unsigned long long* st, bool const_rows = false) {
     (void)st;
 #ifdef DGCN_DIAG
 #define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) st[i] += _t - bt; bt = _t; } while (0)
@@ -492,10 +600,14 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 #ifdef DGCN_DIAG
         bt = __builtin_amdgcn_s_memtime();
 #endif
-        const int v = rb.v[k];
+        int v = rb.v[k];
+        asm volatile("" : "+v"(v));  // (opaque: what derives from the row - swizzle keys, addresses - is formed here, per layer,
+                                     // instead of being hoisted out of the layer loop into registers the kernel does not have)
         const unsigned ri = rb.ri[k];
         const int rs = ri & 0xffff, re = rs + (ri >> 16);
-        float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+        RowAcc<F64> accA, accB;
+        accA.clear();
+        accB.clear();
         // (the row's own Z0 chunks are requested ahead of the gathers: while four row blocks' worth of state lived through
         // the layer loop these 8 registers spilled elsewhere and cost 2 %; with two it is 0.5 % the other way)
         float4* ownA = reinterpret_cast<float4*>(bufA + v * kHid + ((cfirst ^ (v & 7)) << 2));
@@ -527,29 +639,71 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
                 zB[e] = lds_chunk(w ^ cB);                                                                     \
             }                                                                                                  \
             _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                   \
-                accA = fma4(av[e], zA[e], accA);                                                               \
-                accB = fma4(av[e], zB[e], accB);                                                               \
+                accA.add(av[e], zA[e]);                                                                        \
+                accB.add(av[e], zB[e]);                                                                        \
             }                                                                                                  \
+        }
+        // (chains in double: two entries' gathers in flight instead of four - with 16 accumulator registers and the
+        // conversions on top, four would push the row-block state into scratch memory; once per launch, the pace does not matter)
+#define DGCN_TRIP_PAIR(E0, NE)                                                                                 \
+        {                                                                                                      \
+            _Pragma("unroll") for (int e = (E0); e < (E0) + 2 && e < (NE); ++e) {                              \
+                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(cur.y, 0) : e == 1 ? DGCN_QB(cur.y, 1)          \
+                                              : e == 2 ? DGCN_QB(cur.y, 2) : DGCN_QB(cur.y, 3));               \
+                const float a1 = __int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)        \
+                                                : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));             \
+                accA.add(a1, lds_chunk(w ^ cA));                                                               \
+                accB.add(a1, lds_chunk(w ^ cB));                                                               \
+            }                                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }
+        if constexpr (F64) {
+            if (const_rows) {
+                // Constant input features (X == NULL: every reference script's case): all rows of Z1 are the SAME 32 numbers,
+                // so the chain fma(val_j, Z1[u_j][c], acc) needs the entries' values only - no gathers.  Same chain, same bits.
+                const float4 fA = lds_chunk(cA), fB = lds_chunk(cB);  // row 0 of bufB (keyB(0) = 0: chunk c sits at byte 16 c)
+                const double dA[4] = {(double)fA.x, (double)fA.y, (double)fA.z, (double)fA.w};
+                const double dB[4] = {(double)fB.x, (double)fB.y, (double)fB.z, (double)fB.w};
+                for (; j + 4 <= re; j += 4) {
+                    const uint2 nxt = rec[j + 4 + kq];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double ad = (double)__int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)
+                                                                 : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));
+                        accA.add_d(ad, dA);
+                        accB.add_d(ad, dB);
+                    }
+                    cur = nxt;
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {  // the row's last 1..3 entries (a quad = one row: the test is uniform in it)
+                    const double ad = (double)__int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1) : DGCN_QB(cur.x, 2));
+                    if (j + e < re) {
+                        accA.add_d(ad, dA);
+                        accB.add_d(ad, dB);
+                    }
+                }
+                j = re;
+            }
         }
         for (; j + 4 <= re; j += 4) {
             const uint2 nxt = rec[j + 4 + kq];  // may be the next row's entry or slack: neutralised below if so
-            DGCN_TRIP(4)
+            if constexpr (F64) { DGCN_TRIP_PAIR(0, 4) DGCN_TRIP_PAIR(2, 4) }
+            else DGCN_TRIP(4)
             cur = nxt;
         }
         BSTAMP(1);
         if (j < re) {
             if (j + kq >= re) cur = make_uint2(0x80000000u, zrow);
-            DGCN_TRIP(3)
+            if constexpr (F64) { DGCN_TRIP_PAIR(0, 3) DGCN_TRIP_PAIR(2, 3) }
+            else DGCN_TRIP(3)
         }
+#undef DGCN_TRIP_PAIR
 #undef DGCN_TRIP
 #undef DGCN_QB
         BSTAMP(2);
-        float4 oA = make_float4(yA.x + accA.x, yA.y + accA.y, yA.z + accA.z, yA.w + accA.w);
-        float4 oB = make_float4(yB.x + accB.x, yB.y + accB.y, yB.z + accB.z, yB.w + accB.w);
-        if constexpr (BIAS) {
-            oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
-            oB.x += biasB.x; oB.y += biasB.y; oB.z += biasB.z; oB.w += biasB.w;
-        }
+        float4 oA = accA.template finish<BIAS>(yA, biasA);
+        float4 oB = accB.template finish<BIAS>(yB, biasB);
         oA.x = apply_act(oA.x, ACT); oA.y = apply_act(oA.y, ACT); oA.z = apply_act(oA.z, ACT); oA.w = apply_act(oA.w, ACT);
         oB.x = apply_act(oB.x, ACT); oB.y = apply_act(oB.y, ACT); oB.z = apply_act(oB.z, ACT); oB.w = apply_act(oB.w, ACT);
         *ownA = oA;
@@ -599,18 +753,19 @@ __device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const
     }
 }
 
-template <int BLOCK, int ACT>
+template <int BLOCK, int ACT, bool F64 = false>
 __device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* bufA, const ClusterRows& cr, const uint2* rec,
                                                  unsigned zrow) {
     const int lane = threadIdx.x & 63;
     const int q = lane & 7, kq = lane & 3;
     const unsigned cq = (unsigned)q << 4;
-    float4 bias = make_float4(-0.f, -0.f, -0.f, -0.f);  // x + (-0.0f) == x for every x
+    float4 bias = make_float4(-0.f, -0.f, -0.f, -0.f);  // x + (-0.0f) == x for every x (float and double alike)
     if (bias_ptr) bias = *reinterpret_cast<const float4*>(bias_ptr + 4 * q);
     if (!__any(cr.v >= 0) || cr.v < 0) return;
     const int v = cr.v;
     const int rs = (int)(cr.ri & 0xffff), re = rs + (int)(cr.ri >> 16);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    RowAcc<F64> acc;
+    acc.clear();
     float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
     const float4 y = *own;  // the row's Z0 chunk, requested ahead of the gathers (registers are plentiful here)
     int j = rs;
@@ -626,7 +781,7 @@ __device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* b
             av[e] = __int_as_float(e < 4 ? DGCN_PICK(r0.x, e & 3) : DGCN_PICK(r1.x, e & 3));          \
             z[e] = lds_chunk(w ^ cq);                                                                \
         }                                                                                            \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) acc = fma4(av[e], z[e], acc);                  \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) acc.add(av[e], z[e]);                          \
     }
     const uint2 nothing = make_uint2(0x80000000u, zrow);  // value -0.0f on the zero row: fmaf leaves acc as it is
 #pragma unroll
@@ -649,16 +804,22 @@ __device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* b
 #undef DGCN_TRIP8C
 #undef DGCN_PICK
 #undef DGCN_QB
-    float4 o = make_float4(y.x + acc.x, y.y + acc.y, y.z + acc.z, y.w + acc.w);
-    o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+    float4 o = acc.template finish<true>(y, bias);
     o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
     *own = o;
 }
 
 template <int BLOCK>
-__device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bufA, const ClusterRows& cr, const uint2* rec, unsigned zrow) {
+__device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bufA, const ClusterRows& cr, const uint2* rec, unsigned zrow,
+                                                  bool precise) {
     const float* bias = L.bias;
     const int act = L.act;
+    if (precise) {  // layer index 0: chains in double
+        if (act == DGCN_ACT_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, cr, rec, zrow);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, cr, rec, zrow);
+        else aggregate_rows8c<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, cr, rec, zrow);
+        return;
+    }
     if (act == DGCN_ACT_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_RELU>(bias, bufA, cr, rec, zrow);
     else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, cr, rec, zrow);
     else aggregate_rows8c<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, cr, rec, zrow);
@@ -667,9 +828,21 @@ __device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bu
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
 template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
-                                                 unsigned zrow, unsigned long long* st = nullptr) {
+                                                 unsigned zrow, bool precise, unsigned long long* st = nullptr, bool const_rows = false) {
     const float* bias = L.bias;
     const int act = L.act;
+    if (precise) {  // layer index 0: chains in double (once per launch: not worth twelve instantiations, the bias is a runtime test there)
+        if (bias) {
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+        } else {
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+        }
+        return;
+    }
     if (bias) {
         if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, zrow, st);
         else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, zrow, st);
@@ -1133,11 +1306,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         // live while that loop holds its MFMA operands.)
         const FusedLayer& LL = a.layers[P];
         const int v = threadIdx.x;
-        float zc0 = 0.f, zc1 = 0.f;
+        double zc0 = 0.0, zc1 = 0.0;  // (the last layer is layer index 1: its chains run in double)
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow);
+            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -1146,17 +1319,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     const float hk[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        zc0 = fmaf(hk[i], LL.W[(kHid * p + 4 * c + i) * 2 + 0], zc0);
-                        zc1 = fmaf(hk[i], LL.W[(kHid * p + 4 * c + i) * 2 + 1], zc1);
+                        zc0 = fma((double)hk[i], (double)LL.W[(kHid * p + 4 * c + i) * 2 + 0], zc0);
+                        zc1 = fma((double)hk[i], (double)LL.W[(kHid * p + 4 * c + i) * 2 + 1], zc1);
                     }
                 }
             }
             __syncthreads();
         }
-        if (v < ng) { bufA[v] = zc0; bufB[v] = zc1; }
+        if (v < ng) { bufA[v] = (float)zc0; bufB[v] = (float)zc1; }
         l_first = P;
     }
-    if (a.num_layers > 2 && P == 1 && !scores_given) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3));  // first hidden 32x64 product
+    // (layer 1's fragments are fetched behind layer 0's aggregation like every other layer's, not here: they would be live
+    // through that aggregation, whose chains run in double, and push the row-block state into scratch memory.  bfrag is
+    // first read in iteration l = 1, after the fetch at the end of iteration 0.)
+    // Layer 0 of a deep stack runs apart from the loop: its aggregation carries the chains in double, and inside the loop
+    // the loop-invariant parts of that code (and of the first transform) would be hoisted and kept in registers through all
+    // the other layers - the kernel has none to spare (every spill also makes the launch set up scratch memory).
+    if (!scores_given && P == 1 && a.num_layers > 1 && a.layers[0].cout == kHid) {
+        const FusedLayer& L = a.layers[0];
+        const int prio_base = (second && a.prio_second) ? 1 : 0;
+        if (a.prio_second || a.prio_gather) set_prio(prio_base);
+        first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
+        STAMP(a, g, 3, tclk);
+        __syncthreads();
+        if (a.prio_gather) set_prio(prio_base + a.prio_gather);
+        if constexpr (CLUSTER) {
+            cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
+        } else {
+            hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
+        }
+        STAMP(a, g, 4, tclk);
+        if (a.layers[1].cout == kHid) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3), true);  // layer index 1: the f64 MFMA's lane map
+        __syncthreads();
+        l_first = 1;
+    }
     for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
         // fp32 MFMAs and VALU work exclude each other on a SIMD and the older wave wins (tools/micro/mfma_valu.hip):
@@ -1181,19 +1378,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 #ifdef DGCN_DIAG
             if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (l == 0) first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
-            else if constexpr (CLUSTER) {
+            if constexpr (CLUSTER) {  // (l >= 1 here: layer 0 ran above)
                 float* xz0 = a.xz + (size_t)g * 3 * a.max_nodes * kHid;
                 float* slice = xz0 + (size_t)(l % 3) * a.max_nodes * kHid;
-                hidden_transform_owned<BLOCK>(bfrag, ctile, bufA, bufB, slice);
+                if (l == 1) hidden_transform_owned_f64<BLOCK>(bfrag, ctile, bufA, bufB, slice);
+                else hidden_transform_owned<BLOCK>(bfrag, ctile, bufA, bufB, slice);
                 cluster_pull_rows<BLOCK>(slice, bufB, perm, ng, K, cw, a.status);
                 cluster_mark_unwritten<BLOCK>(ctile, xz0 + (size_t)((l + 2) % 3) * a.max_nodes * kHid);
             }
+            else if (l == 1) hidden_transform_f64<BLOCK>(bfrag, ng, bufA, bufB);
             else if (!DIAG_ON(a, 1)) hidden_transform<BLOCK>(bfrag, ng, bufA, bufB);
 #ifdef DGCN_DIAG
             if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-            STAMP(a, g, l == 0 ? 3 : 5, tclk);  // transform body (wave 0)
+            STAMP(a, g, 5, tclk);  // transform body (wave 0)
             __syncthreads();
             STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
 #ifdef DGCN_DIAG
@@ -1206,19 +1404,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
             }
             if constexpr (CLUSTER) {
-                cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow);
+                cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow, false);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
             } else {
 #ifdef DGCN_DIAG
-                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-                hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow);
+                hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, false);
 #endif
             }
 #ifdef DGCN_DIAG
             if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
-            STAMP(a, g, l == 0 ? 4 : 7, tclk);  // gather body (wave 0)
+            STAMP(a, g, 7, tclk);  // gather body (wave 0)
             // fetch the next hidden layer's weights now: they land while this wave waits at the barrier, and
             // their 32 registers are not live during the gather phase
             // (both branches define bfrag: otherwise its 32 registers count as live through the gather of every layer)
@@ -1247,6 +1445,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 if (P > 1) {  // chains already run block by block above
                     z0 = bufA[v];
                     z1 = bufB[v];
+                } else if (l == 1) {  // layer index 1 (a two-layer stack): both chains in double, same k order
+                    double d0 = 0.0, d1 = 0.0;
+                    for (int k = 0; k < L.cin; ++k) {
+                        const double h = (double)bufA[swz(v, k)];
+                        d0 = fma(h, (double)L.W[k * 2 + 0], d0);
+                        d1 = fma(h, (double)L.W[k * 2 + 1], d1);
+                    }
+                    z0 = (float)d0;
+                    z1 = (float)d1;
                 } else if (l > 0 && L.cin == kHid) {  // the row as 8 swizzled 16-byte chunks, same k order
 #pragma unroll
                     for (int c = 0; c < kHid / 4; ++c) {
@@ -1277,20 +1484,38 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (owned) {
                 const unsigned ri = rinfo[v];
                 const int rs = ri & 0xffff, re = rs + (ri >> 16);
-                float acc = 0.f;
+                float o;
                 int j = rs;
-                for (; j + 4 <= re; j += 4) {  // loads of four entries in flight, chain order unchanged
-                    const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
-                    const float y0 = bufB[words[j] >> 7], y1 = bufB[words[j + 1] >> 7];
-                    const float y2 = bufB[words[j + 2] >> 7], y3 = bufB[words[j + 3] >> 7];
-                    acc = fmaf(a0, y0, acc);
-                    acc = fmaf(a1, y1, acc);
-                    acc = fmaf(a2, y2, acc);
-                    acc = fmaf(a3, y3, acc);
+                if (l == 0) {  // layer index 0 (a one-layer model): the chain in double, rounded once after + z0 (+ bias)
+                    double acc = 0.0;
+                    for (; j + 4 <= re; j += 4) {
+                        const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
+                        const float y0 = bufB[words[j] >> 7], y1 = bufB[words[j + 1] >> 7];
+                        const float y2 = bufB[words[j + 2] >> 7], y3 = bufB[words[j + 3] >> 7];
+                        acc = fma((double)a0, (double)y0, acc);
+                        acc = fma((double)a1, (double)y1, acc);
+                        acc = fma((double)a2, (double)y2, acc);
+                        acc = fma((double)a3, (double)y3, acc);
+                    }
+                    for (; j < re; ++j) acc = fma((double)vals[j], (double)bufB[words[j] >> 7], acc);
+                    acc = (double)z0 + acc;
+                    if (L.bias) acc += (double)L.bias[0];
+                    o = (float)acc;
+                } else {
+                    float acc = 0.f;
+                    for (; j + 4 <= re; j += 4) {  // loads of four entries in flight, chain order unchanged
+                        const float a0 = vals[j], a1 = vals[j + 1], a2 = vals[j + 2], a3 = vals[j + 3];
+                        const float y0 = bufB[words[j] >> 7], y1 = bufB[words[j + 1] >> 7];
+                        const float y2 = bufB[words[j + 2] >> 7], y3 = bufB[words[j + 3] >> 7];
+                        acc = fmaf(a0, y0, acc);
+                        acc = fmaf(a1, y1, acc);
+                        acc = fmaf(a2, y2, acc);
+                        acc = fmaf(a3, y3, acc);
+                    }
+                    for (; j < re; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
+                    o = z0 + acc;
+                    if (L.bias) o += L.bias[0];
                 }
-                for (; j < re; ++j) acc = fmaf(vals[j], bufB[words[j] >> 7], acc);
-                float o = z0 + acc;
-                if (L.bias) o += L.bias[0];
                 score = apply_act(o, L.act);
                 if (a.scores && !(CLUSTER && a.do_lgs)) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;  // (cluster + search: below)
                 if constexpr (CLUSTER) xs0[a.max_nodes + v] = score;

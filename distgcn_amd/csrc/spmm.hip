@@ -215,6 +215,58 @@ __global__ __launch_bounds__(256) void k_spmm_global(const int32_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row sums carried in double (the contract of layer index 0, DGCN_PRECISE in include/dgcn.h): ONE fma chain over the row's
+// entries in CSR order, out = (float)((double)y0 + acc [+ (double)bias]), activation in float32.  Runs once per forward
+// of the layer-by-layer path: a plain global-gather kernel, LPR lanes x VEC features per row.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_f64acc(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                     const float* __restrict__ values, int num_rows, const float* __restrict__ Z,
+                                                     int ldz, int C, const float* __restrict__ Y0, int ldy0,
+                                                     const float* __restrict__ bias, int act, float* __restrict__ Y, int ldy) {
+    const int per_row = (C + VEC - 1) / VEC;
+    const long total = (long)num_rows * per_row;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i / per_row), foff = (int)(i - (long)v * per_row) * VEC;
+        double acc[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
+        const int rs = row_ptr[v], re = row_ptr[v + 1];
+        for (int j = rs; j < re; ++j) {
+            const double a = (double)values[j];
+            const float* z = Z + (size_t)col_idx[j] * ldz + foff;
+            if constexpr (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(z);
+                acc[0] = fma(a, (double)q.x, acc[0]); acc[1] = fma(a, (double)q.y, acc[1]);
+                acc[2] = fma(a, (double)q.z, acc[2]); acc[3] = fma(a, (double)q.w, acc[3]);
+            } else {
+                acc[0] = fma(a, (double)z[0], acc[0]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            double o = acc[c];
+            if (Y0) o = (double)Y0[(size_t)v * ldy0 + foff + c] + o;
+            if (bias) o = o + (double)bias[foff + c];
+            Y[(size_t)v * ldy + foff + c] = apply_act((float)o, act);
+        }
+    }
+}
+
+int spmm_f64acc_dispatch(const DgcnCsr* S, const float* Z, int ldz, int C, const float* Y0, int ldy0, const float* bias, int act,
+                         float* Y, int ldy, hipStream_t s) {
+    if (S->num_rows <= 0) return DGCN_OK;
+    const bool vec = (C % 4 == 0) && (ldz % 4 == 0) && ((uintptr_t)Z % 16 == 0);
+    const long total = (long)S->num_rows * (vec ? C / 4 : C);
+    const int blocks = (int)min((total + 255) / 256, (long)256 * 32);
+    TimedLaunch t("spmm", s);
+    if (vec) DGCN_LAUNCH(t, (k_spmm_f64acc<4>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values, S->num_rows, Z, ldz, C,
+                         Y0, ldy0, bias, act, Y, ldy);
+    else DGCN_LAUNCH(t, (k_spmm_f64acc<1>), dim3(blocks), dim3(256), 0, s, S->row_ptr, S->col_idx, S->values, S->num_rows, Z, ldz, C,
+                     Y0, ldy0, bias, act, Y, ldy);
+    return check_launch("k_spmm_f64acc");
+}
+
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     if (!e || !*e) return dflt;
@@ -350,6 +402,14 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
 using namespace dgcn;
 
 extern "C" int dgcn_spmm_split(int32_t C) { return C > 0 ? spmm_split_for(C) : 1; }
+
+extern "C" int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const float* Z, int32_t ldz, int32_t C, const float* Y0, int32_t ldy0,
+                                      const float* bias, int32_t act, float* Y, int32_t ldy, void* stream) {
+    if (!S || !Z || !Y || !S->row_ptr || (S->nnz > 0 && (!S->col_idx || !S->values)))
+        return fail(DGCN_ERR_ARG, "dgcn_spmm_f64acc_batch: null argument");
+    if (C <= 0 || ldz < C || ldy < C || (Y0 && ldy0 < C)) return fail(DGCN_ERR_ARG, "dgcn_spmm_f64acc_batch: bad strides");
+    return spmm_f64acc_dispatch(S, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, (hipStream_t)stream);
+}
 
 extern "C" int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
                                const float* Z, int32_t ldz, int32_t C, const float* Y0, int32_t ldy0,

@@ -110,6 +110,34 @@ __global__ __launch_bounds__(256) void k_transform_narrow(const float* __restric
     }
 }
 
+// The k chain carried in double and rounded once (the contract of layer index 1, DGCN_PRECISE in include/dgcn.h): one thread
+// per output element.  Runs once per forward of the layer-by-layer path.
+__global__ __launch_bounds__(256) void k_transform_f64acc(const float* __restrict__ H, int ldh, float h_const, int rows, int cin,
+                                                          const float* __restrict__ W, int ctot, float* __restrict__ Z, int ldz) {
+    const long total = (long)rows * ctot;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / ctot), n = (int)(i - (long)r * ctot);
+        double acc = 0.0;
+        if (H) {
+            const float* h = H + (size_t)r * ldh;
+            for (int k = 0; k < cin; ++k) acc = fma((double)h[k], (double)W[k * ctot + n], acc);
+        } else {
+            for (int k = 0; k < cin; ++k) acc = fma((double)h_const, (double)W[k * ctot + n], acc);
+        }
+        Z[(size_t)r * ldz + n] = (float)acc;
+    }
+}
+
+int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
+                              int ldz, hipStream_t s) {
+    if (rows <= 0) return DGCN_OK;
+    TimedLaunch t("transform", s);
+    const long total = (long)rows * ctot;
+    const int blocks = (int)min((total + 255) / 256, (long)256 * 32);
+    DGCN_LAUNCH(t, k_transform_f64acc, dim3(blocks), dim3(256), 0, s, H, ldh, h_const, rows, cin, W, ctot, Z, ldz);
+    return check_launch("k_transform_f64acc");
+}
+
 int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                        int ldz, hipStream_t s) {
     if (rows <= 0) return DGCN_OK;
@@ -151,4 +179,11 @@ extern "C" int dgcn_transform_batch(const float* H, int32_t ldh, float h_const, 
     if (!W || !Z) return fail(DGCN_ERR_ARG, "dgcn_transform_batch: null argument");
     if (cin <= 0 || ctot <= 0 || ldz < ctot || (H && ldh < cin)) return fail(DGCN_ERR_ARG, "dgcn_transform_batch: bad sizes");
     return transform_dispatch(H, ldh, h_const, rows, cin, W, ctot, Z, ldz, (hipStream_t)stream);
+}
+
+extern "C" int dgcn_transform_f64acc_batch(const float* H, int32_t ldh, float h_const, int32_t rows, int32_t cin,
+                                           const float* W, int32_t ctot, float* Z, int32_t ldz, void* stream) {
+    if (!W || !Z) return fail(DGCN_ERR_ARG, "dgcn_transform_f64acc_batch: null argument");
+    if (cin <= 0 || ctot <= 0 || ldz < ctot || (H && ldh < cin)) return fail(DGCN_ERR_ARG, "dgcn_transform_f64acc_batch: bad sizes");
+    return transform_f64acc_dispatch(H, ldh, h_const, rows, cin, W, ctot, Z, ldz, (hipStream_t)stream);
 }

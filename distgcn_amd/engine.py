@@ -203,12 +203,19 @@ class Engine:
 
     # ------------------------------------------------------------------ K4
     def spmm(self, csr: dict, Z, C_feat: int, ldz: Optional[int] = None, graph_ptr=None, num_graphs=0, max_nodes=0,
-             Y0=None, ldy0=0, bias=None, act="linear", out=None):
+             Y0=None, ldy0=0, bias=None, act="linear", out=None, precise=False):
+        """``precise``: the row sums carried in double (``dgcn_spmm_f64acc_batch``, the contract of layer index 0)."""
         t = self.torch
         n = int(csr["c"].num_rows)
         ldz = ldz or int(Z.shape[-1])
         if out is None:
             out = t.empty((n, C_feat), dtype=t.float32, device=self.device)
+        if precise:
+            _lib.check(self.lib.dgcn_spmm_f64acc_batch(
+                C.byref(csr["c"]), Z.data_ptr(), ldz, C_feat, Y0.data_ptr() if Y0 is not None else None, ldy0,
+                bias.data_ptr() if bias is not None else None, ACT_CODES[act], out.data_ptr(), int(out.shape[-1]),
+                self._stream()), "dgcn_spmm_f64acc_batch")
+            return out
         _lib.check(self.lib.dgcn_spmm_batch(
             C.byref(csr["c"]), graph_ptr.data_ptr() if graph_ptr is not None else None, num_graphs, max_nodes,
             Z.data_ptr(), ldz, C_feat, Y0.data_ptr() if Y0 is not None else None, ldy0,
@@ -217,13 +224,15 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ K2/K3
-    def transform(self, H, W, rows: Optional[int] = None, h_const: float = 1.0):
+    def transform(self, H, W, rows: Optional[int] = None, h_const: float = 1.0, precise=False):
+        """``precise``: the k chains carried in double (``dgcn_transform_f64acc_batch``, the contract of layer index 1)."""
         t = self.torch
         cin, ctot = int(W.shape[0]), int(W.shape[1])
         if H is not None:
             rows = int(H.shape[0])
         out = t.empty((rows, ctot), dtype=t.float32, device=self.device)
-        _lib.check(self.lib.dgcn_transform_batch(H.data_ptr() if H is not None else None,
+        fn = self.lib.dgcn_transform_f64acc_batch if precise else self.lib.dgcn_transform_batch
+        _lib.check(fn(H.data_ptr() if H is not None else None,
                                                  int(H.shape[1]) if H is not None else cin, h_const, rows, cin,
                                                  W.data_ptr(), ctot, out.data_ptr(), ctot, self._stream()),
                    "dgcn_transform_batch")

@@ -210,6 +210,15 @@ class MWISSolver(object):
             best = np.dot(nIS_vec, wts)
         return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
+    def solve_mwis_cgs_train(self, adj_0, wts_0, train=False, grd=1.0):
+        """The ``CGCN-CGS`` scheduler of ``wireless_dqn_test.py:262-266`` (``mwis_gdpg_call.py:778-839``): with
+        ``train=False`` the reference runs exactly the loop of ``solve_mwis_cit`` (its replay bookkeeping is all behind
+        ``if train``), so inference is that solver; ``train=True`` memorises transitions for the optimiser - outside the
+        inference drop-in."""
+        if train:
+            raise NotImplementedError("training is outside the inference drop-in")
+        return self.solve_mwis_cit(adj_0, wts_0, train=False, grd=grd)
+
     def _rollout(self, which, adj_0, wts_0, b=16, rng=None, reference_ties=False):
         """The four rollout searches of the reference share one loop; ``ROLLOUT_VARIANTS[which]`` says
         whether the GCN is re-run on every residual graph and what orders the greedy completions.

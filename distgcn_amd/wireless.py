@@ -14,7 +14,12 @@ Solvers (``algo``): ``"DGCN-LGS-it"`` = ``solve_mwis_dit`` (``:251-254``) and ``
 before the GCN runs (``mwis_dqn_call.py:202-207``) - a mask of the residual-graph kernel
 (``dgcn_solve_residual_batch``) instead of a re-sliced matrix.  The Gurobi denominators (``mlp_gurobi``) and the
 Poisson-disk topology generator (``graph_util``, absent from the reference) are out of scope: callers bring
-their conflict graphs; ``total_wt`` per slot is returned so that any denominator can be applied.
+their single-channel conflict graphs; ``total_wt`` per slot is returned so that any denominator can be applied.
+``"CGCN-CGS"`` = ``solve_mwis_cgs_train(train=False)`` (``:262-266``; ``mwis_gdpg_call.py:778-839``).
+The multi-channel expansion IS here: ``multichannel_conflict_simulate`` (per-channel copies of a conflict graph with
+edges dropped at random, ``wireless_rollout_test_flood.py:70-95``) and ``multichannel_conflict_graph`` (the joint graph
+on ``n_ch * nflows`` vertices: the channels' graphs on the diagonal blocks plus a clique over every flow's copies -
+one radio per node, ``:98-133``), both checked against the reference's own functions (tests/golden/multichannel.npz).
 Multi-channel graphs (vertex = channel * nflows + flow, ``order='F'`` at ``:234``): when several channels
 schedule the same flow the reference keeps whichever its Python set iterates last; here the highest channel.
 """
@@ -61,6 +66,60 @@ def slot_weights(queue, rates, wt_sel: str):
     raise ValueError("wt_sel must be one of qr, q, qor, qrm (the reference's random weights are unseeded per slot)")
 
 
+def multichannel_conflict_simulate(adj_i, k: int = 3, p: float = 0.8, rng=np.random) -> List:
+    """``k`` per-channel copies of the conflict graph ``adj_i``, each edge of each copy kept with probability ``p``
+    (``wireless_rollout_test_flood.py:83-95``; what ``wireless_dqn_test_mc.py:160`` calls
+    ``multichannel_conflict_simulate``).  The reference draws ``np.random.rand()`` once per edge, channel by channel,
+    edges in the order (u ascending, v < u ascending), and drops the edge when the draw exceeds ``p``: with
+    ``rng=np.random`` and the same seed the same graphs come back.  -> list of symmetric CSR matrices (values 1.0)."""
+    import scipy.sparse as sp
+    a = sp.csr_matrix(adj_i)
+    n = a.shape[0]
+    low = sp.tril(a, k=-1).tocsr()  # row u holds its neighbours v < u, ascending after sort_indices
+    low.sort_indices()
+    us = np.repeat(np.arange(n), np.diff(low.indptr))
+    vs = low.indices
+    keep_val = low.data != 0
+    us, vs = us[keep_val], vs[keep_val]
+    out = []
+    for _ in range(int(k)):
+        draws = np.array([rng.rand() for _ in range(us.size)]) if us.size else np.zeros(0)
+        keep = ~(draws > p)
+        u, v = us[keep], vs[keep]
+        m = sp.csr_matrix((np.ones(2 * u.size), (np.concatenate([u, v]), np.concatenate([v, u]))), shape=(n, n))
+        m.sort_indices()
+        out.append(m)
+    return out
+
+
+def multichannel_conflict_graph(graphs: Sequence):
+    """``(adj_list, adj_gK)`` of ``wireless_rollout_test_flood.py:98-133`` (used at ``wireless_dqn_test_mc.py:161``):
+    ``adj_list[k]`` = channel k's conflict graph (for the channel-by-channel schedulers, ``simulate_seq``); ``adj_gK`` =
+    the joint conflict graph on ``K * nn`` vertices, vertex ``k * nn + v`` = link v on channel k (``order='F'`` of the
+    weight matrix, ``:240``): block k of the diagonal is channel k's graph, and the K copies of every link form a
+    clique (a node has one radio: a link is active on at most one channel, ``:116-124``).  ``graphs``: K adjacency
+    matrices (SciPy / dense / anything ``as_csr`` takes) of one size.  Values are 1.0; CSR with sorted rows."""
+    import scipy.sparse as sp
+    mats = [sp.csr_matrix(as_csr(g)) for g in graphs]
+    if not mats:
+        raise ValueError("no channel graphs")
+    nn = mats[0].shape[0]
+    if any(m.shape != (nn, nn) for m in mats):
+        raise AssertionError("channel graphs differ in size")  # the reference's assert(len(set(no_nodes)) == 1)
+    K = len(mats)
+    adj_list = []
+    for m in mats:
+        c = sp.csr_matrix((np.ones(m.nnz), m.indices.copy(), m.indptr.copy()), shape=m.shape)
+        c.sort_indices()
+        adj_list.append(c)
+    eye = sp.identity(nn, format="csr")
+    blocks = [[adj_list[k] if k == j else eye for j in range(K)] for k in range(K)]
+    adj_gK = sp.bmat(blocks, format="csr")
+    adj_gK.data[:] = 1.0
+    adj_gK.sort_indices()
+    return adj_list, adj_gK
+
+
 def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: str = "DGCN-LGS", agent=None,
              wt_sel: str = "qr") -> List[Dict[str, np.ndarray]]:
     """Run all instances (``adjs[i]``: conflict graph on ``nflows_i * n_ch`` vertices, ``traffics[i]`` from
@@ -68,8 +127,8 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
     [T, nflows], "total_wt": [T], "scheduled": [T]}`` (queue lengths AFTER the slot's departures, as the
     reference's ``queue_mtx_dict``)."""
     import torch
-    if algo not in ("Greedy", "DGCN-LGS", "DGCN-LGS-it", "DGCN-RS"):
-        raise ValueError("algo must be 'Greedy', 'DGCN-LGS', 'DGCN-LGS-it' or 'DGCN-RS'")
+    if algo not in ("Greedy", "DGCN-LGS", "DGCN-LGS-it", "DGCN-RS", "CGCN-CGS"):
+        raise ValueError("algo must be 'Greedy', 'DGCN-LGS', 'DGCN-LGS-it', 'DGCN-RS' or 'CGCN-CGS'")
     if algo != "Greedy" and agent is None:
         raise ValueError("%s needs an agent (mwis_dqn_call.DQNAgent / mwis_gdpg_call.DQNAgent)" % algo)
     eng = get_engine()
@@ -141,10 +200,11 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
         else:
             # 'DGCN-LGS-it' = solve_mwis_dit (wireless_dqn_test.py:251-254): the GCN is re-run on the residual graph
             # before every greedy round; 'DGCN-RS' = solve_mwis_rollout_wrap (:256-260): top-16 candidates, greedy
-            # completions, per connected component.  Both: one launch per solver step for every instance / component.
+            # completions, per connected component; 'CGCN-CGS' = solve_mwis_cgs_train(train=False) (:262-266), the
+            # centralised argmax step.  All: one launch per solver step for every instance / component.
             state.zero_()
             res = eng.solve_residual(db, dm, state, predict=agent.flags.predict,
-                                     greedy=eng.GREEDY_ROUNDS if algo == "DGCN-LGS-it" else eng.GREEDY_ROLLOUT,
+                                     greedy={"DGCN-LGS-it": eng.GREEDY_ROUNDS, "CGCN-CGS": eng.GREEDY_CENTRAL}.get(algo, eng.GREEDY_ROLLOUT),
                                      max_rounds=1, beam=16, weight_features=agent.flags.predict != "mwis", out=out)
             st, status = state[:hb.num_nodes], res["status"]
         # (dense selects instead of boolean-mask indexing: nothing here waits for the device)

@@ -159,6 +159,13 @@ int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_grap
                     const float* Y0, int32_t ldy0, const float* bias, int32_t act,
                     float* Y, int32_t ldy, void* stream);
 
+/* The same aggregation with the row sum carried in double: ONE fma chain over the row's entries in CSR order starting
+ * from 0.0, then (double)Y0 + sum, then + (double)bias, rounded to float32 once, activation in float32.  This is the
+ * contract of LAYER INDEX 0 in every forward / solve entry point below (see "Precision" at dgcn_gcn_forward_batch). */
+int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const float* Z, int32_t ldz, int32_t C,
+                           const float* Y0, int32_t ldy0, const float* bias, int32_t act,
+                           float* Y, int32_t ldy, void* stream);
+
 /* ---- K2/K3: gcn/layers.py:29-31 dot(x, W_i) for all supports at once -------------------------
  * Z[r, 0:ctot] = sum_k H[r, k] * W[k, 0:ctot], a float32 fmaf chain over k = 0..cin-1 starting
  * from 0 (bit-identical between the MFMA and the VALU code paths).  W is [cin][ctot] row-major
@@ -167,7 +174,21 @@ int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_grap
 int dgcn_transform_batch(const float* H, int32_t ldh, float h_const, int32_t rows, int32_t cin,
                          const float* W, int32_t ctot, float* Z, int32_t ldz, void* stream);
 
+/* The same product with the k chain carried in double (fma from 0.0, ascending k) and rounded to float32 once: the
+ * contract of LAYER INDEX 1 in every forward / solve entry point below. */
+int dgcn_transform_f64acc_batch(const float* H, int32_t ldh, float h_const, int32_t rows, int32_t cin,
+                                const float* W, int32_t ctot, float* Z, int32_t ldz, void* stream);
+
 /* ---- A4-A6: sess.run(model.outputs_softmax) for a batch (mwis_dqn_call.py:140-143) ------------
+ * Precision (part of the ABI, mirrored by oracle/dgcn_oracle.c, identical in every mode and entry point): float32
+ * fmaf chains as described at dgcn_transform_batch / dgcn_spmm_batch, EXCEPT the aggregation of layer index 0 and
+ * the transform of layer index 1, whose chains run in double and are rounded once (dgcn_spmm_f64acc_batch,
+ * dgcn_transform_f64acc_batch).  Reason: the first layer's output is an affine function of one scalar per vertex (its
+ * degree-normalised neighbour sum, large on hub vertices) and the second layer's products cancel it; float32 rounding
+ * in those two places is what the remaining layers amplify.  Measured on 4 000 BA graphs with the shipped 20-layer
+ * model: max |score - float64 evaluation| 1.8e-5 with float32 everywhere, 5.5e-6 with these two chains in double
+ * (a NumPy float32 evaluation of the reference's formula: 1.4e-5).  DESIGN.md section 3.
+ *
  * scores[num_nodes * out_dim] = GCN forward over the batch.  X is the dense row-normalised
  * feature matrix [num_nodes][in_dim] or NULL for "every entry = x_const".
  * workspace: dgcn_gcn_forward_workspace() bytes of device scratch.

@@ -82,7 +82,8 @@ def spmm_split(C_feat):
     return int(lib().orc_spmm_split(int(C_feat)))
 
 
-def spmm(row_ptr, col_idx, values, Z, C_feat, Y0=None, bias=None, act=0, split=0):
+def spmm(row_ptr, col_idx, values, Z, C_feat, Y0=None, bias=None, act=0, split=0, precise=False):
+    """``precise``: the row sum as one fma chain in double (the contract of layer index 0, DGCN_SPMM_PRECISE)."""
     n = row_ptr.size - 1
     Z = np.ascontiguousarray(Z, np.float32)
     Y = np.empty((n, C_feat), np.float32)
@@ -90,20 +91,25 @@ def spmm(row_ptr, col_idx, values, Z, C_feat, Y0=None, bias=None, act=0, split=0
         Y0 = np.ascontiguousarray(Y0, np.float32)
     if bias is not None:
         bias = np.ascontiguousarray(bias, np.float32)
+    if precise:
+        lib().orc_spmm_f64(n, _p(row_ptr), _p(col_idx), _p(values), _p(Z), int(Z.shape[1]), C_feat, _p(Y0),
+                           int(Y0.shape[1]) if Y0 is not None else 0, _p(bias), act, _p(Y), C_feat)
+        return Y
     lib().orc_spmm(n, _p(row_ptr), _p(col_idx), _p(values), _p(Z), int(Z.shape[1]), C_feat, _p(Y0),
                    int(Y0.shape[1]) if Y0 is not None else 0, _p(bias), act, _p(Y), C_feat, int(split))
     return Y
 
 
-def transform(H, W, rows=None, h_const=1.0):
+def transform(H, W, rows=None, h_const=1.0, precise=False):
+    """``precise``: the k chain carried in double, rounded once (the contract of layer index 1)."""
     W = np.ascontiguousarray(W, np.float32)
     cin, ctot = W.shape
     if H is not None:
         H = np.ascontiguousarray(H, np.float32)
         rows = H.shape[0]
     Z = np.empty((rows, ctot), np.float32)
-    lib().orc_transform(_p(H), int(H.shape[1]) if H is not None else cin, C.c_float(h_const), rows, cin, _p(W), ctot,
-                        _p(Z), ctot)
+    fn = lib().orc_transform_f64 if precise else lib().orc_transform
+    fn(_p(H), int(H.shape[1]) if H is not None else cin, C.c_float(h_const), rows, cin, _p(W), ctot, _p(Z), ctot)
     return Z
 
 

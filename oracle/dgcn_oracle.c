@@ -8,9 +8,15 @@
  *   supports   (float)(-(dinv[deg u] * dinv[deg v])), diagonal 1.0f first in each row
  *              [gcn/utils.py:120-127, 258-274]
  *   transform  z[r][n] = fmaf chain over k = 0..cin-1 from 0           [gcn/layers.py:202]
+ *              layer index 1 (the first product whose input is a hidden activation): the same chain carried
+ *              in double (fma), rounded to float32 once
  *   aggregate  acc = G interleaved fmaf chains over the row's CSR entries + butterfly (orc_spmm);
  *              out = z0 + acc; out += bias;
  *              activation                                              [gcn/layers.py:206-216]
+ *              layer index 0: one fma chain in double over the entries, out = (float)((double)z0 + acc [+ bias])
+ *   (why those two: the first layer's output is an affine function of ONE scalar per vertex - its normalised
+ *   degree sum, large on hubs - and the second layer's products cancel it; float32 rounding there is what the
+ *   other 18 layers amplify.  profiles/r03_error_budget.txt)
  *   priority   (double)score * weight                                  [mwis_dqn_call.py:232]
  *   lgs        synchronous rounds, order (priority desc, index asc)    [heuristics.py:77-116]
  * Parity status: pinned for supports / lgs (golden vectors from the imported reference);
@@ -132,6 +138,17 @@ void orc_transform(const float* H, int ldh, float h_const, int rows, int cin, co
         }
 }
 
+/* the same product with the chain carried in double (DGCN_PRECISE: layer index 1) */
+void orc_transform_f64(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
+                       int ldz) {
+    for (int r = 0; r < rows; ++r)
+        for (int n = 0; n < ctot; ++n) {
+            double acc = 0.0;
+            for (int k = 0; k < cin; ++k) acc = fma((double)(H ? H[(size_t)r * ldh + k] : h_const), (double)W[k * ctot + n], acc);
+            Z[(size_t)r * ldz + n] = (float)acc;
+        }
+}
+
 /* Split factor of the row sum for feature width C: part of the arithmetic contract of
  * dgcn_spmm_batch (include/dgcn.h).  The shipped default is 1 for every width (plain sequential
  * chain); other factors exist only behind the DGCN_SPMM_SPLIT tuning knob. */
@@ -165,6 +182,21 @@ void orc_spmm(int num_rows, const int32_t* row_ptr, const int32_t* col_idx, cons
         }
 }
 
+/* the same aggregation with ONE fma chain in double over the row's entries (DGCN_PRECISE: layer index 0):
+ * out = (float)((double)y0 + acc [+ (double)bias]), then the activation in float32 */
+void orc_spmm_f64(int num_rows, const int32_t* row_ptr, const int32_t* col_idx, const float* values, const float* Z,
+                  int ldz, int C, const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy) {
+    for (int v = 0; v < num_rows; ++v)
+        for (int c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int j = row_ptr[v]; j < row_ptr[v + 1]; ++j)
+                acc = fma((double)values[j], (double)Z[(size_t)col_idx[j] * ldz + c], acc);
+            if (Y0) acc = (double)Y0[(size_t)v * ldy0 + c] + acc;
+            if (bias) acc = acc + (double)bias[c];
+            Y[(size_t)v * ldy + c] = act_apply((float)acc, act);
+        }
+}
+
 /* Whole forward, layer by layer, over the supports [I, T_1, .., T_k] (num_supports = k + 1; sup_* arrays hold
  * T_1..T_k).  dims[l], dims[l+1] = in/out of layer l; weights[l] is [in][num_supports*out] (W0 | W1 | ..);
  * biases[l] may be NULL; acts[l] activation code.  out = ((Z_0 + T_1.Z_1) + T_2.Z_2 ..) + b, activation. */
@@ -182,15 +214,20 @@ int orc_forward_poly(int num_nodes, int num_supports, const int32_t* const* sup_
     int ldh = dims[0];
     for (int l = 0; l < num_layers; ++l) {
         const int cin = dims[l], cout = dims[l + 1], ctot = K * cout;
-        orc_transform(H, ldh, x_const, num_nodes, cin, weights[l], ctot, Z, ctot);
+        if (l == 1) orc_transform_f64(H, ldh, x_const, num_nodes, cin, weights[l], ctot, Z, ctot);
+        else orc_transform(H, ldh, x_const, num_nodes, cin, weights[l], ctot, Z, ctot);
         float* out = (l == num_layers - 1) ? scores : Hb;
         const float* run = Z;
         int ldrun = ctot;
         for (int i = 1; i < K; ++i) {
             const int fin = i == K - 1;
             float* dst = fin ? out : Tb;
-            orc_spmm(num_nodes, sup_row_ptr[i - 1], sup_col[i - 1], sup_val[i - 1], Z + i * cout, ctot, cout, run, ldrun,
-                     fin ? biases[l] : NULL, fin ? acts[l] : 0, dst, cout, 0);
+            if (l == 0)
+                orc_spmm_f64(num_nodes, sup_row_ptr[i - 1], sup_col[i - 1], sup_val[i - 1], Z + i * cout, ctot, cout, run,
+                             ldrun, fin ? biases[l] : NULL, fin ? acts[l] : 0, dst, cout);
+            else
+                orc_spmm(num_nodes, sup_row_ptr[i - 1], sup_col[i - 1], sup_val[i - 1], Z + i * cout, ctot, cout, run, ldrun,
+                         fin ? biases[l] : NULL, fin ? acts[l] : 0, dst, cout, 0);
             run = dst;
             ldrun = cout;
         }

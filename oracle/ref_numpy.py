@@ -411,6 +411,12 @@ def solve_mwis_cit(scores_fn, adj_0, wts_0, predict="mwis"):
     return set(int(i) for i in np.argwhere(nIS_vec == 1).flatten()), best
 
 
+def solve_mwis_cgs_train(scores_fn, adj_0, wts_0, predict="mwis"):
+    """``solve_mwis_cgs_train(train=False)`` (mwis_gdpg_call.py:778-839): line for line the loop of solve_mwis_cit
+    (:343-384) - the ``buffers`` / ``memorize`` bookkeeping only runs ``if train`` - so the same restatement serves."""
+    return solve_mwis_cit(scores_fn, adj_0, wts_0, predict)
+
+
 def solve_mwis_rollout(scores_fn, adj_0, wts_0, b=16, predict="mwis", rng=None, rescore=True, by_priority=False,
                        reference_ties=False):
     """Top-b GCN candidates, each scored by its weight plus a greedy completion of the residual

@@ -3,6 +3,7 @@
 build container and store what it returns as golden vectors: tests/golden/ref_exec.npz.  TEST INFRASTRUCTURE.
 
     python oracle/run_reference.py            # needs /root/reference; never runs on the GPU box
+    python oracle/run_reference.py --big      # tests/golden/ref_exec_big.npz: BA N=300 m=2 at l=20, one N=500 b=16 rollout
 
 The reference imports TensorFlow, which cannot be installed here.  oracle/tf_shim/ puts a NumPy stand-in for the
 ~60 tf.compat.v1 entry points its model code touches first on sys.path (lazy graph nodes evaluated in float32 by
@@ -139,7 +140,7 @@ def worker_gdpg(out_path):
         act_values, action = agent.predict(state)
         out["g%02d|scores" % gi] = np.asarray(act_values, dtype=np.float32)
         out["g%02d|action" % gi] = np.asarray(action, dtype=np.int64)
-        for which in ("solve_mwis", "solve_mwis_dit", "solve_mwis_cit", "solve_mwis_cit_wrap", "solve_mwis_rollout",
+        for which in ("solve_mwis", "solve_mwis_dit", "solve_mwis_cit", "solve_mwis_cgs_train", "solve_mwis_cit_wrap", "solve_mwis_rollout",
                       "solve_mwis_rollout_wrap", "solve_mwis_rollout00", "solve_mwis_rollout0", "solve_mwis_rollout1"):
             fn = getattr(agent, which, None)
             if fn is None:
@@ -153,6 +154,87 @@ def worker_gdpg(out_path):
             out["g%02d|%s|set" % (gi, which)] = np.array(sorted(int(v) for v in sol), dtype=np.int64)
             out["g%02d|%s|total" % (gi, which)] = np.float64(np.asarray(total).ravel()[0])
     np.savez_compressed(out_path, **out)
+
+
+# ---- full-size cases (tests/golden/ref_exec_big.npz): where the float32 error tail lives and the C5 shape ----------
+BIG_OUT = os.path.join(ROOT, "tests", "golden", "ref_exec_big.npz")
+BIG_BA = [1320, 3945]       # graphs of datagen.ba_test2_batch (C4): N = 300, m = 2 - the two the round-2 review flagged
+BIG_BA_MODEL = ("result_DQNBA_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn", dict(feature_size=1, hidden1=32, num_layer=20, max_degree=1))
+BIG_C5 = dict(feature_size=1, hidden1=32, num_layer=20, max_degree=1, predict="mwis")  # + IS4SAT l=20 weights, ER G(500, 0.02), b = 16
+
+
+def datagen_graph(kind, index):
+    from distgcn_amd import datagen
+    hb = datagen.ba_test2_batch(1, first_index=index) if kind == "ba" else datagen.er_batch(1, 500, 0.02, first_index=index)
+    n = hb.num_nodes
+    adj = sp.csr_matrix((np.ones(hb.col_idx.size), hb.col_idx, hb.row_ptr), shape=(n, n))
+    return adj, hb.weights.copy()
+
+
+def worker_big_ba(model_dir, out_path):
+    """mwis_dqn_call.DQNAgent (DQNBA l=20) on BA N=300 m=2 graphs of the C4 batch: predict + solve_mwis."""
+    prepare_reference_imports()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import mwis_dqn_call as m
+        m.dqn_agent.load(os.path.join(REF, "model", model_dir))
+    out = {}
+    for gi in BIG_BA:
+        adj, w = datagen_graph("ba", gi)
+        state = m.dqn_agent.makestate(adj, w.reshape(-1, 1))
+        act_values, action = m.dqn_agent.predict(state)
+        sol, total, _ = m.dqn_agent.solve_mwis(adj, w, train=False)
+        out["ba%04d|scores" % gi] = np.asarray(act_values, dtype=np.float32)
+        out["ba%04d|action" % gi] = np.asarray(action, dtype=np.int64)
+        out["ba%04d|set" % gi] = np.array(sorted(int(v) for v in sol), dtype=np.int64)
+        out["ba%04d|total" % gi] = np.float64(total)
+    np.savez_compressed(out_path, **out)
+
+
+def worker_big_c5(out_path):
+    """mwis_gdpg_call.DQNAgent with 20 layers (the shipped IS4SAT l=20 weights copied into its variables, biases
+    left at their initial 0) on one ER G(500, 0.02) graph: predict, solve_mwis_rollout(b=16) (mwis_gdpg_call.py:596-659),
+    solve_mwis_cit and solve_mwis_cgs_train(train=False) (:778-839)."""
+    prepare_reference_imports()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import mwis_gdpg_call as m
+        agent = m.DQNAgent(m.FLAGS, 5000)
+    import tensorflow as tf
+    z = np.load(os.path.join(ROOT, "tests", "golden", "all_models.npz"))
+    pre = "result_IS4SAT_deep_ld1_c32_l20_cheb1_diver1_mwis_dqn|gcn_dqn/"
+    for v in tf._variables:
+        name = v.name[:-2] if v.name.endswith(":0") else v.name
+        for scope in ("model/gcn2_dqn/", "target/gcn2_dqn/"):
+            if name.startswith(scope) and pre + name[len(scope):] in z.files:
+                v.value_ = np.asarray(z[pre + name[len(scope):]], dtype=np.float32)
+    out = {}
+    for name, val in tf.shim_variables().items():
+        if name.startswith("model/"):
+            out["var|" + name] = np.asarray(val)
+    adj, w = datagen_graph("er", 0)
+    state = agent.makestate(adj, w.reshape(-1, 1))
+    act_values, action = agent.predict(state)
+    out["scores"] = np.asarray(act_values, dtype=np.float32)
+    out["action"] = np.asarray(action, dtype=np.int64)
+    for which, kw in (("solve_mwis", {}), ("solve_mwis_cit", {}), ("solve_mwis_cgs_train", {}), ("solve_mwis_rollout", dict(b=16))):
+        np.random.seed(1234)
+        sol, total = getattr(agent, which)(adj, w, train=False, **kw)
+        out["%s|set" % which] = np.array(sorted(int(v) for v in sol), dtype=np.int64)
+        out["%s|total" % which] = np.float64(np.asarray(total).ravel()[0])
+    np.savez_compressed(out_path, **out)
+
+
+def main_big():
+    out = {"ba_graphs": np.array(BIG_BA), "ba_model": np.array(BIG_BA_MODEL[0]), "c5_flags": np.array(json.dumps(BIG_C5))}
+    res = run_worker("big_ba", [BIG_BA_MODEL[0]], BIG_BA_MODEL[1])
+    out.update({"ba|" + k: v for k, v in res.items()})
+    print("big_ba ok (%d arrays)" % len(res))
+    res = run_worker("big_c5", [], BIG_C5)
+    out.update({"c5|" + k: v for k, v in res.items()})
+    print("big_c5 ok (%d arrays): rollout set of %d vertices, total %.6f" % (len(res), res["solve_mwis_rollout|set"].size, float(res["solve_mwis_rollout|total"])))
+    np.savez_compressed(BIG_OUT, **out)
+    print("%s: %d arrays, %d bytes" % (BIG_OUT, len(out), os.path.getsize(BIG_OUT)))
 
 
 def worker_test_loop(out_path):
@@ -230,10 +312,19 @@ def main():
         elif kind == "test_loop":
             sys.argv = [sys.argv[0]] + rest
             worker_test_loop(path)
+        elif kind == "big_ba":
+            model_dir = rest[0]
+            sys.argv = [sys.argv[0]] + rest[1:]
+            worker_big_ba(model_dir, path)
+        elif kind == "big_c5":
+            sys.argv = [sys.argv[0]] + rest
+            worker_big_c5(path)
         else:
             sys.argv = [sys.argv[0]] + rest
             worker_gdpg(path)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--big":
+        return main_big()
     out = {"dqn_models": np.array([m for m, _ in DQN_MODELS]), "graphs": np.array(GRAPHS), "gdpg_graphs": np.array(GDPG_GRAPHS),
            "dqn_flags": np.array([json.dumps(f) for _, f in DQN_MODELS]), "gdpg_flags": np.array([json.dumps(f) for f in GDPG_CONFIGS])}
     for model_dir, flags in DQN_MODELS:

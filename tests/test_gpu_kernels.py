@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-5
+from conftest import TOL, check_scores
 
 
 def _dev(engine, a):
@@ -169,8 +169,7 @@ def test_forward_golden_models(engine, golden, mode):
         for i, (n0, n1) in enumerate(hb.graph_slices()):
             f64 = golden.scores["g%02d|%s|f64" % (i, mname)]
             f32 = golden.scores["g%02d|%s|f32" % (i, mname)]
-            bar = max(TOL, 2.0 * np.abs(f32 - f64).max())
-            assert np.abs(got[n0:n1, 0] - f64).max() <= bar, (mname, golden.names[i])
+            check_scores(got[n0:n1, 0], f32, f64, (mname, golden.names[i]))
     assert ran == len(golden.model_names)
 
 
@@ -475,11 +474,8 @@ def test_every_shipped_checkpoint(engine, golden, all_models):
         e32 = e64 = e3264 = 0.0
         for gi, (n0, n1) in zip(all_models.graph_ids, hb.graph_slices()):
             f64, f32 = all_models.expect(gi, name, "f64"), all_models.expect(gi, name, "f32")
-            e32 = max(e32, float(np.abs(got[n0:n1] - f32).max()))
-            e64 = max(e64, float(np.abs(got[n0:n1] - f64).max()))
-            e3264 = max(e3264, float(np.abs(f32 - f64).max()))
-            assert np.abs(got[n0:n1] - f32).max() <= TOL, (name, gi)
-            assert np.abs(got[n0:n1] - f64).max() <= max(TOL, 2.0 * np.abs(f32 - f64).max()), (name, gi)
+            a32, a64, a3264 = check_scores(got[n0:n1], f32, f64, (name, gi))
+            e32, e64, e3264 = max(e32, a32), max(e64, a64), max(e3264, a3264)
             p, c, _ = golden.csr(gi)
             st, _ = orc.lgs_vectorised(p, c, prio[n0:n1])
             assert np.array_equal(state[n0:n1] == 1, st == 1), (name, gi)
@@ -487,7 +483,7 @@ def test_every_shipped_checkpoint(engine, golden, all_models):
             same_as_reference += set(np.flatnonzero(state[n0:n1] == 1)) == set(all_models.expect(gi, name, "set").tolist())
         table.append("%-62s %5s %12.3e %12.3e %12.3e" % (name, "fused" if mode else "layer", e32, e64, e3264))
     assert fused == 44  # every [I, L] stack: hidden width <= 32, or two layers with a wide first one (c48 / c64)
-    assert same_as_reference >= total - 2, (same_as_reference, total)
+    assert same_as_reference == total, (same_as_reference, total)
     table.append("sets equal to the reference's local_greedy_search on the restatement's priorities: %d of %d" % (same_as_reference, total))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -634,7 +630,7 @@ def test_layer_fused_with_next_transform(engine, golden):
         twin = ctwin.forward(lap, layers, hb.num_nodes, X=X)
         assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
         assert np.array_equal(got.view(np.uint32), twin.view(np.uint32))
-    # the launches really are fused: one "layer" launch per hidden layer boundary, no separate transform after the first
+    # the launches really are fused: one "layer" launch per hidden layer boundary from layer 1 on
     hb, layers, _ = cases[0]
     db = engine.upload(hb)
     dm = DeviceModel(layers, engine.device)
@@ -643,7 +639,9 @@ def test_layer_fused_with_next_transform(engine, golden):
     engine.forward(db, dm, mode=0)
     engine.torch.cuda.synchronize()
     engine.timing(False)
-    assert engine.timing_read("layer")[1] == 4 and engine.timing_read("transform")[1] == 1 and engine.timing_read("spmm")[1] == 1
+    # (layer 0's aggregation and layer 1's transform run apart - the two chains the contract carries in double - so a
+    # 5-layer stack is: transform 0, precise spmm 0, precise transform 1, fused launches for layers 1..3, spmm 4)
+    assert engine.timing_read("layer")[1] == 3 and engine.timing_read("transform")[1] == 2 and engine.timing_read("spmm")[1] == 2
 
 
 @pytest.mark.gpu

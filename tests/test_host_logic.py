@@ -289,3 +289,40 @@ def test_one_call_helper_checks_its_arguments_before_calling_anything():
         m.solve_lists(0, 0, 0, [np.arange(6, dtype=np.int32)[::2]], [ix], [w])  # not contiguous
     with pytest.raises(ValueError, match="more than 64"):
         m.solve_lists(0, 0, 0, [ip] * 65, [ix] * 65, None)
+
+
+def test_multichannel_conflict_graphs_match_the_reference(golden):
+    """wireless.multichannel_conflict_simulate / multichannel_conflict_graph against what the reference's own functions
+    returned (tests/golden/multichannel.npz: wireless_rollout_test_flood.py:70-95 and :98-133 cut out with ast and
+    executed by oracle/make_golden_multichannel.py): same per-channel graphs from the same np.random seed, same joint
+    graph on K * nn vertices (diagonal blocks + per-link cliques), entry for entry."""
+    import os
+    import scipy.sparse as sp
+    from conftest import GOLDEN
+    from distgcn_amd import wireless
+    z = np.load(os.path.join(GOLDEN, "multichannel.npz"))
+    for ci, (gi, k, p, seed) in enumerate(z["cases"]):
+        gi, k, seed = int(gi), int(k), int(seed)
+        adj = golden.scipy(gi)
+        np.random.seed(seed)
+        graphs = wireless.multichannel_conflict_simulate(adj, k, float(p), rng=np.random)
+        adj_list, adj_gk = wireless.multichannel_conflict_graph(graphs)
+        assert len(adj_list) == k
+        n = adj.shape[0]
+        for c, a in enumerate(adj_list):
+            a = sp.csr_matrix(a)
+            assert np.array_equal(a.indptr, z["c%d|ch%d|indptr" % (ci, c)]) and np.array_equal(a.indices, z["c%d|ch%d|indices" % (ci, c)])
+            assert np.array_equal(a.data, z["c%d|ch%d|data" % (ci, c)])
+            assert (a != a.T).nnz == 0 and a.diagonal().sum() == 0
+        assert adj_gk.shape == (k * n, k * n)
+        assert np.array_equal(adj_gk.indptr, z["c%d|joint|indptr" % ci]) and np.array_equal(adj_gk.indices, z["c%d|joint|indices" % ci])
+        assert np.array_equal(adj_gk.data, z["c%d|joint|data" % ci])
+        # structure: a link's K copies form a clique, block k is channel k's graph
+        dense = adj_gk.toarray()
+        for k1 in range(k):
+            assert np.array_equal(dense[k1 * n:(k1 + 1) * n, k1 * n:(k1 + 1) * n], adj_list[k1].toarray())
+            for k2 in range(k):
+                if k1 != k2:
+                    assert np.array_equal(dense[k1 * n:(k1 + 1) * n, k2 * n:(k2 + 1) * n], np.eye(n))
+    with pytest.raises(AssertionError):
+        wireless.multichannel_conflict_graph([golden.scipy(0), golden.scipy(2)])

@@ -9,7 +9,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "er"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nl = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 500
-hb = datagen.er_batch(B, 200, 0.1) if kind == "er" else datagen.ba_test2_batch(B)
+hb = (datagen.er_batch(B, int(kind[2:] or 200), 0.1) if kind.startswith("er") else datagen.ba_test2_batch(B))
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
 eng.timing(True)
 for _ in range(iters):

@@ -8,7 +8,7 @@ from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
 kind = sys.argv[1] if len(sys.argv) > 1 else "er"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nb_graphs = int(sys.argv[3]) if len(sys.argv) > 3 else 500
-hb = datagen.er_batch(nb_graphs, 200, 0.1) if kind == "er" else datagen.ba_test2_batch(nb_graphs)
+hb = (datagen.er_batch(nb_graphs, int(kind[2:] or 200), 0.1) if kind.startswith("er") else datagen.ba_test2_batch(nb_graphs))
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
 for _ in range(3): eng.solve(db, model, mode=MODE_FUSED)
 torch.cuda.synchronize()
