@@ -1,0 +1,125 @@
+"""Full-size parity report: a score vector (HIP or twin) against the oracle restatement, graph by graph.
+TEST / BENCH INFRASTRUCTURE ONLY - the checker, never the thing measured or shipped.
+
+For every graph of a batch: max |score - float32 restatement|, max |score - float64 restatement| and the float32
+restatement's own distance from float64 (oracle/ref_numpy.gcn_forward on the reference's makestate, one graph per call
+like the reference; errors in units of max(1, |score|), see tests/conftest.check_scores); the set the reference's local
+greedy search picks on the RESTATEMENT's priorities (ref_numpy.lgs_vectorised, pinned against the imported
+heuristics.local_greedy_search) against the given states; and SURVEY 7.3(c)'s margin count at delta = twice the
+measured error.  `full_size_configs()` names the BASELINE configurations (C2, C3, C4 at l=1 and l=20, a C5-sized batch).
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_numpy as orc  # noqa: E402
+
+
+def graph_report(indptr, indices, weights, layers, scores, state=None, predict="mwis", flavour="gdpg"):
+    """One graph -> dict(e32, e64, e3264, set_differs, risk_at_2e).  `state`: membership bytes (1 = member) to compare
+    with the reference search on the restatement's priorities; None: the search is run on `scores` here."""
+    n = int(weights.size)
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    st = orc.makestate(adj, weights.reshape(-1, 1), layers[0]["weights"][0].shape[0], len(layers[0]["weights"]) - 1, flavour, predict)
+    f32 = orc.gcn_forward(layers, st, np.float32)[0][:, 0]
+    f64 = orc.gcn_forward(layers, st, np.float64)[0][:, 0]
+    scores = np.asarray(scores, dtype=np.float32).ravel()
+    unit = np.maximum(1.0, np.abs(f64))
+    e32 = float((np.abs(scores.astype(np.float64) - f32) / unit).max()) if n else 0.0
+    e64 = float((np.abs(scores - f64) / unit).max()) if n else 0.0
+    e3264 = float((np.abs(f32.astype(np.float64) - f64) / unit).max()) if n else 0.0
+    pr_ref = orc.priority(f32, weights, predict)
+    ref_state, _ = orc.lgs_vectorised(indptr, indices, pr_ref)
+    pr_got = orc.priority(scores, weights, predict)
+    if state is None:
+        state, _ = orc.lgs_vectorised(indptr, indices, pr_got)
+    differs = not np.array_equal(np.asarray(state) == 1, ref_state == 1)
+    wabs = weights if predict == "mwis" else None
+    risk = orc.margin_risk(indptr, indices, pr_got, np.asarray(state), 2.0 * e32, wabs)
+    return {"e32": e32, "e64": e64, "e3264": e3264, "set_differs": bool(differs), "risk_at_2e": int(risk)}
+
+
+def batch_report(hb, layers, scores, state=None, predict="mwis", flavour="gdpg", graphs=None):
+    """Per-graph reports of a HostBatch (all graphs, or the listed ones)."""
+    out = []
+    slices = hb.graph_slices()
+    for g in (range(hb.num_graphs) if graphs is None else graphs):
+        n0, n1 = slices[g]
+        ip = hb.row_ptr[n0:n1 + 1].astype(np.int64) - int(hb.row_ptr[n0])
+        ix = hb.col_idx[hb.row_ptr[n0]:hb.row_ptr[n1]].astype(np.int64) - n0
+        out.append(graph_report(ip, ix, hb.weights[n0:n1], layers, scores[n0:n1], None if state is None else state[n0:n1],
+                                predict, flavour))
+    return out
+
+
+def summarize(reports):
+    e32 = np.array([r["e32"] for r in reports])
+    e64 = np.array([r["e64"] for r in reports])
+    e3264 = np.array([r["e3264"] for r in reports])
+    over = e32 > 1e-5
+    return {"graphs": len(reports),
+            "max_err_vs_f32_restatement": float(e32.max()), "graphs_over_1e-5_vs_f32_restatement": int(over.sum()),
+            "of_those_restatement_further_from_f64": int((over & (e3264 > e64)).sum()),
+            "max_err_vs_f64": float(e64.max()), "graphs_over_1e-5_vs_f64": int((e64 > 1e-5).sum()),
+            "restatement_max_err_vs_f64": float(e3264.max()),
+            "sets_differing": int(sum(r["set_differs"] for r in reports)),
+            "sets_differing_not_flagged_by_margin": int(sum(r["set_differs"] and r["risk_at_2e"] == 0 for r in reports)),
+            "graphs_at_margin_risk_at_2x_error": int(sum(r["risk_at_2e"] > 0 for r in reports))}
+
+
+# ---------------------------------------------------------------------------------------------- the BASELINE configurations
+def _model(name):
+    from distgcn_amd.gcn.models import layers_from_params
+    z = np.load(os.path.join(ROOT, "tests", "golden", "all_models.npz"))
+    pre = name + "|"
+    return layers_from_params({k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and "graphconvolution" in k})
+
+
+def full_size_configs():
+    """name -> (family, graphs, model fixture name, batch maker(count, first))."""
+    from distgcn_amd import datagen
+    m = "result_%s_deep_ld1_c32_l%d_cheb1_diver1_mwis_dqn"
+    return {
+        "C2": ("500 ER N=100 p=0.1, IS4SAT l=1", 500, m % ("IS4SAT", 1), lambda c, f: datagen.er_batch(c, 100, 0.1, first_index=f)),
+        "C3": ("500 ER N=200 p=0.1, IS4SAT l=20", 500, m % ("IS4SAT", 20), lambda c, f: datagen.er_batch(c, 200, 0.1, first_index=f)),
+        "C4-l1": ("4000 BA test2 mix, DQNBA l=1", 4000, m % ("DQNBA", 1), lambda c, f: datagen.ba_test2_batch(c, first_index=f)),
+        "C4-l20": ("4000 BA test2 mix, DQNBA l=20", 4000, m % ("DQNBA", 20), lambda c, f: datagen.ba_test2_batch(c, first_index=f)),
+        "C5-size": ("64 ER N=500 p=0.02, IS4SAT l=20", 64, m % ("IS4SAT", 20), lambda c, f: datagen.er_batch(c, 500, 0.02, first_index=f)),
+    }
+
+
+def _chunk(args):
+    """Worker: graphs [first, first + count) of a configuration through the C twin (bit-equal to the HIP kernels: the
+    -m gpu suite proves it on these very batches) and the report above."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    name, first, count = args
+    from oracle import ctwin
+    _, _, model, make = full_size_configs()[name]
+    layers = _model(model)
+    hb = make(count, first)
+    res = ctwin.solve(hb, layers)
+    return batch_report(hb, layers, res["scores"][:, 0], res["state"])
+
+
+def twin_report(name, procs=None, chunk=125):
+    """The whole configuration on the CPU twin, in forked workers -> (summary dict, per-graph reports)."""
+    _, total, _, _ = full_size_configs()[name]
+    jobs = [(name, f, min(chunk, total - f)) for f in range(0, total, chunk)]
+    procs = procs or min(len(jobs), max(1, (os.cpu_count() or 2) - 0), 8)
+    if procs <= 1:
+        parts = [_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_chunk, jobs)
+    reports = [r for p in parts for r in p]
+    return summarize(reports), reports
