@@ -58,7 +58,25 @@ def parse(argv=None):
                     help="also time the step issued alternately on two HIP streams (side figure; its overlapping launches would "
                          "blur a kernel trace of the run, so it is not part of the default command)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
-    return ap.parse_args(argv)
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5"], default=None,
+                    help="BASELINE.json configuration shortcuts: C2 = 500 ER N=100 l=1; C3 = 500 ER N=200 l=20 (the default line); "
+                         "C4 = the 4 000-graph BA batch over the ranks (--layers as given, default 20); C4-share = one GPU's 500 "
+                         "graphs of it; C5 = GCN-guided rollout (b=16) on 64 ER N=500 graphs")
+    ap.add_argument("--parity-seconds", type=float, default=25.0,
+                    help="budget of the full-size parity report against the oracle restatement (0 = skip)")
+    ap.add_argument("--beam", type=int, default=16, help="C5: rollout candidates per step")
+    args = ap.parse_args(argv)
+    if args.config == "C2":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "er", 500, 100, 0.1, 1
+    elif args.config == "C3":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "er", 500, 200, 0.1, 20
+    elif args.config == "C4":
+        args.family, args.graphs, args.scaling = "ba", 4000, "strong"
+    elif args.config == "C4-share":
+        args.family, args.graphs = "ba", 500
+    elif args.config == "C5":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "er", 64, 500, 0.02, 20
+    return args
 
 
 def load_layers(args):
@@ -158,9 +176,29 @@ def build_host_batch(args, rank, world):
         return datagen.er_batch(count, args.nodes, args.p, first_index=first)
     if args.scaling == "weak":
         return gen(args.graphs, rank * args.graphs), world * args.graphs
-    full = gen(args.graphs, 0)
-    lo, hi = parallel.shard_ranges(full, world)[rank]
-    return full.subset(lo, hi), args.graphs
+    if world == 1:
+        return gen(args.graphs, 0), args.graphs
+    # strong: the shard boundaries need every graph's size (sum(nnz + N)), not the graphs: sizes are cheap to know
+    # without generating (ER: drawn; BA: N and m fix the edge count), so each rank generates only its own range
+    lo, hi = parallel.shard_ranges_from_sizes(graph_sizes(args), world)[rank]
+    return gen(hi - lo, lo), args.graphs
+
+
+def graph_sizes(args):
+    """(vertices, directed entries) of every graph of the job's batch without building it.  BA(n, m) of
+    datagen.ba_graph has exactly m * (n - m) undirected edges (star seed on m + 1 vertices, then m per new vertex);
+    ER graphs are drawn (their edge count is random), which costs what generating them costs - only used for BA."""
+    from distgcn_amd import datagen
+    if args.family == "ba":
+        cells = [(n, d) for n in datagen.TEST2_SIZES for d in datagen.TEST2_DEGREES]
+        out = []
+        for g in range(args.graphs):
+            n, m = cells[g % len(cells)]
+            m = max(1, min(int(m), n - 1))
+            out.append((n, 2 * (m + m * (n - m - 1))))
+        return out
+    hb = datagen.er_batch(args.graphs, args.nodes, args.p)
+    return [(int(n1 - n0), int(hb.row_ptr[n1] - hb.row_ptr[n0])) for n0, n1 in hb.graph_slices()]
 
 
 class GpuWorkload:
@@ -494,18 +532,49 @@ def single_graph_probe(args, wl):
                     "place (several workgroups per graph on one XCD when the stack is deep enough), results written to pinned memory"}
 
 
-def margin_probe(wl):
+def parity_probe(wl, budget_s):
+    """Scores and sets of THIS run's batch, fetched from the GPU, against the oracle restatement graph by graph
+    (oracle/parity.py, the checker: float32 and float64 evaluations of the reference's formula, the reference's greedy
+    search on the restatement's priorities), for as many graphs as fit the time budget (all of C2 / C3)."""
+    from oracle import parity
+    eng, db, hb = wl.eng, wl.db, wl.hb
+    res = eng.solve_fused(db, wl.model, want_scores=True)
+    wl.sync()
+    scores = res["scores"].reshape(-1).cpu().numpy()
+    state = res["state"].cpu().numpy()
+    reports, t0, g = [], time.perf_counter(), 0
+    stride = 1
+    order = list(range(hb.num_graphs))
+    while g < len(order) and (time.perf_counter() - t0 < budget_s or g < 8):
+        reports += parity.batch_report(hb, wl.layers, scores, state, graphs=[order[g]])
+        g += stride
+    summ = parity.summarize(reports)
+    out = {"graphs_checked": len(reports), "of": hb.num_graphs, "seconds": round(time.perf_counter() - t0, 1),
+           "max_err": summ["max_err_vs_f32_restatement"], "graphs_over_1e-5": summ["graphs_over_1e-5_vs_f32_restatement"],
+           "of_those_restatement_further_from_f64": summ["of_those_restatement_further_from_f64"],
+           "max_err_vs_f64": summ["max_err_vs_f64"], "graphs_over_1e-5_vs_f64": summ["graphs_over_1e-5_vs_f64"],
+           "restatement_max_err_vs_f64": summ["restatement_max_err_vs_f64"], "sets_differing": summ["sets_differing"],
+           "against": "oracle/ref_numpy float32 / float64 restatements, one graph per call; sets: reference local_greedy_search on the "
+                      "float32 restatement's priorities; errors in units of max(1, |score|)",
+           "whole_configurations": "profiles/r03_parity_full_size.json (tests/test_full_size_parity.py: every graph of C2, C3, C4 l=1/l=20, C5-size)"}
+    return out
+
+
+def margin_probe(wl, measured_err=None):
     """how many of this batch's selected sets could a score error flip?  For delta = 2 x the score
-    tolerance (1e-5) and 2 x the error measured against the float32 restatement for this model
-    (profiles/r02_model_errors.txt: 1.4e-6), the number of graphs with at least one excluded vertex whose exclusion
+    tolerance (1e-5) and 2 x the error parity_probe just measured against the float32 restatement on this very batch,
+    the number of graphs with at least one excluded vertex whose exclusion
     does not survive a per-score error of delta (dgcn_margin_risk_batch); the others provably keep their set."""
     eng, db = wl.eng, wl.db
     res = eng.solve_fused(db, wl.model, want_scores=True)
     scores = res["scores"].reshape(-1)
     out = {"criterion": "excluded vertex v is safe iff a member neighbour u has p_u - p_v > delta*(|w_u|+|w_v|)", "graphs": wl.hb.num_graphs}
-    for name, delta in (("delta_2x_tolerance_2e-5", 2e-5), ("delta_2x_measured_error_2.8e-6", 2.8e-6)):
+    deltas = [("delta_2x_tolerance_2e-5", 2e-5)]
+    if measured_err is not None:  # twice what parity_probe measured against the float32 restatement on THIS batch
+        deltas.append(("delta_2x_measured_error", 2.0 * measured_err))
+    for name, delta in deltas:
         r = eng.margin_risk(db, res["state"], delta, scores=scores, weights=db.weights).cpu().numpy()
-        out[name] = {"graphs_at_risk": int((r > 0).sum()), "vertices_at_risk": int(r.sum())}
+        out[name] = {"delta": delta, "graphs_at_risk": int((r > 0).sum()), "vertices_at_risk": int(r.sum())}
     return out
 
 
@@ -642,9 +711,11 @@ def main(argv=None, workload_factory=None):
     if rank == 0 and world == 1 and not args.no_spmm_probe and isinstance(wl, GpuWorkload):  # N = 1 line only: ranks must not wait on it
         spmm_line = spmm_probe(args, wl, traffic_db)
 
-    margin = None
+    margin = parity_rep = None
     if rank == 0 and world == 1 and isinstance(wl, GpuWorkload) and wl.ring is not None:
-        margin = margin_probe(wl)
+        if args.parity_seconds > 0:
+            parity_rep = parity_probe(wl, args.parity_seconds)
+        margin = margin_probe(wl, parity_rep["max_err"] if parity_rep else None)
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e and isinstance(wl, GpuWorkload) and wl.ring is not None:
         e2e = e2e_probe(args, wl, res["state"].cpu().numpy())
@@ -683,6 +754,7 @@ def main(argv=None, workload_factory=None):
             "e2e": e2e,
             "single_graph": single,
             "two_streams": two,
+            "parity_full_size": parity_rep,
             "margin_risk": margin,
             "dist": dist_report,
             "roofline": roofline,

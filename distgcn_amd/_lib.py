@@ -25,7 +25,7 @@ FAULT_NAMES = {
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
-    "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
+    "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_set_cluster", "dgcn_get_cluster", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
     "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_host_solver_create", "dgcn_host_solver_destroy", "dgcn_host_solver_submit", "dgcn_host_solver_result",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
@@ -108,6 +108,10 @@ def load():
     lib.dgcn_spmm_batch.argtypes = [C.POINTER(DgcnCsr), vp, i32, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, vp]
     lib.dgcn_transform_batch.restype = C.c_int
     lib.dgcn_transform_batch.argtypes = [vp, i32, f32, i32, i32, vp, i32, vp, i32, vp]
+    lib.dgcn_set_cluster.restype = None
+    lib.dgcn_set_cluster.argtypes = [i32]
+    lib.dgcn_get_cluster.restype = i32
+    lib.dgcn_get_cluster.argtypes = []
     lib.dgcn_transform_f64acc_batch.restype = C.c_int
     lib.dgcn_transform_f64acc_batch.argtypes = [vp, i32, f32, i32, i32, vp, i32, vp, i32, vp]
     lib.dgcn_spmm_f64acc_batch.restype = C.c_int

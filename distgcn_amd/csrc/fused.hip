@@ -1617,27 +1617,66 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (a.greedy_mode != 2) {
             rounds = greedy_rounds<BLOCK>(key, st, 2, words, rs, re, vv, sub, lpv, mine, wflags, a.max_rounds, a.greedy_mode == 1);
         } else {
-            // candidates in GCN-priority order (stable argsort of -priority = the rank keys)
+            // candidates in GCN-priority order (stable argsort of -priority = the rank keys): candidate i is the vertex of
+            // rank i, so the list is one scatter
+            int* cid = reinterpret_cast<int*>(cand + 64);  // [64]
+            if (threadIdx.x < 64) cid[threadIdx.x] = -1;
+            __syncthreads();
+            if (tv < ng && gkey[tv] < (unsigned short)min(a.beam, 64)) cid[gkey[tv]] = tv;
+            __syncthreads();
             int nc = 0;
-            for (int i = 0; i < a.beam && i < 64; ++i) {
-                if (threadIdx.x == 0) pick[0] = -1;
-                __syncthreads();
-                if (tv < ng && gkey[tv] == (unsigned short)i) pick[0] = tv;
-                __syncthreads();
-                const int c = pick[0];
-                if (c < 0) break;  // fewer remaining vertices than candidates
-                ++nc;
-                // the residual graph minus the candidate's closed neighbourhood, ranked by weight
-                if (tv < ng) { key[tv] = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey[tv] : wkey[tv]; jn[tv] = 0; }
-                __syncthreads();
-                {
-                    const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
-                    for (int j = crs + tv; j < cre; j += BLOCK) key[words[j] >> 7] = (unsigned short)kDead;  // diagonal entry: c itself
+            while (nc < a.beam && nc < 64 && cid[nc] >= 0) ++nc;  // fewer remaining vertices than candidates: the list ends early
+            // The completions - for each candidate: the residual graph minus its closed neighbourhood, searched greedily by
+            // weight (or by priority), total weight of what joins - run CONCURRENTLY, one wave per candidate, each on its own
+            // rank array in LDS (bufA / bufB are free here) and without a single workgroup barrier.  A wave walks its instance's
+            // vertices in passes of 64 and lets a vertex join as soon as it beats all its live neighbours; removals by earlier
+            // passes are visible to later ones, which changes the number of rounds but not the result: the set the local
+            // greedy search returns is the unique independent set in which every excluded vertex has a member neighbour ahead
+            // of it in the order, whatever the schedule (heuristics.py:13-35 sweeps sequentially, :77-116 in synchronous
+            // rounds - same set).  (One after the other with the whole workgroup per candidate this was ~20 barriers x 16
+            // candidates = 120 of a step's 300 us at N = 500.)
+            {
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                constexpr int kWaves = BLOCK / 64;
+                unsigned short* kbase = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey : wkey;
+                // per-wave rank arrays behind everything the phase keeps in bufA (keys, states, pick, cand, cid)
+                unsigned short* kw0 = reinterpret_cast<unsigned short*>(cid + 64);
+                const int kstride = (a.max_nodes + 7) & ~7;
+                for (int i = wave; i < nc; i += kWaves) {
+                    unsigned short* kw = kw0 + (size_t)wave * kstride;
+                    const int c = cid[i];
+                    for (int v = lane; v < ng; v += 64) kw[v] = kbase[v];
+                    {
+                        const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
+                        for (int j = crs + lane; j < cre; j += 64) kw[words[j] >> 7] = (unsigned short)kDead;  // diagonal entry: c itself
+                    }
+                    double tot = 0.0;
+                    while (true) {
+                        bool any_live = false;
+                        for (int v0 = 0; v0 < ng; v0 += 64) {
+                            const int v = v0 + lane;
+                            const unsigned kv = v < ng ? (unsigned)kw[v] : kDead;
+                            const bool live = kv != kDead;
+                            unsigned m = kDead;
+                            const int vrs = live ? (int)(rinfo[v] & 0xffff) : 0, vre = live ? vrs + (int)(rinfo[v] >> 16) : 0;
+                            for (int j = vrs; j < vre; ++j) {
+                                const int u = words[j] >> 7;
+                                const unsigned ku = kw[u];
+                                if (u != v) m = min(m, ku);
+                            }
+                            const bool won = live && kv < m;
+                            if (won) {
+                                for (int j = vrs; j < vre; ++j) kw[words[j] >> 7] = (unsigned short)kDead;  // neighbours and itself
+                                tot += wl[v];
+                            }
+                            any_live |= live && !won;
+                        }
+                        if (!__any(any_live)) break;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                    if (lane == 0) cand[i] = wl[c] + tot;
                 }
-                __syncthreads();
-                greedy_rounds<BLOCK>(key, jn, 0, words, rs, re, vv, sub, lpv, mine, wflags, 0, false);
-                const double tot = block_sum<BLOCK>((tv < ng && jn[tv] == 1) ? wl[tv] : 0.0, red);
-                if (threadIdx.x == 0) cand[i] = wl[c] + tot;
             }
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -1977,6 +2016,24 @@ static bool fused_wants_order(const DgcnBatch* b) {
            (double)b->max_graph_edges * b->num_graphs > 1.25 * (double)b->num_edges;
 }
 
+// The variant's switch: the environment variable DGCN_FUSED_CLUSTER read ONCE (first use), afterwards only
+// dgcn_set_cluster() - called by the fault path of host_solver.hip and by the Python engine when a launch reports
+// DGCN_FAULT_CLUSTER - changes it.  (It used to be setenv() + getenv() per launch: a data race in glibc next to the
+// packing threads, and a mutation every child process inherited.)
+static std::atomic<int> g_cluster_setting{-2};  // -2: not read yet
+int cluster_setting() {
+    int v = g_cluster_setting.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("DGCN_FUSED_CLUSTER");
+        int fresh = e ? atoi(e) : -1;
+        if (fresh < -1) fresh = -1;
+        int expect = -2;
+        g_cluster_setting.compare_exchange_strong(expect, fresh, std::memory_order_relaxed);
+        v = g_cluster_setting.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
 // Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
 // (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
@@ -1988,8 +2045,8 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // every workgroup of every graph must be resident at once; two tiles per workgroup is as fine as it pays
     int K = min(min(8, device_cus() / max(gpad, 1)), (blocks + 1) / 2);
     bool forced = false;
-    if (const char* e = getenv("DGCN_FUSED_CLUSTER")) {
-        const int want = atoi(e);
+    const int want = cluster_setting();  // -1 automatic, 0 / 1 off, K forced
+    if (want >= 0) {
         if (want <= 1) return 0;
         K = min(8, want);
         forced = true;
@@ -2118,14 +2175,12 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         p += gpad * 16 * sizeof(int32_t);
         a->xz = reinterpret_cast<float*>(p);
         a->xs = a->xz + (size_t)b->num_graphs * 3 * a->max_nodes * kHid;
-        // a buffer this thread has not just used may hold anything: clear its progress words (what a previous launch of
-        // ours left there is harmless: older epochs)
-        static thread_local const void* last_flags = nullptr;
-        if (last_flags != a->xflag) {
-            if (hipMemsetAsync(a->xflag, 0, gpad * 16 * sizeof(int32_t), stream) != hipSuccess)
-                return fail(DGCN_ERR_LAUNCH, "%s: clearing the exchange flags failed", who);
-            last_flags = a->xflag;
-        }
+        // The workspace is the caller's: between two cluster launches anything may have written these bytes (a layered
+        // forward, an ordinary fused launch's records, a freed-and-reallocated buffer at the same address), and a stale word
+        // that happens to compare "not older than this epoch" would let a workgroup pull rows its peers have not marked yet.
+        // So the progress words and XCC slots are cleared on EVERY launch, in stream order (a few hundred bytes).
+        if (hipMemsetAsync(a->xflag, 0, gpad * 16 * sizeof(int32_t), stream) != hipSuccess)
+            return fail(DGCN_ERR_LAUNCH, "%s: clearing the exchange flags failed", who);
         static std::atomic<uint32_t> launches{1};
         a->epoch = (int32_t)(launches.fetch_add(1, std::memory_order_relaxed) << 6);  // 64 steps per launch; compared modulo 2^32
     }
@@ -2236,9 +2291,17 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     return fused_launch(args, b->num_graphs, lds, "fused_forward", s, false, gvals);
 }
 
+bool shallow_takes(const DgcnBatch* b, const DgcnModel* m);
+int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
+                  float x_const, const double* weights, int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds,
+                  double* totals, int32_t* status, const DoneHook& hook, hipStream_t s);
+
 }  // namespace dgcn
 
 using namespace dgcn;
+
+extern "C" void dgcn_set_cluster(int32_t setting) { g_cluster_setting.store(setting < -1 ? -1 : setting, std::memory_order_relaxed); }
+extern "C" int32_t dgcn_get_cluster(void) { return cluster_setting(); }
 
 extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m || !m->layers_host || m->num_supports != 2) return 0;
@@ -2262,6 +2325,10 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
     if (b->num_graphs <= 0) return DGCN_OK;
+    // one-layer models: the small dedicated kernel (shallow.hip) - same results, a fraction of the dependent chain
+    if (shallow_takes(b, m))
+        return shallow_solve(b, m, dinv_table, table_len, X, x_const, weights, predict_mwis, scores, state, rounds, totals, status, hook,
+                             (hipStream_t)stream);
     FusedArgs args = {};
     args.row_ptr = b->row_ptr;
     args.col_idx = b->col_idx;

@@ -341,7 +341,7 @@ int dgcn_host_solver_result(DgcnHostSolver* h, int32_t slot, const uint8_t** sta
         // The several-workgroups-per-graph variant of the fused kernel found its workgroups on different XCDs (a partition
         // mode with another dispatch order) or lost one: its results cannot be trusted.  Switch the variant off for the
         // rest of the process and solve the batch again - it is still where the packer put it.
-        setenv("DGCN_FUSED_CLUSTER", "0", 1);
+        dgcn_set_cluster(0);
         if (s.direct) *reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status) = 0;
         else if (hipMemsetAsync(static_cast<char*>(s.out_dev) + s.off_status, 0, 4, s.stream) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_result: clearing the status word failed");

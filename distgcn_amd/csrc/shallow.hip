@@ -1,0 +1,375 @@
+// One-layer models (F -> 1: the paper's headline "shallow GCN", README.md:14; BASELINE configs C1, C2, C4 at l = 1)
+// through dgcn_solve_batch: adjacency in, selected set out, ONE small workgroup per graph.
+//
+// k_fused serves these too, but it is built around a 32-wide LDS image (two 128-byte rows per vertex, entry records,
+// row ranking for the wave-lockstep gather) that a width-1 layer never uses, and its greedy phase first turns the
+// priorities into unique ranks - N^2 comparisons - which pays over 19 hidden layers and not here.  Measured on the
+// C2 batch (500 ER N=100 graphs), hundred-cycle phase clocks of k_fused: row pointers 39, entries 40, row order 15,
+// layer 46, priorities + ranks + rounds 175, tail 21 (profiles/r03_shallow_phase_clocks.txt) - the kernel is a chain of
+// dependent global / LDS round trips, not a bandwidth problem.  This kernel is that chain and nothing else:
+//
+//   1. row_ptr[v], row_ptr[v + 1], weight[v] (one round trip; graph_ptr and the model's 2-4 numbers are scalar loads)
+//   2. d^-1/2 table lookup by degree + the row's column ids, lpv lanes per row (second round trip)    -> LDS
+//   3. entry values (float)(-(dinv[u] * dinv[v])) by all lanes, then ONE lane per row runs the contract's chain:
+//      acc = fma((double)val_j, (double)z1[u_j], acc) over [diagonal, row entries in CSR order], score =
+//      act((float)((double)z0 + acc [+ bias]))                         (gcn/layers.py:202-216; layer index 0: double chain)
+//   4. priority (double)score * weight (mwis_dqn_call.py:232) into LDS, NaN check
+//   5. local greedy rounds DIRECTLY on the float64 priorities (heuristics.py:77-116): a live vertex loses to a live
+//      neighbour with (p_u > p_v) or (p_u == p_v and u < v); removed vertices hold NaN, which loses every comparison.
+//      No ranking pass.  lpv lanes share a vertex's neighbour list.
+//
+// Same arithmetic contract, same outputs, same fault bits as k_fused (tests compare both with the twin bit for bit).
+#include <atomic>
+
+#include "common.h"
+
+namespace dgcn {
+
+struct ShallowArgs {
+    const int32_t* graph_ptr;
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const double* dinv_table;
+    int32_t table_len;
+    const float* X;  // [num_nodes][cin] or null
+    float x_const;
+    int32_t cin;
+    const float* W;     // [cin][2]
+    const float* bias;  // [1] or null
+    int32_t act;
+    const double* weights;
+    int32_t predict_mwis;
+    float* scores;
+    uint8_t* state;
+    int32_t* rounds;
+    double* totals;
+    int32_t* status;
+    int32_t max_nodes;
+    int32_t cap;  // entry slots per graph in LDS
+    int32_t* done_flag;
+    uint32_t* done_count;
+    uint32_t done_target;
+    unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][8] phase clocks of thread 0 (s_memtime)
+};
+
+#ifdef DGCN_DIAG
+#define SH_STAMP(a, g, i, t0)                                                       \
+    do {                                                                            \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+        if ((a).stamps && threadIdx.x == 0) (a).stamps[(size_t)(g) * 8 + (i)] = _t - (t0); \
+        (t0) = _t;                                                                  \
+    } while (0)
+#else
+#define SH_STAMP(a, g, i, t0) do { } while (0)
+#endif
+
+template <int BLOCK>
+__device__ __forceinline__ bool sh_block_or(bool pred, unsigned* wflags) {
+    if constexpr (BLOCK == 64) return __ballot(pred) != 0ull;
+    const unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = m != 0ull;
+    __syncthreads();
+    unsigned any = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) any |= wflags[w];
+    return any != 0;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void sh_signal_done(const ShallowArgs& a) {
+    if (!a.done_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        const unsigned prev = atomicAdd(a.done_count, 1u);
+        if (prev + 1u == a.done_target) __hip_atomic_store(a.done_flag, (int32_t)a.done_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
+    const int g = blockIdx.x;
+    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
+    const int ng = n1 - n0;
+    double* dinv = reinterpret_cast<double*>(sh_raw);       // [max_nodes]
+    double* pr = dinv + a.max_nodes;                         // [max_nodes]
+    double* red = pr + a.max_nodes;                          // [BLOCK / 64] block-sum partials (+ pad to 16)
+    float* z1 = reinterpret_cast<float*>(red + 16);          // [max_nodes]
+    float* vals = z1 + a.max_nodes;                          // [cap]
+    unsigned* wflags = reinterpret_cast<unsigned*>(vals + a.cap);              // [16]
+    unsigned short* nbr = reinterpret_cast<unsigned short*>(wflags + 16);      // [cap] local neighbour ids
+    uint8_t* st = reinterpret_cast<uint8_t*>(nbr + a.cap);                     // [max_nodes]
+    if (ng <= 0) {
+        if (threadIdx.x == 0) {
+            if (a.rounds) a.rounds[g] = 0;
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        sh_signal_done<BLOCK>(a);
+        return;
+    }
+    // lanes per vertex: as many as the block affords (<= 8)
+    int lsh = 0;
+    while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
+    const int lpv = 1 << lsh;
+    const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
+    const bool mine = vv < ng;
+    int fault = 0;
+    unsigned long long tclk = 0;
+#ifdef DGCN_DIAG
+    tclk = __builtin_amdgcn_s_memtime();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)g * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    (void)tclk;
+    // ---- round trip 1: row bounds, weight, the model's numbers, this vertex's features
+    const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
+    int rs = 0, re = 0;
+    double w = 0.0;
+    if (mine) {
+        rs = a.row_ptr[n0 + vv];
+        re = a.row_ptr[n0 + vv + 1];
+        if (a.weights) w = a.weights[n0 + vv];
+    }
+    float z0 = 0.f, z1v = 0.f;
+    for (int k = 0; k < a.cin; ++k) {  // layer 0's transform: float32 fmaf chain over the input features
+        const float x = (a.X && mine) ? a.X[(size_t)(n0 + vv) * a.cin + k] : a.x_const;
+        z0 = fmaf(x, a.W[k * 2 + 0], z0);
+        z1v = fmaf(x, a.W[k * 2 + 1], z1v);
+    }
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    SH_STAMP(a, g, 0, tclk);
+    // ---- round trip 2: degree table + the graph's columns
+    const int deg = re - rs;
+    double dv = 0.0;
+    if (mine && sub == 0) {
+        if (deg < a.table_len) dv = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+    }
+    // the graph's column ids, cooperatively and coalesced (thread t takes entries t, t + BLOCK, ..: eight loads in flight), as
+    // 16-bit local ids; whose row an entry belongs to is not needed here (its position is its index)
+    const bool graph_fits = (e1 - e0) <= a.cap;  // (the host sized `cap` for the largest graph: always true for a sane batch)
+    const bool fits = mine && graph_fits;
+    if (!graph_fits) fault |= DGCN_FAULT_BAD_COLUMN;
+    if (graph_fits) {
+        const int total = e1 - e0;
+        for (int base = threadIdx.x; base < total; base += 8 * BLOCK) {
+            int c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = (base + i * BLOCK < total) ? a.col_idx[e0 + base + i * BLOCK] : n0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (base + i * BLOCK < total) {
+                    int u = c[i] - n0;
+                    if (u < 0 || u >= ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = 0xFFFF; }
+                    nbr[base + i * BLOCK] = (unsigned short)u;
+                }
+            }
+        }
+    }
+    SH_STAMP(a, g, 1, tclk);
+    if (mine && sub == 0) {
+        dinv[vv] = dv;
+        z1[vv] = z1v;
+        st[vv] = 0;
+    }
+    __syncthreads();
+    SH_STAMP(a, g, 2, tclk);
+    // ---- entry values by all lanes of the row, then the chain by its first lane (LDS operations of one wave complete in
+    // order and the lpv lanes of a row sit in one wave: no barrier between the writes and the reads)
+    const double dvv = mine ? dinv[vv] : 0.0;
+    if (fits) {
+        for (int j = rs + sub; j < re; j += lpv) {
+            const int u = nbr[j - e0];
+            if (u == vv) fault |= DGCN_FAULT_SELF_LOOP;
+            vals[j - e0] = u == 0xFFFF ? 0.f : (float)(-(dinv[u] * dvv));
+        }
+    }
+    float score = 0.f;
+    double p = 0.0;
+    int bad = 0;
+    if (mine && sub == 0) {
+        double acc = fma(1.0, (double)z1v, 0.0);  // the diagonal entry of L comes first
+        if (fits) {
+            int j = rs;
+            if (a.X) {
+                for (; j < re; ++j) {
+                    const int u = nbr[j - e0];
+                    acc = fma((double)vals[j - e0], (double)(u == 0xFFFF ? 0.f : z1[u]), acc);
+                }
+            } else {  // constant features: every z1[u] is this vertex's own z1
+                const double zd = (double)z1v;
+                for (; j + 4 <= re; j += 4) {
+                    const float v0 = vals[j - e0], v1 = vals[j + 1 - e0], v2 = vals[j + 2 - e0], v3 = vals[j + 3 - e0];
+                    acc = fma((double)v0, zd, acc);
+                    acc = fma((double)v1, zd, acc);
+                    acc = fma((double)v2, zd, acc);
+                    acc = fma((double)v3, zd, acc);
+                }
+                for (; j < re; ++j) acc = fma((double)vals[j - e0], zd, acc);
+            }
+        }
+        acc = (double)z0 + acc;
+        if (a.bias) acc += (double)bias;
+        score = apply_act((float)acc, a.act);
+        if (a.scores) a.scores[n0 + vv] = score;
+        p = (double)score;
+        if (a.predict_mwis && a.weights) p *= w;
+        bad = p != p;
+        pr[vv] = p;
+    }
+    const bool any_bad = sh_block_or<BLOCK>(bad != 0, wflags);
+    if (any_bad) {
+        if (threadIdx.x == 0) {
+            atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+            if (a.rounds) a.rounds[g] = -1;
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        if (mine && sub == 0) a.state[n0 + vv] = 0;
+        sh_signal_done<BLOCK>(a);
+        return;
+    }
+    __syncthreads();  // priorities are in LDS (and the flag words free again)
+    SH_STAMP(a, g, 3, tclk);
+    // ---- local greedy rounds on the priorities themselves
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    int rounds = 0;
+    bool member = false;
+    while (true) {
+        const double pv = mine ? pr[vv] : qnan;
+        const bool live = pv == pv;
+        bool lost = false;
+        if (live && fits) {
+            int j = rs + sub;
+            for (; j + 3 * lpv < re; j += 4 * lpv) {  // four independent id -> priority chains in flight
+                const int u0 = nbr[j - e0], u1 = nbr[j + lpv - e0], u2 = nbr[j + 2 * lpv - e0], u3 = nbr[j + 3 * lpv - e0];
+                const double p0 = u0 == 0xFFFF ? qnan : pr[u0], p1 = u1 == 0xFFFF ? qnan : pr[u1];
+                const double p2 = u2 == 0xFFFF ? qnan : pr[u2], p3 = u3 == 0xFFFF ? qnan : pr[u3];
+                lost |= (p0 > pv) | ((p0 == pv) & (u0 < vv));
+                lost |= (p1 > pv) | ((p1 == pv) & (u1 < vv));
+                lost |= (p2 > pv) | ((p2 == pv) & (u2 < vv));
+                lost |= (p3 > pv) | ((p3 == pv) & (u3 < vv));
+            }
+            for (; j < re; j += lpv) {
+                const int u = nbr[j - e0];
+                const double pu = u == 0xFFFF ? qnan : pr[u];
+                lost |= (pu > pv) | ((pu == pv) & (u < vv));
+            }
+        }
+        for (int off = 1; off < lpv; off <<= 1) lost |= (bool)__shfl_xor((int)lost, off);
+        const bool won = live && !lost;
+        if (!sh_block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every priority read before the removals below
+        ++rounds;
+        if (won) {
+            if (fits)
+                for (int j = rs + sub; j < re; j += lpv) {
+                    const int u = nbr[j - e0];
+                    if (u != 0xFFFF && u != vv) { pr[u] = qnan; st[u] = 2; }
+                }
+            if (sub == 0) { pr[vv] = qnan; member = true; }
+        }
+        __syncthreads();
+    }
+    SH_STAMP(a, g, 4, tclk);
+    if (mine && sub == 0) {
+        // (a winner's own byte is written after the loop: a neighbour can never have written 2 to it, since two adjacent
+        // vertices cannot both win a round)
+        a.state[n0 + vv] = member ? 1 : st[vv];
+    }
+    if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+    if (a.totals) {
+        // block-wide sum in a fixed order: shuffle tree inside a wave, then the wave partials in wave order
+        double part = (mine && sub == 0 && member) ? (a.weights ? w : p) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if constexpr (BLOCK > 64) {
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+            __syncthreads();
+            part = red[0];
+#pragma unroll
+            for (int wv = 1; wv < BLOCK / 64; ++wv) part += red[wv];
+        }
+        if (threadIdx.x == 0) a.totals[g] = part;
+    }
+    if (fault) atomicOr(a.status, fault);
+    sh_signal_done<BLOCK>(a);
+    SH_STAMP(a, g, 5, tclk);
+#ifdef DGCN_DIAG
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)g * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+static size_t shallow_lds(int max_nodes, int cap) {
+    return (size_t)max_nodes * (8 + 8 + 4 + 1) + 16 * 8 + 64 + (size_t)cap * 6 + 64;
+}
+
+// does this (batch, model) go through k_shallow?  One layer F -> 1 with two supports, graphs of <= 512 vertices whose
+// neighbour lists fit the LDS.  DGCN_SHALLOW=0 sends everything to k_fused (tests compare the two).
+bool shallow_takes(const DgcnBatch* b, const DgcnModel* m) {
+    if (const char* e = getenv("DGCN_SHALLOW")) if (atoi(e) == 0) return false;
+    if (!m->layers_host || m->num_layers != 1 || m->num_supports != 2) return false;
+    const DgcnLayer& L = m->layers_host[0];
+    if (L.out_dim != 1 || L.in_dim < 1 || L.in_dim > 64) return false;
+    if (b->max_nodes > 512) return false;
+    const int cap = (b->max_graph_edges + 7) & ~7;
+    return shallow_lds(max(b->max_nodes, 64), cap) <= 96 * 1024;
+}
+
+template <int BLOCK>
+static int shallow_launch_b(ShallowArgs& a, int B, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        static std::atomic<int> raised[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!raised[dev & 63].load(std::memory_order_relaxed)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shallow<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    96 * 1024) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "k_shallow: cannot reserve %zu bytes of LDS", lds);
+            raised[dev & 63].store(1, std::memory_order_relaxed);
+        }
+    }
+    TimedLaunch t("fused_solve", s);  // (the same timing family as k_fused: it is the same entry point's launch)
+    DGCN_LAUNCH(t, (k_shallow<BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
+    return check_launch("k_shallow");
+}
+
+int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
+                  float x_const, const double* weights, int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds,
+                  double* totals, int32_t* status, const DoneHook& hook, hipStream_t s) {
+    const DgcnLayer& L = m->layers_host[0];
+    ShallowArgs a = {};
+    a.graph_ptr = b->graph_ptr;
+    a.row_ptr = b->row_ptr;
+    a.col_idx = b->col_idx;
+    a.dinv_table = dinv_table;
+    a.table_len = table_len;
+    a.X = X;
+    a.x_const = x_const;
+    a.cin = L.in_dim;
+    a.W = L.weights;
+    a.bias = L.bias;
+    a.act = L.act;
+    a.weights = weights;
+    a.predict_mwis = predict_mwis;
+    a.scores = scores;
+    a.state = state;
+    a.rounds = rounds;
+    a.totals = totals;
+    a.status = status;
+    a.max_nodes = max(b->max_nodes, 64);
+    a.cap = (b->max_graph_edges + 7) & ~7;
+    a.done_flag = hook.flag;
+    a.done_count = hook.count;
+    a.done_target = hook.target;
+#ifdef DGCN_DIAG
+    a.stamps = getenv("DGCN_SHALLOW_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_SHALLOW_STAMPS"), nullptr, 0) : nullptr;
+#endif
+    const size_t lds = shallow_lds(a.max_nodes, a.cap);
+    // threads: a vertex per thread at least; small graphs get several lanes per vertex (<= 8) out of a 64..256-thread block
+    const int mn = b->max_nodes;
+    if (mn <= 16) return shallow_launch_b<64>(a, b->num_graphs, lds, s);
+    if (mn <= 64) return shallow_launch_b<128>(a, b->num_graphs, lds, s);
+    if (mn <= 128) return shallow_launch_b<256>(a, b->num_graphs, lds, s);
+    return shallow_launch_b<512>(a, b->num_graphs, lds, s);
+}
+
+}  // namespace dgcn

@@ -144,8 +144,7 @@ class Engine:
         if bits & 16:
             # the cluster variant of the fused kernel relies on a placement that this device / partition mode does not give:
             # switch it off for the rest of the process, so that a retry (and every later call) takes the ordinary launch
-            import os
-            os.environ["DGCN_FUSED_CLUSTER"] = "0"
+            _lib.load().dgcn_set_cluster(0)
         if bits:
             raise _lib.DgcnError("device-side validation failed: " + _lib.fault_text(bits))
 

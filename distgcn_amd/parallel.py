@@ -23,12 +23,19 @@ from .batch import HostBatch
 
 def shard_ranges(hb: HostBatch, world: int) -> List[Tuple[int, int]]:
     """Contiguous graph ranges [lo, hi) per rank, balanced on sum(nnz_g + N_g) (BA graphs vary 30x)."""
-    B = hb.num_graphs
-    if world <= 1:
-        return [(0, B)]
     sizes = np.diff(hb.graph_ptr).astype(np.int64)
     nnz = (hb.row_ptr[hb.graph_ptr[1:]] - hb.row_ptr[hb.graph_ptr[:-1]]).astype(np.int64)
-    cost = np.cumsum(sizes + nnz)
+    return shard_ranges_from_sizes(list(zip(sizes, nnz)), world)
+
+
+def shard_ranges_from_sizes(sizes_nnz, world: int) -> List[Tuple[int, int]]:
+    """The same cut from (vertices, entries) pairs alone: a rank that knows every graph's size can find its range
+    without holding the other ranks' graphs."""
+    B = len(sizes_nnz)
+    if world <= 1:
+        return [(0, B)]
+    arr = np.asarray(sizes_nnz, dtype=np.int64).reshape(B, 2)
+    cost = np.cumsum(arr[:, 0] + arr[:, 1])
     total = int(cost[-1]) if B else 0
     cuts = [0]
     for r in range(1, world):
@@ -87,6 +94,14 @@ def solve_sharded(hb: HostBatch, solve_fn: Callable[[HostBatch], Dict[str, np.nd
     return {"state": state, "totals": totals, "rounds": rounds}
 
 
+def _shape_probe(hb: HostBatch) -> HostBatch:
+    """A two-graph stand-in with the full batch's extreme shapes (its largest and its densest graph): what
+    ``dgcn_solve_supported`` looks at (max_nodes, max_graph_edges), identical on every rank."""
+    sizes = np.diff(hb.graph_ptr)
+    nnz = hb.row_ptr[hb.graph_ptr[1:]] - hb.row_ptr[hb.graph_ptr[:-1]]
+    return hb.select(sorted({int(np.argmax(sizes)), int(np.argmax(nnz))}))
+
+
 def solve_sharded_device(engine, model, hb: HostBatch, predict: str = "mwis", group=None) -> Dict[str, np.ndarray]:
     """``solve_sharded`` for the HIP engine without the host round trip: every rank uploads its shard, runs the ONE
     fused launch into a packed result buffer laid out for the largest shard (``Engine.solve_buffers(cap_*)``), the ranks
@@ -106,9 +121,12 @@ def solve_sharded_device(engine, model, hb: HostBatch, predict: str = "mwis", gr
     db = engine.upload(sub)
     dm = model if hasattr(model, "c") else model.device_model(engine)
     out = engine.solve_buffers(db, want_scores=False, cap_nodes=cap_nodes, cap_graphs=cap_graphs)
+    # Every rank decides on the shape of the WHOLE batch (largest graph, densest graph), which they all hold: a decision
+    # taken per shard could differ between ranks, and a rank that raised here would leave the others waiting in the
+    # collective below.
+    if hb.num_nodes and not engine.solve_supported(engine.upload(_shape_probe(hb)), dm):
+        raise _lib.DgcnError("solve_sharded_device: this model / batch shape is outside the fused kernel")
     if sub.num_nodes:
-        if not engine.solve_supported(db, dm):
-            raise _lib.DgcnError("solve_sharded_device: this model / batch shape is outside the fused kernel")
         engine.solve_fused(db, dm, predict=predict, want_scores=False, out=out)
     flat = out["flat"]
     if world > 1:

@@ -56,7 +56,10 @@ class _Slot:
             t = self.torch
             cap = (max(int(n * 1.25), 64), max(int(B * 1.25), 8))
             size, self.layout = packed_layout(solve_buffer_specs(cap[0], cap[1], want_scores))
-            self.out = t.zeros(size, dtype=t.uint8, device=self.device)
+            # zero-filled ON THE SLOT'S STREAM: everything that touches the buffer afterwards is enqueued there, and the
+            # stream is non-blocking - a fill on the current stream could land after (or in the middle of) the first solve
+            with t.cuda.stream(self.stream):
+                self.out = t.zeros(size, dtype=t.uint8, device=self.device)
             self.res = t.empty(size, dtype=t.uint8, pin_memory=True)
             self.res_np = self.res.numpy()
             self.cap = cap
@@ -121,7 +124,7 @@ class SolvePipeline:
             slot.dev[:total].copy_(slot.staging[:total], non_blocking=True)
             _lib.check(self.lib.dgcn_solve_batch(
                 C.byref(bc), C.byref(self.model.c), self.table.data_ptr(), int(self.table.numel()), None, self.x_const,
-                base + int(info.off_weights), 1 if self.predict == "mwis" else 0,
+                (base + int(info.off_weights)) if int(info.off_weights) >= 0 else None, 1 if self.predict == "mwis" else 0,
                 (ob + lay["scores"][0]) if self.want_scores else None, ob + lay["state"][0],
                 ob + lay["rounds"][0], ob + lay["totals"][0], ob + lay["status"][0], slot.ws.data_ptr(), need,
                 C.c_void_p(slot.stream.cuda_stream)), "dgcn_solve_batch")
@@ -171,6 +174,10 @@ class SolvePipeline:
         depth = len(self.slots)
         it = iter(batches)
         inflight = deque()
+        if depth < 2:  # one slot: nothing to overlap with - pack, launch, collect, batch by batch
+            for b in it:
+                yield self.result(self.submit(*b), copy)
+            return
         with ThreadPoolExecutor(max_workers=1) as ex:
             def start_pack():
                 b = next(it, None)

@@ -271,6 +271,11 @@ int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t pr
  * scores (float[num_nodes]), rounds, totals may be NULL.  weights NULL or predict_mwis = 0: the
  * priority is the score itself (mwis_dqn_call.py:234). */
 int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
+/* The several-workgroups-per-graph launch variant (small batches): -1 = chosen automatically (default), 0 = off,
+ * K >= 2 = forced.  Process-wide, atomic; initialised once from the environment variable DGCN_FUSED_CLUSTER.  The
+ * library's own recovery from DGCN_FAULT_CLUSTER calls dgcn_set_cluster(0). */
+void dgcn_set_cluster(int32_t setting);
+int32_t dgcn_get_cluster(void);
 /* Bytes of device scratch dgcn_solve_batch / dgcn_solve_residual_batch need for this batch.  Graphs whose
  * whole image fits the LDS need a token amount; larger ones (e.g. 500 vertices, 5 000 edges) keep their
  * entry values in this scratch (one float per entry slot) and only states + gather words in LDS. */

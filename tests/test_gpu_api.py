@@ -1009,11 +1009,9 @@ def test_native_host_solver(engine, golden):
     one.close()
     # A placement fault of the several-workgroups-per-graph kernel (injected: DGCN_FUSED_CLUSTER_INJECT_FAULT) is not the
     # caller's problem: the object switches the variant off for the process, solves the batch again and hands out that.
-    import ctypes
-    c_getenv = ctypes.CDLL(None).getenv
-    c_getenv.restype, c_getenv.argtypes = ctypes.c_char_p, [ctypes.c_char_p]
-    saved = os.environ.get("DGCN_FUSED_CLUSTER")
-    os.environ.pop("DGCN_FUSED_CLUSTER", None)
+    from distgcn_amd import _lib
+    lib = _lib.load()
+    initial = int(lib.dgcn_get_cluster())
     os.environ["DGCN_FUSED_CLUSTER_INJECT_FAULT"] = "1"
     try:
         for direct in ("0", None):
@@ -1021,22 +1019,17 @@ def test_native_host_solver(engine, golden):
                 os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
             else:
                 os.environ["DGCN_HOST_DIRECT_BYTES"] = direct
-            os.environ.pop("DGCN_FUSED_CLUSTER", None)
-            os.unsetenv("DGCN_FUSED_CLUSTER")  # (the library's setenv is invisible to os.environ)
+            lib.dgcn_set_cluster(-1)
             one = HostSolver(engine, dm, depth=1, want_scores=True)
             g = one.solve(*batches[1])  # one N = 200 graph, 20 layers: the cluster variant's case
-            assert c_getenv(b"DGCN_FUSED_CLUSTER") == b"0"
+            assert int(lib.dgcn_get_cluster()) == 0  # switched off process-wide by the library itself (an atomic, not setenv)
             assert np.array_equal(g["state"], refs[1]["state"]) and np.array_equal(g["rounds"], refs[1]["rounds"])
             assert np.array_equal(g["scores"].view(np.uint32), np.asarray(refs[1]["scores"], np.float32).ravel().view(np.uint32))
             one.close()
     finally:
         os.environ.pop("DGCN_FUSED_CLUSTER_INJECT_FAULT", None)
         os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
-        os.unsetenv("DGCN_FUSED_CLUSTER")
-        if saved is None:
-            os.environ.pop("DGCN_FUSED_CLUSTER", None)
-        else:
-            os.environ["DGCN_FUSED_CLUSTER"] = saved
+        lib.dgcn_set_cluster(initial)
 
 
 def _ref_exec():
@@ -1222,7 +1215,7 @@ def test_c4_full_batch_and_its_eight_shards(engine, golden):
 
 
 @pytest.mark.parametrize("which", ["dit", "cit", "rollout", "rollout1"])
-def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkeypatch):
+def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkeypatch, cluster_switch):
     """The residual-graph kernel also runs as several workgroups per graph (small batches of deep stacks): same sets and
     totals as with one workgroup per graph, for graphs that fill several tiles, a 12-layer stack, weight features."""
     from distgcn_amd import datagen
@@ -1234,10 +1227,7 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
     ws = [hb.weights[n0:n1] for n0, n1 in hb.graph_slices()]
     got = {}
     for mode in ("0", "8", None):
-        if mode is None:
-            monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
-        else:
-            monkeypatch.setenv("DGCN_FUSED_CLUSTER", mode)
+        cluster_switch(mode)
         got[mode] = agent.solve_iterative_batch(adjs, ws, which, b=8)
         assert got[mode] is not None
     for mode in ("8", None):

@@ -5,6 +5,8 @@ Bars: integer / index / byte outputs bit-exact; float32 scores bit-exact against
 (oracle/ref_numpy.py) - loosened to twice the float32 restatement's own distance from float64 on the
 few ill-conditioned fixture graphs where plain float32 arithmetic itself exceeds 1e-5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -646,7 +648,7 @@ def test_layer_fused_with_next_transform(engine, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layers_n", [2, 3, 20])
-def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch):
+def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch, cluster_switch):
     """k_fused<.., CLUSTER>: one graph on K workgroups that hand their Z1 rows round through L2 every layer
     (csrc/fused.hip, "cluster variant").  Forced on for K = 2, 3, 4, 8 over ragged small batches - graph sizes that do
     not fill the last tile, single-tile graphs, an empty graph, biases, both activations - and compared bit for bit with
@@ -674,10 +676,7 @@ def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch)
         db = engine.upload(hb)
         ref = None
         for force in ("0", "2", "3", "4", "8", None):
-            if force is None:
-                monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
-            else:
-                monkeypatch.setenv("DGCN_FUSED_CLUSTER", force)
+            cluster_switch(force)
             out = engine.solve_buffers(db, True)
             for _ in range(3):
                 engine.solve_fused(db, model, out=out, want_scores=True)
@@ -692,7 +691,7 @@ def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch)
 
 
 @pytest.mark.gpu
-def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch):
+def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch, cluster_switch):
     """The cluster variant's readers poll the exchange slices themselves (a chunk that still reads "unwritten" is not
     there yet), so what a previous launch - of any kind - left in the workspace must never look like data: every workgroup
     marks its rows at kernel start and the others wait for that once.  Alternate cluster launches of different batch
@@ -707,12 +706,12 @@ def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch
            for i, (b, n) in enumerate(shapes)]
     big = engine.upload(datagen.er_batch(300, 120, 0.1, first_index=990))  # far too many graphs to cluster: an ordinary launch
     refs = []
-    monkeypatch.setenv("DGCN_FUSED_CLUSTER", "0")
+    cluster_switch(0)
     for db in dbs:
         out = engine.solve_buffers(db, True)
         engine.solve_fused(db, model, out=out, want_scores=True)
         refs.append({k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")})
-    monkeypatch.delenv("DGCN_FUSED_CLUSTER", raising=False)
+    cluster_switch(None)
     for rep in range(4):
         for db, ref in zip(dbs, refs):
             out = engine.solve_buffers(db, True)
@@ -758,3 +757,74 @@ def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatc
         for order in ("1", None):
             for k in got["0"]:
                 assert np.array_equal(got["0"][k].view(np.uint8), got[order][k].view(np.uint8)), (layers_n, order, k)
+
+
+@pytest.mark.parametrize("case", ["ties", "features_bias", "ba", "n512", "c2"])
+def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
+    """One-layer models go through the small dedicated kernel (csrc/shallow.hip: no 32-wide image, greedy rounds on the
+    float64 priorities themselves instead of on ranks).  Against the twin bit for bit, and against k_fused forced on the
+    same batch (DGCN_SHALLOW=0): ties everywhere (weights from a handful of values), isolated vertices, 1-vertex and
+    empty graphs, explicit features with a bias and an activation (GCN2_DQN's last layer), the BA mix with hubs, 512-vertex
+    graphs, and the C2 batch itself with the trained weights."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    rng = np.random.default_rng(77)
+    X = None
+    if case == "ties":
+        ps, cs, ws = [], [], []
+        for i in range(150):
+            n = int(rng.integers(1, 71)) if i % 9 else 0
+            indptr, indices = datagen.er_graph(n, float(rng.choice([0.0, 0.05, 0.2, 0.6])), rng) if n else (np.zeros(1, np.int64), np.zeros(0, np.int64))
+            ps.append(indptr); cs.append(indices)
+            ws.append(rng.choice([0.25, 0.5, 0.5, 1.0, 2.0], size=n))
+        hb = HostBatch.from_csr_lists(ps, cs, ws)
+        layers = datagen.random_model(1, 32, seed=3)
+    elif case == "features_bias":
+        hb = datagen.er_batch(40, 90, 0.08)
+        layers = datagen.random_model(1, 32, feature_size=8, bias=True, last_act="leaky_relu", seed=4)
+        X = rng.random((hb.num_nodes, 8)).astype(np.float32)
+        X[rng.random(hb.num_nodes) < 0.1] = 0.0
+    elif case == "ba":
+        hb = datagen.ba_test2_batch(100)
+        layers = datagen.random_model(1, 32, seed=5)
+    elif case == "n512":
+        hb = datagen.er_batch(6, 512, 0.02)
+        layers = datagen.random_model(1, 32, bias=True, seed=6)
+    else:
+        hb = datagen.er_batch(500, 100, 0.1)
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models.npz"))
+        from distgcn_amd.gcn.models import layers_from_params
+        pre = "result_IS4SAT_deep_ld1_c32_l1_cheb1_diver1_mwis_dqn|"
+        layers = layers_from_params({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    Xd = None if X is None else _dev(engine, X)
+    if X is None:
+        ref = ctwin.solve(hb, layers)
+    else:
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        sc = ctwin.forward(lap, layers, hb.num_nodes, X=X)
+        ref = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, sc[:, 0].astype(np.float64) * hb.weights, sum_weights=hb.weights, want_stats=False)
+        ref["scores"] = sc
+    engine.timing(True)
+    got = engine.solve(db, dm, mode=1, X=Xd)
+    engine.torch.cuda.synchronize()
+    engine.timing(False)
+    engine.check_status(got["status"])
+    monkeypatch.setenv("DGCN_SHALLOW", "0")
+    old = engine.solve(db, dm, mode=1, X=Xd)
+    engine.check_status(old["status"])
+    monkeypatch.delenv("DGCN_SHALLOW")
+    for name, out in (("shallow", got), ("fused", old)):
+        assert np.array_equal(out["scores"].cpu().numpy().reshape(-1).view(np.uint32), ref["scores"][:, 0].view(np.uint32)), name
+        assert np.array_equal(out["state"].cpu().numpy(), ref["state"]), name
+        assert np.array_equal(out["rounds"].cpu().numpy(), ref["rounds"]), name
+        assert np.allclose(out["totals"].cpu().numpy(), ref["totals"], rtol=1e-12, atol=0), name
+    # a self-loop is reported, not looped on
+    bad = sp.csr_matrix(np.array([[1, 1, 0], [1, 0, 1], [0, 1, 0]], dtype=float))
+    hbb = HostBatch.from_scipy([bad], [np.ones(3)])
+    r = engine.solve(engine.upload(hbb), dm if X is None else DeviceModel(datagen.random_model(1, 32), engine.device), mode=1)
+    assert int(r["status"].cpu().numpy()[0]) & 1

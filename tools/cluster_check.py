@@ -13,9 +13,8 @@ for layers in ((20,) if len(sys.argv) > 1 else (20, 3, 2)):
         db = eng.upload(hb)
         res = {}
         for mode in ("0", "auto"):
-            if mode == "0": os.environ["DGCN_FUSED_CLUSTER"] = "0"
-            elif len(sys.argv) > 1: os.environ["DGCN_FUSED_CLUSTER"] = sys.argv[1]
-            else: os.environ.pop("DGCN_FUSED_CLUSTER", None)
+            # (the switch is an atomic inside the library, read from the environment once: set it through the C ABI)
+            eng.lib.dgcn_set_cluster(0 if mode == "0" else (int(sys.argv[1]) if len(sys.argv) > 1 else -1))
             out = eng.solve_buffers(db, True)
             for _ in range(20): eng.solve_fused(db, model, out=out, want_scores=True)
             torch.cuda.synchronize()

@@ -12,7 +12,7 @@ for B, n in ((1, 200), (16, 200), (4, 300), (8, 128)):
         model = DeviceModel(datagen.random_model(layers, 32), "cuda:0")
         r = {}
         for mode in ("0", "8"):
-            os.environ["DGCN_FUSED_CLUSTER"] = mode
+            eng.lib.dgcn_set_cluster(int(mode))
             out = eng.solve_buffers(db, False)
             for _ in range(30): eng.solve_fused(db, model, out=out)
             torch.cuda.synchronize(); eng.timing(True)
