@@ -37,8 +37,8 @@ F32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500, help="timed steps (default: ~0.3 s of timed region on C3)")
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1500: ~0.3 s of timed region on C3; C5: 20 complete searches)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; C5: 2)")
     ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU (weak scaling) or in the whole job (strong)")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--p", type=float, default=0.1)
@@ -76,6 +76,10 @@ def parse(argv=None):
         args.family, args.graphs = "ba", 500
     elif args.config == "C5":
         args.family, args.graphs, args.nodes, args.p, args.layers = "er", 64, 500, 0.02, 20
+    if args.steps is None:
+        args.steps = 20 if args.config == "C5" else 1500
+    if args.warmup is None:
+        args.warmup = 2 if args.config == "C5" else 20
     return args
 
 
@@ -276,6 +280,111 @@ class GpuWorkload:
             if n:
                 fam_ms[fam] = (ms, n)
         return fam_ms
+
+
+class RolloutWorkload:
+    """BASELINE config 5: GCN-guided rollout search (mwis_gdpg_call.py:596-659, b candidates per step) on N = 500 conflict
+    graphs, every graph of the batch advanced by the same launches (dgcn_solve_residual_batch, greedy_mode 2).  One step
+    of the benchmark = the COMPLETE search of the batch: ~ (set size) launches, each a 20-layer forward on the residual
+    graphs + b greedy completions + the pick, all on the device; the host reads a progress word per group of launches."""
+
+    def __init__(self, args, rank, world, local):
+        import torch
+        from distgcn_amd import datagen
+        from distgcn_amd.engine import Engine
+        from distgcn_amd.mwis_gdpg_call import DQNAgent
+        from distgcn_amd.runtime_config import FLAGS
+        self.torch, self.args = torch, args
+        self.dev = "cuda:%d" % local
+        torch.cuda.set_device(local)
+        self.hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
+        self.job_graphs = world * args.graphs
+        self.layers, self.weights_note = load_layers(args)
+        self.eng = Engine(self.dev)
+        self.db = self.eng.upload(self.hb)
+        flags = FLAGS.copy(feature_size=1, hidden1=args.hidden, num_layer=args.layers, diver_num=1, max_degree=1, predict="mwis")
+        self.agent = DQNAgent(flags, seed=3)
+        for lyr_dst, lyr_src in zip(self.agent.model.layers, self.layers):  # GCN2_DQN (activation on the last layer) with the trained weights
+            lyr_dst["weights"] = lyr_src["weights"]
+        for lyr in self.agent.model.layers:
+            lyr["bias"] = None
+        self.layers = self.agent.model.layers
+        from distgcn_amd.engine import DeviceModel
+        self.model = DeviceModel(self.layers, self.dev)
+        self.ring = None
+        self.mode_name = "residual-graph rollout (device-resident)"
+        self.settle_s = 0.0
+        self.launches = 0
+        self.out = self.eng.solve_buffers(self.db, False)
+        self.state = torch.zeros(self.hb.num_nodes, dtype=torch.uint8, device=self.dev)
+
+    def collective_device(self):
+        return self.dev
+
+    def make_buffers(self, cap_nodes, cap_graphs):
+        pass
+
+    def step(self):
+        self.state.zero_()
+        res = self.eng.solve_residual(self.db, self.model, self.state, greedy=self.eng.GREEDY_ROLLOUT, max_rounds=1,
+                                      beam=self.args.beam, out=self.out)
+        self.launches = res["steps"]
+        return {"status": res["status"], "state": res["state"], "flat": res["state"], "layout": None}
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def check(self, res):
+        self.eng.check_status(res["status"])
+
+    def timing(self, on):
+        self.eng.timing(on)
+
+    def kernel_times(self):
+        ms, n = self.eng.timing_read("fused_residual")
+        return {"fused_residual": (ms, n)} if n else {}
+
+    def residual_bytes(self):
+        """SURVEY 8d's layer-by-layer bytes of every launch of one search, from the residual graphs' actual sizes:
+        the search replayed one launch at a time (untimed), the state read back after each."""
+        hb, eng, t = self.hb, self.eng, self.torch
+        rows = np.repeat(np.arange(hb.num_nodes), np.diff(hb.row_ptr))
+        gid = np.repeat(np.arange(hb.num_graphs), np.diff(hb.graph_ptr))
+        state = t.zeros(hb.num_nodes, dtype=t.uint8, device=self.dev)
+        total, launches = 0.0, 0
+        while True:
+            alive = state.cpu().numpy() == 0
+            if not alive.any():
+                break
+            n_res = int(alive.sum())
+            nnz_res = int((alive[rows] & alive[hb.col_idx]).sum())
+            graphs_res = int(np.unique(gid[alive]).size)
+            csr = (nnz_res + n_res) * 8 + (n_res + graphs_res) * 4
+            for lyr in self.layers:
+                total += csr + 2 * 4 * lyr["weights"][0].shape[1] * n_res
+            eng.solve_residual(self.db, self.model, state, greedy=eng.GREEDY_ROLLOUT, max_rounds=1, beam=self.args.beam,
+                               out=self.out, max_steps=1)
+            launches += 1
+            if launches > hb.max_nodes + 2:
+                break
+        return total, launches
+
+
+def c5_cpu_baseline(wl, budget_s):
+    """The oracle's rollout (oracle/ref_numpy.solve_mwis_rollout: NumPy forward on the re-sliced residual graph + b
+    Python greedy completions per step, like the reference) on the first graph(s) of the batch, one core."""
+    from oracle import ref_numpy as orc
+    hb = wl.hb
+    fn = orc._default_scores_fn(wl.layers, 1, 1, "mwis")
+    done, t0 = 0, time.perf_counter()
+    while done < hb.num_graphs and (done == 0 or time.perf_counter() - t0 < budget_s):
+        n0, n1 = hb.graph_slices()[done]
+        orc.solve_mwis_rollout(fn, hb.scipy_graph(done), hb.weights[n0:n1], b=wl.args.beam, predict="mwis")
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "graphs/s", "cores": 1, "kind": "port",
+            "sample": "%d complete rollout searches (b=%d) over the first graphs of rank 0's batch, %.1f s, python "
+                      "oracle/ref_numpy.solve_mwis_rollout" % (done, wl.args.beam, dt), "host_cpus": os.cpu_count()}
 
 
 def decode_flat(flat_host, layout, num_nodes, num_graphs):
@@ -615,7 +724,9 @@ def main(argv=None, workload_factory=None):
         os.environ.setdefault("WORLD_SIZE", "1")
         parallel.init_rank_group(args.backend)
 
-    wl = (workload_factory or GpuWorkload)(args, rank, world, local)
+    if args.config == "C5":
+        args.no_gather = True  # (the searches' sets stay on their ranks: nothing of C5 is gathered per launch)
+    wl = (workload_factory or (RolloutWorkload if args.config == "C5" else GpuWorkload))(args, rank, world, local)
     hb = wl.hb
     cdev = wl.collective_device()
 
@@ -654,7 +765,7 @@ def main(argv=None, workload_factory=None):
         while pending:
             pending.pop(0)[0].wait()
 
-    if hasattr(wl, "settle"):
+    if hasattr(wl, "settle") and args.config != "C5":
         wl.settle()
     res = None
     for _ in range(args.warmup):
@@ -705,7 +816,20 @@ def main(argv=None, workload_factory=None):
                 "content": "state[uint8 per vertex] + totals[f64 per graph] + rounds[i32 per graph] + status[i32]"}
 
     fam_ms = wl.kernel_times()
-    roofline, kernel_us, traffic_db = roofline_objects(args, wl, fam_ms)
+    if isinstance(wl, RolloutWorkload):
+        ms, n = fam_ms.get("fused_residual", (0.0, 0))
+        algo, launches = wl.residual_bytes() if rank == 0 else (0.0, 1)
+        avg_s = ms / max(n, 1) * 1e-3
+        ach = (algo / max(launches, 1)) / avg_s / 1e9 if avg_s > 0 else None
+        roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_search": launches,
+                    "algorithmic_bytes_per_launch": algo / max(launches, 1),
+                    "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's launches"}
+        kernel_us = {"fused_residual": {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)}}
+        traffic_db = {}
+    else:
+        roofline, kernel_us, traffic_db = roofline_objects(args, wl, fam_ms)
 
     spmm_line = None
     if rank == 0 and world == 1 and not args.no_spmm_probe and isinstance(wl, GpuWorkload):  # N = 1 line only: ranks must not wait on it
@@ -761,7 +885,12 @@ def main(argv=None, workload_factory=None):
             "spmm_kernel_roofline": spmm_line,
             "kernels": kernel_us,
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and isinstance(wl, RolloutWorkload):
+            out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on ER N=%d p=%g" % (args.beam, args.nodes, args.p)
+            out["config"]["workload"] = ("C5: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per step of the search, "
+                                         "~%d launches per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
+            out["cpu_baseline"] = c5_cpu_baseline(wl, args.cpu_seconds)
+        elif world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(hb, wl.layers, args.cpu_seconds)
             if not args.no_cpu_pool and args.family == "er":
                 out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args, min(args.cpu_seconds, 6.0))

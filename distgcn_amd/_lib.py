@@ -25,7 +25,7 @@ FAULT_NAMES = {
 
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
-    "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_set_cluster", "dgcn_get_cluster", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
+    "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_pack_compact_layout", "dgcn_pack_compact_batch", "dgcn_expand_compact_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_set_cluster", "dgcn_get_cluster", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
     "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_host_solver_create", "dgcn_host_solver_destroy", "dgcn_host_solver_submit", "dgcn_host_solver_result",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
@@ -68,6 +68,11 @@ class DgcnPackInfo(C.Structure):
                 ("off_row_ptr", C.c_int64), ("off_col_idx", C.c_int64), ("off_weights", C.c_int64), ("total_bytes", C.c_int64)]
 
 
+class DgcnCompactInfo(C.Structure):
+    _fields_ = [("off_graph_ptr", C.c_int64), ("off_up_ptr", C.c_int64), ("off_updeg", C.c_int64), ("off_upcol", C.c_int64),
+                ("off_weights", C.c_int64), ("total_bytes", C.c_int64)]
+
+
 _lib = None
 
 
@@ -93,6 +98,12 @@ def load():
     lib.dgcn_pack_measure.argtypes = [vp, vp, i32, i32, i32, C.POINTER(DgcnPackInfo), vp]
     lib.dgcn_pack_batch.restype = C.c_int
     lib.dgcn_pack_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, sz, C.POINTER(DgcnPackInfo), i32]
+    lib.dgcn_pack_compact_layout.restype = C.c_int
+    lib.dgcn_pack_compact_layout.argtypes = [C.POINTER(DgcnPackInfo), C.POINTER(DgcnCompactInfo)]
+    lib.dgcn_pack_compact_batch.restype = C.c_int
+    lib.dgcn_pack_compact_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp, sz, C.POINTER(DgcnPackInfo), C.POINTER(DgcnCompactInfo), i32]
+    lib.dgcn_expand_compact_batch.restype = C.c_int
+    lib.dgcn_expand_compact_batch.argtypes = [vp, C.POINTER(DgcnCompactInfo), i32, i32, i32, vp, vp, vp]
     lib.dgcn_supports_batch.restype = C.c_int
     lib.dgcn_supports_batch.argtypes = [C.POINTER(DgcnBatch), vp, i32, vp, vp, vp, vp, vp]
     lib.dgcn_supports2_count_batch.restype = C.c_int

@@ -12,6 +12,7 @@
 // with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
 // consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
 // DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,8 @@ struct DgcnHostSolver {
         void* in_host_dev = nullptr;  // the same bytes as the device addresses them (small batches are read in place)
         void* in_dev = nullptr;
         size_t in_cap = 0;
+        void* exp_dev = nullptr;  // compact transfers: the expanded row_ptr | col_idx (expand.hip)
+        size_t exp_cap = 0;
         void* out_host = nullptr;  // pinned: totals | rounds | status | state
         void* out_host_dev = nullptr;
         void* out_dev = nullptr;
@@ -130,6 +133,18 @@ static int ensure_out(DgcnHostSolver::Slot& s, int nodes, int graphs, bool want_
     return DGCN_OK;
 }
 
+static int ensure_exp(DgcnHostSolver::Slot& s, size_t bytes) {
+    if (bytes <= s.exp_cap) return DGCN_OK;
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.exp_dev) (void)hipFree(s.exp_dev);
+    s.exp_dev = nullptr;
+    s.exp_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&s.exp_dev, cap) != hipSuccess) return fail(DGCN_ERR_WORKSPACE, "dgcn_host_solver: cannot allocate %zu bytes for the expanded batch", cap);
+    s.exp_cap = cap;
+    return DGCN_OK;
+}
+
 static int ensure_ws(DgcnHostSolver::Slot& s, size_t bytes) {
     if (bytes <= s.ws_cap) return DGCN_OK;
     if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -226,6 +241,7 @@ void dgcn_host_solver_destroy(DgcnHostSolver* h) {
         free_in(s);
         free_out(s);
         if (s.ws) (void)hipFree(s.ws);
+        if (s.exp_dev) (void)hipFree(s.exp_dev);
         if (s.done_count) (void)hipFree(s.done_count);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.copied) (void)hipEventDestroy(s.copied);
@@ -252,12 +268,6 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     if (h->lgs_only && !weights_host) return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: the greedy search needs weights");
     int threads = h->pack_threads;
     if (threads <= 0) threads = 8;
-    rc = pack_batch(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, s.in_host, s.in_cap, &info,
-                    threads, h->lgs_only);
-    if (rc) return rc;
-    if (!h->lgs_only && info.max_degree >= h->table_len)
-        return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: vertex degree %d beyond the d^-1/2 table (%d entries)", info.max_degree,
-                    h->table_len);
     // A batch of up to a few dozen graphs: the kernel reads it where the packer left it and writes its results where the
     // caller reads them (pinned memory is device-addressable) - two copy commands and the gaps around them cost more
     // than PCIe round trips inside the kernel (tools/direct_probe.py: 101 vs 110 us for one N = 200 graph, 150 vs 170 us
@@ -265,6 +275,27 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     const char* direct_env = getenv("DGCN_HOST_DIRECT_BYTES");
     const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(2 << 20);
     const bool direct = (size_t)info.total_bytes <= direct_bytes;
+    // Larger batches cross PCIe in the compact form when they can (symmetric graphs with sorted rows, <= 512 vertices:
+    // upper triangle, 16-bit ids - a third of the bytes) and are expanded on the device (expand.hip); anything else, and
+    // every batch when DGCN_HOST_COMPACT=0, goes as the ordinary block-diagonal CSR.
+    const char* compact_env = getenv("DGCN_HOST_COMPACT");
+    const bool compact_ok = !compact_env || atoi(compact_env) != 0;
+    DgcnCompactInfo ci = {};
+    bool compact = false;
+    if (!direct && compact_ok && info.max_nodes <= 512 && info.num_nodes > 0 && compact_layout(&info, &ci) == 0) {
+        rc = pack_compact(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, s.in_host, s.in_cap, &info, &ci,
+                          threads);
+        if (rc < 0) return rc;
+        compact = rc == 0;
+    }
+    if (!compact) {
+        rc = pack_batch(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, s.in_host, s.in_cap, &info,
+                        threads, h->lgs_only);
+        if (rc) return rc;
+    }
+    if (!h->lgs_only && info.max_degree >= h->table_len)
+        return fail(DGCN_ERR_ARG, "dgcn_host_solver_submit: vertex degree %d beyond the d^-1/2 table (%d entries)", info.max_degree,
+                    h->table_len);
     char* base = static_cast<char*>(direct ? s.in_host_dev : s.in_dev);
     DgcnBatch b;
     b.num_graphs = info.num_graphs;
@@ -272,9 +303,18 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     b.num_edges = info.num_edges;
     b.max_nodes = info.max_nodes;
     b.max_graph_edges = info.max_graph_edges;
-    b.graph_ptr = reinterpret_cast<const int32_t*>(base + info.off_graph_ptr);
-    b.row_ptr = reinterpret_cast<const int32_t*>(base + info.off_row_ptr);
-    b.col_idx = reinterpret_cast<const int32_t*>(base + info.off_col_idx);
+    size_t exp_col_off = 0;
+    if (compact) {
+        exp_col_off = align16(((size_t)info.num_nodes + 1) * 4);
+        if ((rc = ensure_exp(s, exp_col_off + align16((size_t)std::max(info.num_edges, 1) * 4)))) return rc;
+        b.graph_ptr = reinterpret_cast<const int32_t*>(base + ci.off_graph_ptr);
+        b.row_ptr = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev));
+        b.col_idx = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off);
+    } else {
+        b.graph_ptr = reinterpret_cast<const int32_t*>(base + info.off_graph_ptr);
+        b.row_ptr = reinterpret_cast<const int32_t*>(base + info.off_row_ptr);
+        b.col_idx = reinterpret_cast<const int32_t*>(base + info.off_col_idx);
+    }
     if (!h->lgs_only && !dgcn_solve_supported(&b, &h->model))
         return fail(DGCN_ERR_UNSUPPORTED, "dgcn_host_solver_submit: this model / batch shape is outside the fused kernel");
     if ((rc = ensure_out(s, info.num_nodes, info.num_graphs, h->want_scores != 0))) return rc;
@@ -286,8 +326,9 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     s.num_graphs = info.num_graphs;
     s.direct = direct;
     s.batch = b;
-    s.off_weights = info.off_weights;
+    s.off_weights = compact ? ci.off_weights : info.off_weights;
     s.done_total = 0;
+    const size_t copy_bytes = compact ? (size_t)ci.total_bytes : (size_t)info.total_bytes;
     if (info.num_graphs > 0 && info.num_nodes > 0) {
         if (direct) {
             int32_t* st = reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status);
@@ -300,12 +341,16 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
                 st[2] = 0;
             }
         } else if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
-            if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
+            if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
-        } else if (hipMemcpyAsync(s.in_dev, s.in_host, (size_t)info.total_bytes, hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
+        } else if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
                    hipEventRecord(s.copied, h->copy_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess) {
             return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
         }
+        if (compact && (rc = expand_compact(s.in_dev, &ci, info.num_graphs, info.num_nodes, info.max_nodes,
+                                            static_cast<int32_t*>(s.exp_dev), reinterpret_cast<int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off),
+                                            s.stream)))
+            return rc;
         if ((rc = launch_slot(h, s))) return rc;
     } else {  // nothing to launch: graphs without vertices have total 0 after 0 rounds
         std::memset(s.out_host, 0, s.off_state);

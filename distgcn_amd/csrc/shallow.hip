@@ -93,14 +93,17 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int ng = n1 - n0;
-    double* dinv = reinterpret_cast<double*>(sh_raw);       // [max_nodes]
-    double* pr = dinv + a.max_nodes;                         // [max_nodes]
-    double* red = pr + a.max_nodes;                          // [BLOCK / 64] block-sum partials (+ pad to 16)
-    float* z1 = reinterpret_cast<float*>(red + 16);          // [max_nodes]
-    float* vals = z1 + a.max_nodes;                          // [cap]
-    unsigned* wflags = reinterpret_cast<unsigned*>(vals + a.cap);              // [16]
-    unsigned short* nbr = reinterpret_cast<unsigned short*>(wflags + 16);      // [cap] local neighbour ids
-    uint8_t* st = reinterpret_cast<uint8_t*>(nbr + a.cap);                     // [max_nodes]
+    // (slot max_nodes of dinv / pr / kr is a vertex nobody owns: d^-1/2 = 0, priority NaN - a lane's unused neighbour slots
+    // point there, so the unrolled loops below need no bounds tests)
+    const int mn1 = a.max_nodes + 1;
+    double* dinv = reinterpret_cast<double*>(sh_raw);       // [max_nodes + 1]
+    double* pr = dinv + mn1;                                 // [max_nodes + 1]
+    double* red = pr + mn1;                                  // [16] block-sum partials
+    float* z1 = reinterpret_cast<float*>(red + 16);          // [max_nodes + 1]
+    float* vals = z1 + mn1;                                  // [cap]
+    unsigned* wflags = reinterpret_cast<unsigned*>(vals + a.cap);              // [2][16] round votes, [32] NaN flag
+    unsigned short* nbr = reinterpret_cast<unsigned short*>(wflags + 48);      // [cap] local neighbour ids
+    unsigned short* kr = nbr + a.cap;                                          // [max_nodes + 1] round a vertex left in (0xFFFF: still in)
     if (ng <= 0) {
         if (threadIdx.x == 0) {
             if (a.rounds) a.rounds[g] = 0;
@@ -167,18 +170,47 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
         }
     }
     SH_STAMP(a, g, 1, tclk);
+    const int nobody = a.max_nodes;
     if (mine && sub == 0) {
         dinv[vv] = dv;
         z1[vv] = z1v;
-        st[vv] = 0;
+        kr[vv] = 0xFFFFu;
+    }
+    if (threadIdx.x == 0) {
+        dinv[nobody] = 0.0;
+        z1[nobody] = 0.f;
+        pr[nobody] = __longlong_as_double(0x7ff8000000000000ll);
+        kr[nobody] = 0;
+        wflags[32] = 0u;
     }
     __syncthreads();
     SH_STAMP(a, g, 2, tclk);
     // ---- entry values by all lanes of the row, then the chain by its first lane (LDS operations of one wave complete in
-    // order and the lpv lanes of a row sit in one wave: no barrier between the writes and the reads)
+    // order and the lpv lanes of a row sit in one wave: no barrier between the writes and the reads).  A lane keeps the ids
+    // of its first kNb entries in registers for the greedy rounds below.
+    constexpr int kNb = 8;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double dvv = mine ? dinv[vv] : 0.0;
+    int nb[kNb];
+#pragma unroll
+    for (int i = 0; i < kNb; ++i) {
+        const int j = rs + sub + i * lpv;
+        int u = (fits && j < re) ? (int)nbr[j - e0] : nobody;
+        if (u == 0xFFFF) u = nobody;
+        nb[i] = u;
+    }
     if (fits) {
-        for (int j = rs + sub; j < re; j += lpv) {
+        double dn[kNb];
+#pragma unroll
+        for (int i = 0; i < kNb; ++i) dn[i] = dinv[nb[i]];
+#pragma unroll
+        for (int i = 0; i < kNb; ++i) {
+            const int j = rs + sub + i * lpv;
+            if (nb[i] == vv) fault |= DGCN_FAULT_SELF_LOOP;
+            if (j < re) vals[j - e0] = (float)(-(dn[i] * dvv));
+        }
+#pragma unroll 4
+        for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {  // long rows (BA hubs): the rest through the table
             const int u = nbr[j - e0];
             if (u == vv) fault |= DGCN_FAULT_SELF_LOOP;
             vals[j - e0] = u == 0xFFFF ? 0.f : (float)(-(dinv[u] * dvv));
@@ -186,26 +218,30 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
     }
     float score = 0.f;
     double p = 0.0;
-    int bad = 0;
     if (mine && sub == 0) {
         double acc = fma(1.0, (double)z1v, 0.0);  // the diagonal entry of L comes first
         if (fits) {
             int j = rs;
             if (a.X) {
+#pragma unroll 4
                 for (; j < re; ++j) {
                     const int u = nbr[j - e0];
-                    acc = fma((double)vals[j - e0], (double)(u == 0xFFFF ? 0.f : z1[u]), acc);
+                    acc = fma((double)vals[j - e0], (double)z1[u == 0xFFFF ? nobody : u], acc);
                 }
             } else {  // constant features: every z1[u] is this vertex's own z1
                 const double zd = (double)z1v;
-                for (; j + 4 <= re; j += 4) {
-                    const float v0 = vals[j - e0], v1 = vals[j + 1 - e0], v2 = vals[j + 2 - e0], v3 = vals[j + 3 - e0];
-                    acc = fma((double)v0, zd, acc);
-                    acc = fma((double)v1, zd, acc);
-                    acc = fma((double)v2, zd, acc);
-                    acc = fma((double)v3, zd, acc);
+                for (; j + 8 <= re; j += 8) {  // eight independent reads in flight, chain order unchanged
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = vals[j + i - e0];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc = fma((double)v[i], zd, acc);
                 }
-                for (; j < re; ++j) acc = fma((double)vals[j - e0], zd, acc);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = j + i < re ? vals[j + i - e0] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (j + i < re) acc = fma((double)v[i], zd, acc);
             }
         }
         acc = (double)z0 + acc;
@@ -214,11 +250,11 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
         if (a.scores) a.scores[n0 + vv] = score;
         p = (double)score;
         if (a.predict_mwis && a.weights) p *= w;
-        bad = p != p;
+        if (p != p) wflags[32] = 1u;
         pr[vv] = p;
     }
-    const bool any_bad = sh_block_or<BLOCK>(bad != 0, wflags);
-    if (any_bad) {
+    __syncthreads();  // priorities (and the NaN flag) are in LDS
+    if (wflags[32]) {
         if (threadIdx.x == 0) {
             atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
             if (a.rounds) a.rounds[g] = -1;
@@ -228,52 +264,63 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
         sh_signal_done<BLOCK>(a);
         return;
     }
-    __syncthreads();  // priorities are in LDS (and the flag words free again)
     SH_STAMP(a, g, 3, tclk);
-    // ---- local greedy rounds on the priorities themselves
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    // ---- local greedy rounds on the priorities themselves.  kr[u] = the round u left the graph in (winner or removed
+    // neighbour), 0xFFFF while it is in: in round r a vertex counts as present iff kr >= r, so what a fast wave removes in
+    // round r does not change what a slow wave still reads in round r - ONE barrier per round (which also carries the
+    // "anybody still in?" votes) instead of two.  Priorities never change.
+    // (Tried: ONE WAVE per graph with ceil(N / 64) vertices per lane and no barrier at all.  27.9 us against 12.6 us for
+    // the C2 launch, 144 against 53 us on the BA mix: the phases are chains of dependent LDS round trips, and one wave has
+    // nothing to issue while it waits - several waves per graph hide each other's latency.)
     int rounds = 0;
     bool member = false;
-    while (true) {
+    for (unsigned r = 1;; ++r) {
         const double pv = mine ? pr[vv] : qnan;
-        const bool live = pv == pv;
+        const bool live = mine && (unsigned)kr[vv] >= r;
         bool lost = false;
+        unsigned ku[kNb];
         if (live && fits) {
-            int j = rs + sub;
-            for (; j + 3 * lpv < re; j += 4 * lpv) {  // four independent id -> priority chains in flight
-                const int u0 = nbr[j - e0], u1 = nbr[j + lpv - e0], u2 = nbr[j + 2 * lpv - e0], u3 = nbr[j + 3 * lpv - e0];
-                const double p0 = u0 == 0xFFFF ? qnan : pr[u0], p1 = u1 == 0xFFFF ? qnan : pr[u1];
-                const double p2 = u2 == 0xFFFF ? qnan : pr[u2], p3 = u3 == 0xFFFF ? qnan : pr[u3];
-                lost |= (p0 > pv) | ((p0 == pv) & (u0 < vv));
-                lost |= (p1 > pv) | ((p1 == pv) & (u1 < vv));
-                lost |= (p2 > pv) | ((p2 == pv) & (u2 < vv));
-                lost |= (p3 > pv) | ((p3 == pv) & (u3 < vv));
-            }
-            for (; j < re; j += lpv) {
-                const int u = nbr[j - e0];
-                const double pu = u == 0xFFFF ? qnan : pr[u];
-                lost |= (pu > pv) | ((pu == pv) & (u < vv));
+            double pu[kNb];
+#pragma unroll
+            for (int i = 0; i < kNb; ++i) { pu[i] = pr[nb[i]]; ku[i] = kr[nb[i]]; }
+#pragma unroll
+            for (int i = 0; i < kNb; ++i) lost |= (ku[i] >= r) & ((pu[i] > pv) | ((pu[i] == pv) & (nb[i] < vv)));
+#pragma unroll 4
+            for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+                const int u0 = nbr[j - e0];
+                const int u = u0 == 0xFFFF ? nobody : u0;
+                const double q = pr[u];
+                lost |= ((unsigned)kr[u] >= r) & ((q > pv) | ((q == pv) & (u < vv)));
             }
         }
         for (int off = 1; off < lpv; off <<= 1) lost |= (bool)__shfl_xor((int)lost, off);
         const bool won = live && !lost;
-        if (!sh_block_or<BLOCK>(live, wflags)) break;  // its barrier also orders every priority read before the removals below
-        ++rounds;
-        if (won) {
-            if (fits)
-                for (int j = rs + sub; j < re; j += lpv) {
+        {
+            const unsigned long long m = __ballot(live);
+            if ((threadIdx.x & 63) == 0) wflags[(r & 1) * 16 + (threadIdx.x >> 6)] = m != 0ull;
+        }
+        if (won) {  // (only vertices still in are stamped: a stale neighbour must not look present again to this round's readers)
+            if (fits) {
+#pragma unroll
+                for (int i = 0; i < kNb; ++i)
+                    if (ku[i] >= r && nb[i] != nobody) kr[nb[i]] = (unsigned short)r;
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
                     const int u = nbr[j - e0];
-                    if (u != 0xFFFF && u != vv) { pr[u] = qnan; st[u] = 2; }
+                    if (u != 0xFFFF && (unsigned)kr[u] >= r) kr[u] = (unsigned short)r;
                 }
-            if (sub == 0) { pr[vv] = qnan; member = true; }
+            }
+            if (sub == 0) { kr[vv] = (unsigned short)r; member = true; }
         }
         __syncthreads();
+        unsigned any = 0;
+#pragma unroll
+        for (int wv = 0; wv < BLOCK / 64; ++wv) any |= wflags[(r & 1) * 16 + wv];
+        if (!any) break;  // nobody was in at the start of round r: it did not happen
+        ++rounds;
     }
     SH_STAMP(a, g, 4, tclk);
     if (mine && sub == 0) {
-        // (a winner's own byte is written after the loop: a neighbour can never have written 2 to it, since two adjacent
-        // vertices cannot both win a round)
-        a.state[n0 + vv] = member ? 1 : st[vv];
+        a.state[n0 + vv] = member ? 1 : 2;  // (the loop ends when nobody is in: a vertex either joined or was removed)
     }
     if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
     if (a.totals) {
@@ -299,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
 }
 
 static size_t shallow_lds(int max_nodes, int cap) {
-    return (size_t)max_nodes * (8 + 8 + 4 + 1) + 16 * 8 + 64 + (size_t)cap * 6 + 64;
+    return (size_t)(max_nodes + 1) * (8 + 8 + 4 + 2) + 16 * 8 + 48 * 4 + (size_t)cap * 6 + 64;
 }
 
 // does this (batch, model) go through k_shallow?  One layer F -> 1 with two supports, graphs of <= 512 vertices whose
@@ -366,10 +413,16 @@ int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     const size_t lds = shallow_lds(a.max_nodes, a.cap);
     // threads: a vertex per thread at least; small graphs get several lanes per vertex (<= 8) out of a 64..256-thread block
     const int mn = b->max_nodes;
-    if (mn <= 16) return shallow_launch_b<64>(a, b->num_graphs, lds, s);
-    if (mn <= 64) return shallow_launch_b<128>(a, b->num_graphs, lds, s);
-    if (mn <= 128) return shallow_launch_b<256>(a, b->num_graphs, lds, s);
-    return shallow_launch_b<512>(a, b->num_graphs, lds, s);
+    int block = mn <= 16 ? 64 : mn <= 64 ? 128 : mn <= 128 ? 256 : 512;
+    if (const char* e = getenv("DGCN_SHALLOW_BLOCK")) {  // tuning: any of 64 / 128 / 256 / 512 / 1024 that holds a vertex per thread
+        const int want = atoi(e);
+        if ((want == 64 || want == 128 || want == 256 || want == 512 || want == 1024) && want >= mn) block = want;
+    }
+    if (block == 64) return shallow_launch_b<64>(a, b->num_graphs, lds, s);
+    if (block == 128) return shallow_launch_b<128>(a, b->num_graphs, lds, s);
+    if (block == 256) return shallow_launch_b<256>(a, b->num_graphs, lds, s);
+    if (block == 512) return shallow_launch_b<512>(a, b->num_graphs, lds, s);
+    return shallow_launch_b<1024>(a, b->num_graphs, lds, s);
 }
 
 }  // namespace dgcn

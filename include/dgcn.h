@@ -115,6 +115,27 @@ int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_h
                     const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes,
                     void* staging_host, size_t staging_bytes, DgcnPackInfo* info, int32_t num_threads);
 
+/* The compact TRANSFER format of the same batch: what has to cross PCIe for symmetric graphs with sorted rows is the upper
+ * triangle with 16-bit local column ids and a 16-bit count per vertex - a third of the bytes (C3: 3.0 MB instead of 9.2):
+ *   [graph_ptr int32[B+1] | up_ptr int32[B+1] (upper entries before graph g) | updeg uint16[N] | upcol uint16[E/2] | weights float64[N]]
+ * dgcn_pack_compact_layout: offsets from the ordinary DgcnPackInfo (dgcn_pack_measure).  dgcn_pack_compact_batch: writes it;
+ * returns 0, < 0 (structural error), or 1 = "not compactable" - a graph that is not symmetric by count, has an unsorted /
+ * repeated / self entry or more than 65 535 vertices: pack the ordinary format then (its kernels report such data faults);
+ * fills info->max_degree.  dgcn_expand_compact_batch (device, one launch, graphs of <= 512 vertices): rebuilds
+ * row_ptr[num_nodes + 1] and col_idx[num_edges] - entry for entry what dgcn_pack_batch writes for the same graphs; graph_ptr
+ * and weights are used where they lie in the compact buffer.  dgcn_host_solver_* does all of this by itself. */
+typedef struct DgcnCompactInfo {
+    int64_t off_graph_ptr, off_up_ptr, off_updeg, off_upcol, off_weights; /* byte offsets; off_weights = -1 without weights */
+    int64_t total_bytes;
+} DgcnCompactInfo;
+int dgcn_pack_compact_layout(const DgcnPackInfo* info, DgcnCompactInfo* compact);
+int dgcn_pack_compact_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
+                            const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes,
+                            void* staging_host, size_t staging_bytes, DgcnPackInfo* info, const DgcnCompactInfo* compact,
+                            int32_t num_threads);
+int dgcn_expand_compact_batch(const void* compact_dev, const DgcnCompactInfo* compact, int32_t num_graphs, int32_t num_nodes,
+                              int32_t max_nodes, int32_t* row_ptr_out, int32_t* col_idx_out, void* stream);
+
 /* ---- A1/A2: gcn/utils.py:120-127 normalize_adj + :258-274 simple_polynomials (k = 1) ----------
  * Builds L = I - D^-1/2 A D^-1/2 for the whole batch.  dinv_table[d] must hold the float64 value
  * numpy.power(d, -0.5) with inf -> 0 (table built once by the host so the float64 bits equal the

@@ -1233,3 +1233,54 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
     for mode in ("8", None):
         for a, b in zip(got["0"], got[mode]):
             assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), (which, mode)
+
+
+def test_host_solver_compact_transfer(engine, monkeypatch):
+    """Batches above the in-place threshold cross PCIe in the compact form (upper triangle, 16-bit ids: include/dgcn.h
+    DgcnCompactInfo) and are expanded on the device (csrc/expand.hip): same sets / rounds / totals / scores as the ordinary
+    transfer (DGCN_HOST_COMPACT=0) and as the twin, on the BA mix (hubs, 100..300 vertices) and an ER batch; a batch holding
+    one graph with an unsorted row cannot be compacted and silently takes the ordinary format - results follow the
+    caller's entry order, as they always did."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.serving import HostSolver
+    from oracle import ctwin
+    layers = datagen.random_model(3, 32, seed=21)
+    dm = DeviceModel(layers, engine.device)
+    monkeypatch.setenv("DGCN_HOST_DIRECT_BYTES", "0")
+
+    def lists(hb, scramble=None):
+        ps, cs, ws = [], [], []
+        for g, (n0, n1) in enumerate(hb.graph_slices()):
+            e0, e1 = int(hb.row_ptr[n0]), int(hb.row_ptr[n1])
+            p, c = (hb.row_ptr[n0:n1 + 1] - e0).astype(np.int32), (hb.col_idx[e0:e1] - n0).astype(np.int32)
+            if scramble == g:  # reverse the first row with at least two entries
+                v = int(np.flatnonzero(np.diff(p) >= 2)[0])
+                c = c.copy(); c[p[v]:p[v + 1]] = c[p[v]:p[v + 1]][::-1]
+            ps.append(p); cs.append(c); ws.append(hb.weights[n0:n1].copy())
+        return ps, cs, ws
+
+    for hb in (datagen.ba_test2_batch(120, first_index=300), datagen.er_batch(150, 200, 0.1, first_index=7000)):
+        ref = ctwin.solve(hb, layers)
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DGCN_HOST_COMPACT", mode)
+            hs = HostSolver(engine, dm, depth=2, want_scores=True)
+            got[mode] = [hs.solve(*lists(hb)) for _ in range(2)][-1]
+            hs.close()
+        for mode in ("1", "0"):
+            g = got[mode]
+            assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["rounds"], ref["rounds"]), mode
+            assert np.allclose(g["totals"], ref["totals"], rtol=1e-12, atol=0)
+            assert np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32)), mode
+    # not compactable: one unsorted row -> ordinary transfer, entry order as given
+    monkeypatch.setenv("DGCN_HOST_COMPACT", "1")
+    hb = datagen.er_batch(150, 200, 0.1, first_index=7000)
+    ps, cs, ws = lists(hb, scramble=17)
+    hbs = HostBatch.from_csr_lists(ps, cs, ws)
+    ref = ctwin.solve(hbs, layers)
+    hs = HostSolver(engine, dm, depth=2, want_scores=True)
+    g = hs.solve(ps, cs, ws)
+    hs.close()
+    assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32))
