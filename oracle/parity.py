@@ -119,7 +119,9 @@ def twin_report(name, procs=None, chunk=125):
     if procs <= 1:
         parts = [_chunk(j) for j in jobs]
     else:
-        with mp.get_context("fork").Pool(procs) as pool:
+        # fresh interpreters, not forks: the caller (a pytest process that has run BLAS calls, gloo ranks and the native
+        # packer's worker pool) holds threads and locks a forked child would inherit half of
+        with mp.get_context("spawn").Pool(procs) as pool:
             parts = pool.map(_chunk, jobs)
     reports = [r for p in parts for r in p]
     return summarize(reports), reports
