@@ -412,8 +412,8 @@ def roofline_objects(args, wl, fam_ms):
         dom = max(fam_ms, key=lambda k: fam_ms[k][0])
         ms, n = fam_ms[dom]
         avg_s = ms / n * 1e-3
-        tkey = ("spmm|%dx%d|C%d" % (args.graphs, args.nodes, args.hidden)) if dom == "spmm" else \
-            "%s|%dx%d|l%d" % (dom, args.graphs, args.nodes, args.layers)
+        shape = ("ba%d" % args.graphs) if args.family == "ba" else "%dx%d" % (args.graphs, args.nodes)
+        tkey = ("spmm|%s|C%d" % (shape, args.hidden)) if dom == "spmm" else "%s|%s|l%d" % (dom, shape, args.layers)
         traffic = traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")
         if dom in ("spmm", "layer"):
             per = spmm_algorithmic_bytes(hb, layers, with_y0=True)
@@ -566,12 +566,18 @@ def e2e_probe(args, wl, reference_state):
     for _ in range(20):
         _, info = pack_csr_lists(ps, cs, ws, staging=staging)
     pack_ms = (time.perf_counter() - t1) / 20 * 1e3
+    import ctypes
+    from distgcn_amd import _lib
+    ci = _lib.DgcnCompactInfo()
+    compact = os.environ.get("DGCN_HOST_COMPACT", "1") != "0" and _lib.load().dgcn_pack_compact_layout(ctypes.byref(info), ctypes.byref(ci)) == 0
+    h2d = int(ci.total_bytes) if compact else int(info.total_bytes)
     return {"value": hb.num_graphs * batches / dt, "unit": "graphs/s", "ms_per_batch": dt / batches * 1e3, "batches": batches,
-            "path": "dgcn_host_solver_submit / _result: per-graph CSR arrays in host memory -> dgcn_pack_batch into pinned memory -> "
-                    "1 H2D copy (%.1f MB) -> dgcn_solve_batch -> 1 D2H copy (%.0f KB) -> membership + totals + rounds in host memory; "
+            "path": "dgcn_host_solver_submit / _result: per-graph CSR arrays in host memory -> native packing into pinned memory (%s) -> "
+                    "1 H2D copy (%.1f MB) -> %sdgcn_solve_batch -> 1 D2H copy (%.0f KB) -> membership + totals + rounds in host memory; "
                     "3 batches in flight"
-                    % (int(info.total_bytes) / 1e6, (hb.num_nodes + 12 * hb.num_graphs) / 1e3),
-            "pack_ms_per_batch": pack_ms, "results_equal_resident_step": same}
+                    % ("compact transfer format: 16-bit local column ids + degrees" if compact else "block-diagonal int32 CSR", h2d / 1e6,
+                       "k_expand_compact -> " if compact else "", (hb.num_nodes + 12 * hb.num_graphs) / 1e3),
+            "h2d_bytes_per_batch": h2d, "pack_ms_per_batch_ordinary_format": pack_ms, "results_equal_resident_step": same}
 
 
 def two_stream_probe(args, wl, reference_state):

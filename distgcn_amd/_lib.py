@@ -69,7 +69,7 @@ class DgcnPackInfo(C.Structure):
 
 
 class DgcnCompactInfo(C.Structure):
-    _fields_ = [("off_graph_ptr", C.c_int64), ("off_up_ptr", C.c_int64), ("off_updeg", C.c_int64), ("off_upcol", C.c_int64),
+    _fields_ = [("off_graph_ptr", C.c_int64), ("off_edge_ptr", C.c_int64), ("off_deg", C.c_int64), ("off_col", C.c_int64),
                 ("off_weights", C.c_int64), ("total_bytes", C.c_int64)]
 
 
@@ -126,7 +126,7 @@ def load():
     lib.dgcn_transform_f64acc_batch.restype = C.c_int
     lib.dgcn_transform_f64acc_batch.argtypes = [vp, i32, f32, i32, i32, vp, i32, vp, i32, vp]
     lib.dgcn_spmm_f64acc_batch.restype = C.c_int
-    lib.dgcn_spmm_f64acc_batch.argtypes = [C.POINTER(DgcnCsr), vp, i32, i32, vp, i32, vp, i32, vp, i32, vp]
+    lib.dgcn_spmm_f64acc_batch.argtypes = [C.POINTER(DgcnCsr), vp, i32, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, vp]
     lib.dgcn_gcn_forward_workspace.restype = sz
     lib.dgcn_gcn_forward_workspace.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel), i32]
     lib.dgcn_gcn_forward_batch.restype = C.c_int

@@ -38,7 +38,8 @@ def _addresses(arrays, kind):
         if a is None:
             addr[i], cnt[i] = 0, 0
             continue
-        a = np.asarray(a)
+        if not isinstance(a, np.ndarray):  # (a converted temporary would be gone before its address is used)
+            raise TypeError("item %d is a %s, expected a NumPy array" % (i, type(a).__name__))
         want_float = kind == 64
         ok = a.flags.c_contiguous and ((a.dtype == np.float64) if want_float else (a.dtype.kind == "i" and a.dtype.itemsize in (4, 8)))
         if ok and not want_float:

@@ -70,7 +70,7 @@ int pack_batch(const void* const* indptr_host, const void* const* indices_host, 
 int compact_layout(const DgcnPackInfo* std_info, DgcnCompactInfo* ci);  // 0, or 1 = this batch cannot be compacted
 int pack_compact(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
                  const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host, size_t staging_bytes,
-                 DgcnPackInfo* info, const DgcnCompactInfo* ci, int32_t num_threads);  // DGCN_OK, < 0, or 1 = not compactable
+                 DgcnPackInfo* info, const DgcnCompactInfo* ci, int32_t num_threads, bool reject_self_loops);  // DGCN_OK, < 0, or 1 = not compactable
 int expand_compact(const void* compact_dev, const DgcnCompactInfo* ci, int32_t num_graphs, int32_t num_nodes, int32_t max_nodes,
                    int32_t* row_ptr_out, int32_t* col_idx_out, hipStream_t stream);
 

@@ -12,8 +12,8 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
                   const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s);
 int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                        int ldz, hipStream_t s);
-int spmm_f64acc_dispatch(const DgcnCsr* S, const float* Z, int ldz, int C, const float* Y0, int ldy0, const float* bias, int act,
-                         float* Y, int ldy, hipStream_t s);
+int spmm_f64acc_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
+                         const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s);
 int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                               int ldz, hipStream_t s);
 int layer32_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, const float* bias, int act,
@@ -209,8 +209,8 @@ static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const 
             const bool fin = i == K - 1;
             float* dst = fin ? out : Tbuf;
             // K4-K7: dst = run + T_i.Z_i, and on the last support: act(. + b)
-            rc = l == 0 ? spmm_f64acc_dispatch(sup[i - 1], Zbuf + i * L.out_dim, ctot, L.out_dim, run, ldrun, fin ? L.bias : nullptr,
-                                               fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s)
+            rc = l == 0 ? spmm_f64acc_dispatch(sup[i - 1], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + i * L.out_dim, ctot, L.out_dim,
+                                               run, ldrun, fin ? L.bias : nullptr, fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s)
                         : spmm_dispatch(sup[i - 1], b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + i * L.out_dim, ctot, L.out_dim,
                                         run, ldrun, fin ? L.bias : nullptr, fin ? L.act : DGCN_ACT_LINEAR, dst, L.out_dim, s);
             if (rc) return rc;

@@ -32,6 +32,7 @@
 // Shapes handled here: first layer any width -> 32 (VALU), hidden layers 32 -> 32 (MFMA), last layer
 // -> 1; or a single layer F -> 1.  Anything else returns DGCN_ERR_UNSUPPORTED and the caller uses mode 0.
 #include <atomic>
+#include <random>
 
 #include "common.h"
 
@@ -93,12 +94,11 @@ struct FusedArgs {
     // cluster variant (k_fused<false, *, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
     int32_t cluster;
     int32_t cluster_inject;  // test hook (DGCN_FUSED_CLUSTER_INJECT_FAULT=1): report a placement fault although there is none
-    int32_t epoch;      // this launch's value of the progress words ("my exchange rows are marked unwritten"): what a
-                        // previous launch left behind (possibly still cached in this XCD's L2) is always smaller
+    unsigned long long nonce;  // this launch's value of the progress words ("my exchange rows are marked unwritten")
     int32_t num_graphs;
     float* xz;          // [num_graphs][3][max_nodes][32] Z1 rows on their way between the workgroups of a graph (slice l % 3)
     float* xs;          // [num_graphs][2][max_nodes] last layer: z1 scalars, then scores
-    int32_t* xflag;     // G = num_graphs rounded up to 8: [G][8] workgroup progress words, then [G][8] XCC ids
+    unsigned long long* xflag;  // G = num_graphs rounded up to 8: [G][8] 64-bit workgroup progress words, then [G][8] int32 XCC ids
     int32_t diag;  // DGCN_DIAG builds only: bit0 skip gathers, bit1 skip transforms, bit2 skip greedy rounds
     unsigned long long* stamps;  // DGCN_DIAG builds only: [num_graphs][16] wave-0 phase clocks (s_memtime)
     FusedLayer layers[kMaxFusedLayers];
@@ -368,19 +368,22 @@ __device__ __forceinline__ float poll_l2_scalar(const float* p, int32_t* status)
     }
 }
 
-// every store of this workgroup has left the CU -> publish `seq`
+// every store of this workgroup has left the CU -> publish this launch's nonce
 template <int BLOCK>
-__device__ __forceinline__ void cluster_publish(int32_t* flags, int cw, int seq) {
+__device__ __forceinline__ void cluster_publish(unsigned long long* flags, int cw, unsigned long long nonce) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&flags[cw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[cw], nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until all K workgroups have published `seq`
+// wait until all K workgroups have published it.  EQUALITY with a 64-bit value that no other launch of this process ever
+// uses (fused_prepare): whatever the caller's workspace held before - an earlier launch's words, float data, records of an
+// ordinary launch, a recycled allocation - reads as "not yet" with a 2^-64 exception per word, so the words need no
+// clearing (round 2 compared "not older than this launch's epoch" modulo 2^32, which arbitrary bits satisfy half the time).
 template <int BLOCK>
-__device__ __forceinline__ void cluster_wait(int32_t* flags, int K, int seq, int32_t* status) {
+__device__ __forceinline__ void cluster_wait(unsigned long long* flags, int K, unsigned long long nonce, int32_t* status) {
     if ((int)threadIdx.x < K) {
         int spins = 0;
-        while ((int)(__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nonce) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 21)) {  // ~0.3 s: somebody is not coming
                 if (status) atomicOr(status, DGCN_FAULT_CLUSTER);
@@ -1003,7 +1006,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         g = grp * 8 + (rem & 7);
         if (g >= a.num_graphs) return;
     }
-    int32_t* xfl = CLUSTER ? a.xflag + (size_t)g * 8 : nullptr;
+    unsigned long long* xfl = CLUSTER ? a.xflag + (size_t)g * 8 : nullptr;                                   // this graph's progress words
+    int32_t* xcc_slots = CLUSTER ? reinterpret_cast<int32_t*>(a.xflag + (size_t)8 * ((a.num_graphs + 7) & ~7)) + (size_t)g * 8 : nullptr;  // ... XCC ids
     const bool stamp_wg = !CLUSTER || cw == 0;  // (DGCN_DIAG builds: phase clocks of the graph's first workgroup only)
     (void)stamp_wg;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
@@ -1282,7 +1286,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (threadIdx.x == 0) {  // where this workgroup runs: compared after the first exchange
             unsigned id;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-            __hip_atomic_store(&xfl[(size_t)8 * ((a.num_graphs + 7) & ~7) + cw], (int)(id & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&xcc_slots[cw], (int)(id & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // whatever an earlier launch left in the exchange slices: this workgroup's rows read "unwritten" from here on,
         // and the others learn through the progress word that they do (waited for in front of the first pull)
@@ -1292,7 +1296,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             xs0[threadIdx.x] = __uint_as_float(kUnwritten);
             xs0[a.max_nodes + threadIdx.x] = __uint_as_float(kUnwritten);
         }
-        cluster_publish<BLOCK>(xfl, cw, a.epoch);
+        cluster_publish<BLOCK>(xfl, cw, a.nonce);
     }
     STAMP(a, g, 2, tclk);  // P0c: row order
 
@@ -1369,10 +1373,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (a.prio_second || a.prio_gather) set_prio(prio_base);
         if constexpr (CLUSTER) {
             if (l == 1) {  // before the first pull: every workgroup of the graph has marked its exchange rows
-                cluster_wait<BLOCK>(xfl, K, a.epoch, a.status);
+                cluster_wait<BLOCK>(xfl, K, a.nonce, a.status);
                 if (a.cluster_inject && threadIdx.x == 0 && a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
                 if ((int)threadIdx.x < K) {  // all on one XCD?  (the cheap visibility rule above depends on it)
-                    const int32_t* xcc = xfl + (size_t)8 * ((a.num_graphs + 7) & ~7);
+                    const int32_t* xcc = xcc_slots;
                     if (__hip_atomic_load(&xcc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
                         __hip_atomic_load(&xcc[cw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                         if (a.status) atomicOr(a.status, DGCN_FAULT_CLUSTER);
@@ -2072,7 +2076,7 @@ static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
     if (K < 2) return 0;
     const size_t gpad = (size_t)((b->num_graphs + 7) & ~7);
     const size_t mn = (size_t)max(b->max_nodes, 64);
-    return 256 + gpad * 16 * sizeof(int32_t) + (size_t)b->num_graphs * mn * (3 * kHid + 2) * sizeof(float) + 256;
+    return 256 + gpad * 8 * (sizeof(unsigned long long) + sizeof(int32_t)) + (size_t)b->num_graphs * mn * (3 * kHid + 2) * sizeof(float) + 256;
 }
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
@@ -2176,18 +2180,19 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
                         workspace ? workspace_bytes : (size_t)0);
         const size_t gpad = (size_t)((b->num_graphs + 7) & ~7);
         char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-        a->xflag = reinterpret_cast<int32_t*>(p);
-        p += gpad * 16 * sizeof(int32_t);
+        a->xflag = reinterpret_cast<unsigned long long*>(p);
+        p += gpad * 8 * (sizeof(unsigned long long) + sizeof(int32_t));
+        p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
         a->xz = reinterpret_cast<float*>(p);
         a->xs = a->xz + (size_t)b->num_graphs * 3 * a->max_nodes * kHid;
-        // The workspace is the caller's: between two cluster launches anything may have written these bytes (a layered
-        // forward, an ordinary fused launch's records, a freed-and-reallocated buffer at the same address), and a stale word
-        // that happens to compare "not older than this epoch" would let a workgroup pull rows its peers have not marked yet.
-        // So the progress words and XCC slots are cleared on EVERY launch, in stream order (a few hundred bytes).
-        if (hipMemsetAsync(a->xflag, 0, gpad * 16 * sizeof(int32_t), stream) != hipSuccess)
-            return fail(DGCN_ERR_LAUNCH, "%s: clearing the exchange flags failed", who);
-        static std::atomic<uint32_t> launches{1};
-        a->epoch = (int32_t)(launches.fetch_add(1, std::memory_order_relaxed) << 6);  // 64 steps per launch; compared modulo 2^32
+        // The workspace is the caller's: between two cluster launches anything may have written these bytes.  Nothing is
+        // cleared; a launch's progress words are recognised by a 64-bit nonce no other launch of the process shares
+        // (a random start, then a counter): see cluster_wait.
+        static std::atomic<unsigned long long> nonce_src{[] {
+            std::random_device rd;
+            return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ 0x9E3779B97F4A7C15ull;
+        }()};
+        a->nonce = nonce_src.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed);
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
     a->flags_off = (int32_t)(*lds - 256);

@@ -275,16 +275,16 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     const char* direct_env = getenv("DGCN_HOST_DIRECT_BYTES");
     const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(2 << 20);
     const bool direct = (size_t)info.total_bytes <= direct_bytes;
-    // Larger batches cross PCIe in the compact form when they can (symmetric graphs with sorted rows, <= 512 vertices:
-    // upper triangle, 16-bit ids - a third of the bytes) and are expanded on the device (expand.hip); anything else, and
-    // every batch when DGCN_HOST_COMPACT=0, goes as the ordinary block-diagonal CSR.
+    // Larger batches cross PCIe in the compact form (16-bit local column ids, 16-bit degrees: about half the bytes, and
+    // half the bytes for the packer to write) and are expanded on the device (expand.hip); graphs beyond 65 535 vertices,
+    // and every batch when DGCN_HOST_COMPACT=0, go as the ordinary block-diagonal CSR.
     const char* compact_env = getenv("DGCN_HOST_COMPACT");
     const bool compact_ok = !compact_env || atoi(compact_env) != 0;
     DgcnCompactInfo ci = {};
     bool compact = false;
-    if (!direct && compact_ok && info.max_nodes <= 512 && info.num_nodes > 0 && compact_layout(&info, &ci) == 0) {
+    if (!direct && compact_ok && info.num_nodes > 0 && compact_layout(&info, &ci) == 0) {
         rc = pack_compact(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, s.in_host, s.in_cap, &info, &ci,
-                          threads);
+                          threads, h->lgs_only);
         if (rc < 0) return rc;
         compact = rc == 0;
     }
@@ -340,17 +340,21 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
                 s.done_total = s.done_base;
                 st[2] = 0;
             }
-        } else if (h->slots.size() == 1) {  // nothing to overlap with: no cross-stream hop on the latency path
-            if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess)
+        } else {
+            // one slot: nothing to overlap with, everything on the slot's stream (no cross-stream hop on the latency path);
+            // several: copy - and the expansion of a compact batch - on the shared copy stream, beside the previous
+            // batch's solve on its slot's stream, which then only waits for the `copied` event
+            hipStream_t in_stream = h->slots.size() == 1 ? s.stream : h->copy_stream;
+            if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, in_stream) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
-        } else if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, h->copy_stream) != hipSuccess ||
-                   hipEventRecord(s.copied, h->copy_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess) {
-            return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
+            if (compact && (rc = expand_compact(s.in_dev, &ci, info.num_graphs, info.num_nodes, info.max_nodes,
+                                                static_cast<int32_t*>(s.exp_dev), reinterpret_cast<int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off),
+                                                in_stream)))
+                return rc;
+            if (in_stream != s.stream &&
+                (hipEventRecord(s.copied, in_stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.copied, 0) != hipSuccess))
+                return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
         }
-        if (compact && (rc = expand_compact(s.in_dev, &ci, info.num_graphs, info.num_nodes, info.max_nodes,
-                                            static_cast<int32_t*>(s.exp_dev), reinterpret_cast<int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off),
-                                            s.stream)))
-            return rc;
         if ((rc = launch_slot(h, s))) return rc;
     } else {  // nothing to launch: graphs without vertices have total 0 after 0 rounds
         std::memset(s.out_host, 0, s.off_state);

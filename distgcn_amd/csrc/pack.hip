@@ -247,20 +247,24 @@ static int pack_t(const void* const* indptr, const void* const* indices, const d
     return DGCN_OK;
 }
 
-// ---- compact transfer format (host_solver.hip): what has to cross PCIe for a batch of SYMMETRIC graphs with sorted rows
-// is the upper triangle with 16-bit local column ids and a 16-bit count per vertex - 3.0 MB instead of 9.2 MB for a C3 batch;
-// k_expand_compact (expand.hip) rebuilds the block-diagonal CSR on the device, entry for entry what dgcn_pack_batch writes:
-//   [graph_ptr int32[B+1] | up_ptr int32[B+1] (upper entries before graph g) | updeg uint16[N] | upcol uint16[E/2] | weights f64[N]]
-// Returns DGCN_OK, an error, or kNotCompact (1): a graph is not symmetric-by-count, has an unsorted / repeated / self entry
-// or more than 65 535 vertices - the caller then packs the ordinary format (whose kernels report such data faults).
+// ---- compact transfer format (host_solver.hip): what has to cross PCIe is 16-bit LOCAL column ids and a 16-bit degree per
+// vertex instead of 32-bit global ids and row pointers - 5.0 MB instead of 9.2 MB for a C3 batch - and the packing loop
+// writes half the bytes; k_expand_compact (expand.hip) rebuilds the block-diagonal CSR on the device, entry for entry what
+// dgcn_pack_batch writes:
+//   [graph_ptr int32[B+1] | edge_ptr int32[B+1] (entries before graph g) | deg uint16[N] | col uint16[E] | weights f64[N]]
+// (Also tried: the upper triangle only, 3.0 MB.  The packer then has to split every sorted row at its diagonal and verify
+// order and symmetry - 0.74 ms per C3 batch on 8 threads against 0.26 ms for the ordinary format: the host, not PCIe, is
+// what the pipeline waits for.)
+// Returns DGCN_OK, an error, or 1: a graph has more than 65 535 vertices or a vertex more than 65 535 neighbours - the
+// caller then packs the ordinary format.
 int compact_layout(const DgcnPackInfo* std_info, DgcnCompactInfo* ci) {
     const int64_t B = std_info->num_graphs, n = std_info->num_nodes, e = std_info->num_edges;
-    if (e % 2 || std_info->max_nodes > 65535) return 1;
+    if (std_info->max_nodes > 65535) return 1;
     int64_t off = 0;
     ci->off_graph_ptr = off; off = align16(off + (B + 1) * 4);
-    ci->off_up_ptr = off;    off = align16(off + (B + 1) * 4);
-    ci->off_updeg = off;     off = align16(off + (n > 0 ? n : 1) * 2);
-    ci->off_upcol = off;     off = align16(off + (e / 2 > 0 ? e / 2 : 1) * 2);
+    ci->off_edge_ptr = off;  off = align16(off + (B + 1) * 4);
+    ci->off_deg = off;       off = align16(off + (n > 0 ? n : 1) * 2);
+    ci->off_col = off;       off = align16(off + (e > 0 ? e : 1) * 2);
     ci->off_weights = std_info->off_weights >= 0 ? off : -1;
     if (std_info->off_weights >= 0) off = align16(off + (n > 0 ? n : 1) * 8);
     ci->total_bytes = off > 16 ? off : 16;
@@ -269,23 +273,22 @@ int compact_layout(const DgcnPackInfo* std_info, DgcnCompactInfo* ci) {
 
 template <typename I>
 static int pack_compact_t(const void* const* indptr, const void* const* indices, const double* const* weights,
-                          const int32_t* num_nodes, int B, char* dst, DgcnPackInfo* info, const DgcnCompactInfo* ci, int threads) {
+                          const int32_t* num_nodes, int B, char* dst, DgcnPackInfo* info, const DgcnCompactInfo* ci, int threads,
+                          bool reject_self_loops) {
     int32_t* graph_ptr = reinterpret_cast<int32_t*>(dst + ci->off_graph_ptr);
-    int32_t* up_ptr = reinterpret_cast<int32_t*>(dst + ci->off_up_ptr);
-    uint16_t* updeg = reinterpret_cast<uint16_t*>(dst + ci->off_updeg);
-    uint16_t* upcol = reinterpret_cast<uint16_t*>(dst + ci->off_upcol);
+    int32_t* edge_ptr = reinterpret_cast<int32_t*>(dst + ci->off_edge_ptr);
+    uint16_t* deg = reinterpret_cast<uint16_t*>(dst + ci->off_deg);
+    uint16_t* col = reinterpret_cast<uint16_t*>(dst + ci->off_col);
     double* wts = ci->off_weights >= 0 ? reinterpret_cast<double*>(dst + ci->off_weights) : nullptr;
     int64_t n = 0, e = 0;
     for (int g = 0; g < B; ++g) {
-        const int64_t eg = (int64_t) static_cast<const I*>(indptr[g])[num_nodes[g]];
-        if (eg % 2) return 1;
         graph_ptr[g] = (int32_t)n;
-        up_ptr[g] = (int32_t)(e / 2);
+        edge_ptr[g] = (int32_t)e;
         n += num_nodes[g];
-        e += eg;
+        e += (int64_t) static_cast<const I*>(indptr[g])[num_nodes[g]];
     }
     graph_ptr[B] = (int32_t)n;
-    up_ptr[B] = (int32_t)(e / 2);
+    edge_ptr[B] = (int32_t)e;
     if (n != info->num_nodes || e != info->num_edges) return fail(DGCN_ERR_ARG, "dgcn_pack_batch: inputs changed since dgcn_pack_measure");
     if (wts && n == 0) wts[0] = 0.0;
     threads = std::max(1, std::min(threads, std::min(B, 64)));
@@ -297,7 +300,7 @@ static int pack_compact_t(const void* const* indptr, const void* const* indices,
         int g = 0;
         for (int t = 1; t < threads; ++t) {
             const int64_t target = total * t / threads;
-            while (g < B && 2 * (int64_t)up_ptr[g] + graph_ptr[g] < target) ++g;
+            while (g < B && (int64_t)edge_ptr[g] + graph_ptr[g] < target) ++g;
             cut[t] = g;
         }
     }
@@ -305,39 +308,47 @@ static int pack_compact_t(const void* const* indptr, const void* const* indices,
     std::vector<int> maxdeg((size_t)threads, 0);
     auto work = [&](int part) {
         int md = 0;
-        for (int g = cut[part]; g < cut[part + 1] && !not_compact.load(std::memory_order_relaxed); ++g) {
+        for (int g = cut[part]; g < cut[part + 1]; ++g) {
             const int ng = num_nodes[g];
             const I* p = static_cast<const I*>(indptr[g]);
-            const I* c = static_cast<const I*>(indices[g]);
+            const I* __restrict c = static_cast<const I*>(indices[g]);
             const int32_t n0 = graph_ptr[g];
             const int64_t eg = (int64_t)p[ng];
             if (eg > 0 && !c) { bad_graph = g; bad_kind = 3; continue; }
-            uint16_t* uc = upcol + up_ptr[g];
-            int64_t ups = 0, lows = 0, prevp = 0;
-            bool ok = true, plain = true;
-            for (int v = 0; v < ng && ok; ++v) {
-                const int64_t a = (int64_t)p[v], b = (int64_t)p[v + 1];
-                ok &= a >= prevp && b >= a && b <= eg;
-                if (!ok) break;
-                prevp = a;
-                if (b - a > md) md = (int)std::min<int64_t>(b - a, 0x7fffffff);
-                int64_t last = -1;
-                int cnt = 0;
-                for (int64_t j = a; j < b; ++j) {
-                    const int64_t u = (int64_t)c[j];
-                    if (u < 0 || u >= ng) { bad_graph = g; bad_kind = 2; ok = false; break; }
-                    plain &= u > last && u != v;  // strictly ascending, no self-loop
-                    last = u;
-                    if (u > v) {
-                        if (ups < eg / 2) uc[ups] = (uint16_t)u;
-                        ++ups;
-                        ++cnt;
-                    } else ++lows;
-                }
-                updeg[n0 + v] = (uint16_t)cnt;
+            uint16_t* __restrict dg = deg + n0;
+            int64_t prev = 0;
+            bool ok = true;
+            int gmd = 0;
+            for (int v = 0; v < ng; ++v) {
+                const int64_t cur = (int64_t)p[v], d = (int64_t)p[v + 1] - cur;
+                ok &= cur >= prev && d >= 0;
+                if (d > gmd) gmd = (int)std::min<int64_t>(d, 0x7fffffff);
+                dg[v] = (uint16_t)d;
+                prev = cur;
             }
-            if (!ok) { if (bad_graph.load() < 0) { bad_graph = g; bad_kind = 1; } continue; }
-            if (!plain || ups != lows || ups != eg / 2) { not_compact.store(1, std::memory_order_relaxed); continue; }
+            ok &= eg >= prev;
+            if (!ok) { bad_graph = g; bad_kind = 1; continue; }
+            if (gmd > md) md = gmd;
+            if (gmd > 65535) { not_compact.store(1, std::memory_order_relaxed); continue; }
+            uint16_t* __restrict cc = col + edge_ptr[g];
+            unsigned range_bad = 0, self_bad = 0;
+            if (reject_self_loops) {
+                for (int v = 0; v < ng; ++v)
+                    for (int64_t j = (int64_t)p[v]; j < (int64_t)p[v + 1]; ++j) {
+                        const int64_t u = (int64_t)c[j];
+                        range_bad |= (unsigned)(u < 0) | (unsigned)(u >= ng);
+                        self_bad |= (unsigned)(u == v);
+                        cc[j] = (uint16_t)u;
+                    }
+            } else {
+                for (int64_t j = 0; j < eg; ++j) {
+                    const I u = c[j];
+                    range_bad |= (unsigned)(u < 0) | (unsigned)(u >= (I)ng);
+                    cc[j] = (uint16_t)u;
+                }
+            }
+            if (range_bad) { bad_graph = g; bad_kind = 2; continue; }
+            if (self_bad) { bad_graph = g; bad_kind = 5; continue; }
             if (wts) {
                 if (!weights || !weights[g]) { if (ng) { bad_graph = g; bad_kind = 4; } continue; }
                 std::memcpy(wts + n0, weights[g], (size_t)ng * sizeof(double));
@@ -347,7 +358,8 @@ static int pack_compact_t(const void* const* indptr, const void* const* indices,
     };
     Pool::get().run(threads, work);
     if (bad_graph.load() >= 0) {
-        static const char* what[] = {"", "indptr is not non-decreasing", "a column index is outside [0, n)", "indices missing", "weights missing"};
+        static const char* what[] = {"", "indptr is not non-decreasing", "a column index is outside [0, n)", "indices missing",
+                                     "weights missing", "the adjacency has a self-loop (heuristics.py:94 would never terminate)"};
         return fail(DGCN_ERR_ARG, "dgcn_pack_batch: graph %d: %s", bad_graph.load(), what[bad_kind.load()]);
     }
     if (not_compact.load()) return 1;
@@ -359,11 +371,11 @@ static int pack_compact_t(const void* const* indptr, const void* const* indices,
 
 int pack_compact(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
                  const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host, size_t staging_bytes,
-                 DgcnPackInfo* info, const DgcnCompactInfo* ci, int32_t num_threads) {
+                 DgcnPackInfo* info, const DgcnCompactInfo* ci, int32_t num_threads, bool reject_self_loops) {
     if ((int64_t)staging_bytes < ci->total_bytes) return 1;
     char* dst = static_cast<char*>(staging_host);
-    if (index_bytes == 4) return pack_compact_t<int32_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, ci, num_threads);
-    if (index_bytes == 8) return pack_compact_t<int64_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, ci, num_threads);
+    if (index_bytes == 4) return pack_compact_t<int32_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, ci, num_threads, reject_self_loops);
+    if (index_bytes == 8) return pack_compact_t<int64_t>(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, dst, info, ci, num_threads, reject_self_loops);
     return 1;
 }
 
@@ -429,5 +441,5 @@ extern "C" int dgcn_pack_compact_batch(const void* const* indptr_host, const voi
         num_threads = (int)std::min(8u, hc ? hc : 1u);
     }
     return dgcn::pack_compact(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, staging_host,
-                              staging_bytes, info, compact, num_threads);
+                              staging_bytes, info, compact, num_threads, false);
 }

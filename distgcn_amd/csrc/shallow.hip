@@ -413,7 +413,9 @@ int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     const size_t lds = shallow_lds(a.max_nodes, a.cap);
     // threads: a vertex per thread at least; small graphs get several lanes per vertex (<= 8) out of a 64..256-thread block
     const int mn = b->max_nodes;
-    int block = mn <= 16 ? 64 : mn <= 64 ? 128 : mn <= 128 ? 256 : 512;
+    // measured (tools/runs/r03_gpu9.sh, 500 graphs per launch): ER N=100: 17.9 / 12.3 / 13.3 / 24.4 us with 128 / 256 / 512 / 1024
+    // threads; ER N=200: 22.8 (512) / 27.8 (1024); BA mix up to N=300 (hub rows): 53.0 (512) / 44.8 (1024)
+    int block = mn <= 16 ? 64 : mn <= 64 ? 128 : mn <= 128 ? 256 : mn <= 256 ? 512 : 1024;
     if (const char* e = getenv("DGCN_SHALLOW_BLOCK")) {  // tuning: any of 64 / 128 / 256 / 512 / 1024 that holds a vertex per thread
         const int want = atoi(e);
         if ((want == 64 || want == 128 || want == 256 || want == 512 || want == 1024) && want >= mn) block = want;

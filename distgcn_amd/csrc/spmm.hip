@@ -107,7 +107,35 @@ __device__ __forceinline__ void staged_copy(int total, LoadF load, StoreF store)
     }
 }
 
-template <int VEC, int LPR, int G, int BLOCK>
+// F64: the row sum is ONE fma chain in double (G must be 1), out = (float)((double)y0 + sum [+ (double)bias]) - the
+// contract of layer index 0 (k_spmm_f64acc below is the plain-kernel form of the same arithmetic).
+template <int VEC, int G, typename Meta, typename ZRow>
+__device__ __forceinline__ void row_sum_f64(Meta meta, int rs, int re, int foff, ZRow zrow, double (&acc)[VEC]) {
+    using V = typename VecT<VEC>::type;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
+    int j = rs;
+    for (; j + 1 < re; j += 2) {  // two entries' loads in flight, chain order unchanged
+        const ColVal m0 = meta(j), m1 = meta(j + 1);
+        const V z0 = *reinterpret_cast<const V*>(zrow(m0.col) + foff);
+        const V z1 = *reinterpret_cast<const V*>(zrow(m1.col) + foff);
+        const float* f0 = reinterpret_cast<const float*>(&z0);
+        const float* f1 = reinterpret_cast<const float*>(&z1);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = fma((double)m0.val, (double)f0[c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = fma((double)m1.val, (double)f1[c], acc[c]);
+    }
+    if (j < re) {
+        const ColVal m = meta(j);
+        const V z = *reinterpret_cast<const V*>(zrow(m.col) + foff);
+        const float* f = reinterpret_cast<const float*>(&z);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] = fma((double)m.val, (double)f[c], acc[c]);
+    }
+}
+
+template <int VEC, int LPR, int G, int BLOCK, bool F64 = false>
 __global__ __launch_bounds__(BLOCK) void k_spmm_lds(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                     const float* __restrict__ values, const int32_t* __restrict__ graph_ptr,
                                                     int tiles, int rows_per_tile, const float* __restrict__ Z, int ldz,
@@ -176,6 +204,26 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_lds(const int32_t* __restrict__ 
     for (int k = 0; k < kPre; ++k) {
         if (r0 + wave * R + k * kSlots >= r1) break;  // wave-uniform: the whole wave is past the tile
         const int v = r0 + slot + k * kSlots;
+        if constexpr (F64) {
+            static_assert(G == 1, "the double chain is sequential");
+            double accd[VEC];
+            if (csr_in_lds) row_sum_f64<VEC, G>(meta_lds, rs[k], re[k], foff, zrow_scaled, accd);
+            else row_sum_f64<VEC, G>(meta_glob, rs[k], re[k], foff, zrow_scaled, accd);
+            if (v < r1 && lane_on) {
+                V out;
+                float* o = reinterpret_cast<float*>(&out);
+                const float* yy = reinterpret_cast<const float*>(&y0[k]);
+                const float* bb = reinterpret_cast<const float*>(&bv);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    double d = accd[c];
+                    if (Y0) d = (double)yy[c] + d;
+                    if (bias) d = d + (double)bb[c];
+                    o[c] = apply_act((float)d, act);
+                }
+                *reinterpret_cast<V*>(Y + (size_t)v * ldy + foff) = out;
+            }
+        } else {
         V acc;
         if (csr_in_lds) acc = row_sum_split<VEC, G>(meta_lds, rs[k], re[k], gq, foff, LPR * R, zrow_scaled);
         else acc = row_sum_split<VEC, G>(meta_glob, rs[k], re[k], gq, foff, LPR * R, zrow_scaled);
@@ -184,126 +232,16 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_lds(const int32_t* __restrict__ 
             if (bias) acc = vadd(acc, bv);
             *reinterpret_cast<V*>(Y + (size_t)v * ldy + foff) = vact(acc, act);
         }
+        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent variant for batches of many graphs: a fixed grid of workgroups (two per CU), each walking graphs
-// g, g + grid, ...  While a workgroup's waves gather for graph g from LDS, the NEXT graph's Z slice, (col, val) pairs and
-// row bounds are already on their way from HBM into registers (issued before the row loop, stored to LDS after it), and
-// the graph after that one's four scalars (its node / entry ranges) are fetched a step earlier still - so a graph's
-// three dependent round trips (graph_ptr -> row_ptr -> bulk data) overlap two other graphs' work instead of heading
-// every workgroup's life.  k_spmm_lds issues all of that at the start of each workgroup and the chip alternates between
-// a load burst and a gather burst (4 000-graph launch: 108.7 us, 0.39 of 8 TB/s by plain B_spmm).
-// Same arithmetic: rows of 8 lanes x float4 (LPR x VEC), sequential fmaf chain in CSR order, epilogue as above.
-// Register budget (1024 threads, two workgroups per CU = 64 VGPRs): UZ vectors + UP pairs of prefetch per thread, so the
-// host only picks this kernel for graphs with ng * C / VEC <= UZ * BLOCK and nnz <= UP * BLOCK.
-template <int VEC, int LPR, int BLOCK, int UZ, int UP>
-__global__ __launch_bounds__(BLOCK, 8) void k_spmm_persist(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-                                                        const float* __restrict__ values, const int32_t* __restrict__ graph_ptr,
-                                                        int B, const float* __restrict__ Z, int ldz, int C, int zs, int max_nodes,
-                                                        int csr_cap, const float* __restrict__ Y0, int ldy0,
-                                                        const float* __restrict__ bias, int act, float* __restrict__ Y, int ldy) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    using V = typename VecT<VEC>::type;
-    float* zsm = smem;
-    ColVal* cvs = reinterpret_cast<ColVal*>(smem + (size_t)((max_nodes * zs + 3) & ~3));
-    int* rps = reinterpret_cast<int*>(cvs + csr_cap);  // [max_nodes + 1] row starts relative to the graph's first entry
-    const int per_row = C / VEC;
-    constexpr int R = 64 / LPR;
-    constexpr int kSlots = (BLOCK / 64) * R;
-    constexpr int kPre = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane % LPR, rw = lane / LPR;
-    const int slot = wave * R + rw;
-    const int foff = sub * VEC;
-    const bool lane_on = foff < C;
-    V bv = vzero<VEC>();
-    if (bias && lane_on) bv = *reinterpret_cast<const V*>(bias + foff);
-
-    V zreg[UZ];
-    int creg[UP];
-    float vreg[UP];
-    int rpreg = 0;
-    struct Ext { int n0, n1, e0, e1; };
-    auto extents = [&](int g) -> Ext {
-        Ext x = {0, 0, 0, 0};
-        if (g < B) { x.n0 = graph_ptr[g]; x.n1 = graph_ptr[g + 1]; x.e0 = row_ptr[x.n0]; x.e1 = row_ptr[x.n1]; }
-        return x;
-    };
-    auto issue = [&](const Ext& x) {  // global -> registers (nothing waits here)
-        const int ng = x.n1 - x.n0, nz = ng * per_row, ne = x.e1 - x.e0;
-#pragma unroll
-        for (int u = 0; u < UZ; ++u) {
-            const int i = threadIdx.x + u * BLOCK;
-            if (i < nz) { const int row = i / per_row, q = i - row * per_row; zreg[u] = *reinterpret_cast<const V*>(Z + (size_t)(x.n0 + row) * ldz + q * VEC); }
-        }
-#pragma unroll
-        for (int u = 0; u < UP; ++u) {
-            const int i = threadIdx.x + u * BLOCK;
-            if (i < ne) { creg[u] = col_idx[x.e0 + i]; vreg[u] = values[x.e0 + i]; }
-        }
-        if ((int)threadIdx.x <= ng) rpreg = row_ptr[x.n0 + threadIdx.x] - x.e0;  // (ng <= BLOCK - 1: checked by the host)
-    };
-    auto commit = [&](const Ext& x) {  // registers -> LDS
-        const int ng = x.n1 - x.n0, nz = ng * per_row, ne = x.e1 - x.e0;
-#pragma unroll
-        for (int u = 0; u < UZ; ++u) {
-            const int i = threadIdx.x + u * BLOCK;
-            if (i < nz) { const int row = i / per_row, q = i - row * per_row; *reinterpret_cast<V*>(zsm + row * zs + q * VEC) = zreg[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < UP; ++u) {
-            const int i = threadIdx.x + u * BLOCK;
-            if (i < ne) { ColVal m; m.col = (creg[u] - x.n0) * zs; m.val = vreg[u]; cvs[i] = m; }
-        }
-        if ((int)threadIdx.x <= ng) rps[threadIdx.x] = rpreg;
-    };
-
-    int g = blockIdx.x;
-    if (g >= B) return;
-    Ext cur = extents(g);
-    Ext nxt = extents(g + gridDim.x);
-    issue(cur);
-    commit(cur);
-    __syncthreads();
-    while (true) {
-        const int gn = g + gridDim.x;
-        const bool more = gn < B;
-        const Ext after = extents(gn + gridDim.x);  // scalars two graphs ahead
-        if (more) issue(nxt);                       // bulk data one graph ahead: in flight during the row loop
-        // ---- rows of graph g
-        const int ng = cur.n1 - cur.n0;
-        auto zrow_scaled = [&](int off) -> const float* { return zsm + off; };
-        auto meta_lds = [&](int j) -> ColVal { return cvs[j]; };
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-            if (wave * R + k * kSlots >= ng) break;  // wave-uniform
-            const int v = slot + k * kSlots;
-            int rs = 0, re = 0;
-            V y0 = vzero<VEC>();
-            if (v < ng && lane_on) {
-                rs = rps[v];
-                re = rps[v + 1];
-                if (Y0) y0 = *reinterpret_cast<const V*>(Y0 + (size_t)(cur.n0 + v) * ldy0 + foff);
-            }
-            V acc = row_sum_split<VEC, 1>(meta_lds, rs, re, 0, foff, LPR * R, zrow_scaled);
-            if (v < ng && lane_on) {
-                if (Y0) acc = vadd(y0, acc);
-                if (bias) acc = vadd(acc, bv);
-                *reinterpret_cast<V*>(Y + (size_t)(cur.n0 + v) * ldy + foff) = vact(acc, act);
-            }
-        }
-        __syncthreads();  // every gather of graph g is done: the LDS image may be replaced
-        if (!more) break;
-        commit(nxt);
-        g = gn;
-        cur = nxt;
-        nxt = after;
-        __syncthreads();
-    }
-}
-
+// (Tried in round 3 and dropped: a persistent variant - a fixed grid of two workgroups per CU walking graphs g, g + grid, ..,
+// the next graph's Z slice / pairs / row bounds prefetched into registers while the current graph's rows gather from LDS,
+// node and entry ranges fetched two and three graphs ahead, "+ Y0" operands requested first so that waiting for them does
+// not mean waiting for the prefetch (vmcnt retires in order).  131 us against 105 - 109 us for the 4 000-graph launch:
+// at 64 VGPRs (two 1024-thread workgroups per CU) the prefetch registers spill, and what the one-graph-per-workgroup
+// kernel gets for free - 16 000 workgroups in every phase of their lives at once - the pipeline has to build by hand.)
 // ---------------------------------------------------------------------------------------------
 // Global-gather variant: no graph structure needed.
 template <int VEC, int LPR, int G>
@@ -370,8 +308,8 @@ __global__ __launch_bounds__(256) void k_spmm_f64acc(const int32_t* __restrict__
     }
 }
 
-int spmm_f64acc_dispatch(const DgcnCsr* S, const float* Z, int ldz, int C, const float* Y0, int ldy0, const float* bias, int act,
-                         float* Y, int ldy, hipStream_t s) {
+static int spmm_f64acc_plain(const DgcnCsr* S, const float* Z, int ldz, int C, const float* Y0, int ldy0, const float* bias, int act,
+                             float* Y, int ldy, hipStream_t s) {
     if (S->num_rows <= 0) return DGCN_OK;
     const bool vec = (C % 4 == 0) && (ldz % 4 == 0) && ((uintptr_t)Z % 16 == 0);
     const long total = (long)S->num_rows * (vec ? C / 4 : C);
@@ -390,24 +328,19 @@ static int env_int(const char* name, int dflt) {
     return atoi(e);
 }
 
-static int spmm_cus() {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-}
 
-template <int VEC, int LPR, int G, int BLOCK>
+
+template <int VEC, int LPR, int G, int BLOCK, bool F64 = false>
 static int launch_spmm_lds(const DgcnCsr* S, const int32_t* graph_ptr, int B, int tiles, int rows_per_tile,
                            const float* Z, int ldz, int C, int zs, int csr_cap, size_t lds, const float* Y0, int ldy0,
                            const float* bias, int act, float* Y, int ldy, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<VEC, LPR, G, BLOCK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<VEC, LPR, G, BLOCK, F64>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_spmm_lds: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t("spmm", s);
-    DGCN_LAUNCH(t, (k_spmm_lds<VEC, LPR, G, BLOCK>), dim3((unsigned)tiles * (unsigned)B), dim3(BLOCK), lds, s,
+    DGCN_LAUNCH(t, (k_spmm_lds<VEC, LPR, G, BLOCK, F64>), dim3((unsigned)tiles * (unsigned)B), dim3(BLOCK), lds, s,
                        S->row_ptr, S->col_idx, S->values, graph_ptr, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, Y0,
                        ldy0, bias, act, Y, ldy);
     return check_launch("k_spmm_lds");
@@ -415,7 +348,7 @@ static int launch_spmm_lds(const DgcnCsr* S, const int32_t* graph_ptr, int B, in
 
 template <int VEC, int LPR, int G>
 static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
-                       const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s) {
+                       const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s, bool f64 = false) {
     constexpr size_t kLdsMax = 150 * 1024;    // one workgroup may own (almost) the whole 160 KB LDS
     // LDS row stride of the staged Z slice = C + pad floats.  Measured on working sets beyond the Infinity Cache
     // (tools/tune_spmm_hbm.py, 4 000 ER graphs per launch): no padding 103.3 us, one vector 107.9 us, two 107.4 us -
@@ -424,7 +357,7 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
     const int zs = (C == 1) ? 1 : C + (pad / VEC) * VEC;
     const size_t zbytes = (size_t)((max_nodes * zs + 3) & ~3) * sizeof(float);
     const int force_global = env_int("DGCN_SPMM_GLOBAL", 0);
-    if (graph_ptr && B > 0 && max_nodes > 0 && zbytes + 4096 <= kLdsMax && !force_global) {
+    if (graph_ptr && B > 0 && max_nodes > 0 && zbytes + 4096 <= kLdsMax && !force_global && (!f64 || (G == 1 && VEC == 4))) {
         // Tile = the whole graph unless the batch is too small to fill the chip; threads per
         // workgroup chosen so that every row group has about two rows.
         const int rows_env = env_int("DGCN_SPMM_ROWS", 0);
@@ -453,39 +386,20 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
         cap = min(cap, (long)((kLdsMax - zbytes) / 8));
         const int csr_cap = (int)(cap & ~3L);
         const size_t lds = zbytes + (size_t)csr_cap * 8;
-        // many graphs per CU: the persistent, prefetching variant (see k_spmm_persist)
-        if constexpr (G == 1 && VEC == 4) {
-            const int ncu_p = spmm_cus();
-            const bool want = env_int("DGCN_SPMM_PERSIST", 1) != 0 && tiles == 1 && block == 1024 && B >= env_int("DGCN_SPMM_PERSIST_MIN", 6) * ncu_p &&
-                              max_nodes <= 1023 && S->max_graph_nnz > 0 && (C % 4) == 0;
-            if (want) {
-                const long nzv = (long)max_nodes * (C / 4);
-                const int pcap = (S->max_graph_nnz + 3) & ~3;  // every graph's pairs fit by construction
-                const size_t plds = zbytes + (size_t)pcap * 8 + ((size_t)max_nodes + 1) * sizeof(int) + 16;
-                const int grid = min(B, 2 * ncu_p);
-#define DGCN_SPMM_PERSIST_CASE(UZV, UPV)                                                                                        \
-    if (nzv <= (long)UZV * 1024 && S->max_graph_nnz <= UPV * 1024 && plds <= 78 * 1024) {                                        \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_persist<4, LPR, 1024, UZV, UPV>),               \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                               \
-        if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_spmm_persist: cannot reserve %zu bytes of LDS", plds);              \
-        TimedLaunch t("spmm", s);                                                                                                \
-        DGCN_LAUNCH(t, (k_spmm_persist<4, LPR, 1024, UZV, UPV>), dim3(grid), dim3(1024), plds, s, S->row_ptr, S->col_idx, S->values, \
-                    graph_ptr, B, Z, ldz, C, zs, max_nodes, pcap, Y0, ldy0, bias, act, Y, ldy);                                  \
-        return check_launch("k_spmm_persist");                                                                                   \
-    }
-                DGCN_SPMM_PERSIST_CASE(2, 6)
-                DGCN_SPMM_PERSIST_CASE(4, 8)
-#undef DGCN_SPMM_PERSIST_CASE
-            }
-        }
 #define DGCN_SPMM_LDS(BL)                                                                                          \
-    return launch_spmm_lds<VEC, LPR, G, BL>(S, graph_ptr, B, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, lds, Y0, ldy0, \
-                                         bias, act, Y, ldy, s)
+    do {                                                                                                           \
+        if constexpr (G == 1 && VEC == 4)                                                                          \
+            if (f64) return launch_spmm_lds<VEC, LPR, 1, BL, true>(S, graph_ptr, B, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, lds, \
+                                                                   Y0, ldy0, bias, act, Y, ldy, s);                \
+        return launch_spmm_lds<VEC, LPR, G, BL>(S, graph_ptr, B, tiles, rows_per_tile, Z, ldz, C, zs, csr_cap, lds, Y0, ldy0, \
+                                                bias, act, Y, ldy, s);                                             \
+    } while (0)
         if (block == 256) DGCN_SPMM_LDS(256);
         if (block == 512) DGCN_SPMM_LDS(512);
         DGCN_SPMM_LDS(1024);
 #undef DGCN_SPMM_LDS
     }
+    if (f64) return spmm_f64acc_plain(S, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s);
     constexpr int kSlots = 256 / (LPR * G);
     int blocks = ceil_div(S->num_rows, kSlots);
     blocks = min(blocks, 256 * 16);
@@ -546,18 +460,39 @@ int spmm_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nod
     return fail(DGCN_ERR_UNSUPPORTED, "dgcn_spmm_batch: feature width C=%d not supported", C);
 }
 
+// layer index 0's aggregation: the LDS-staged kernel with the double chain when the width allows 16-byte lanes (and the
+// graphs fit), the plain kernel otherwise
+int spmm_f64acc_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, int ldz, int C,
+                         const float* Y0, int ldy0, const float* bias, int act, float* Y, int ldy, hipStream_t s) {
+    const bool aligned = (ldz % 4 == 0) && (ldy % 4 == 0) && (!Y0 || ldy0 % 4 == 0) && ((uintptr_t)Z % 16 == 0) &&
+                         ((uintptr_t)Y % 16 == 0) && (!Y0 || (uintptr_t)Y0 % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
+    if ((C % 4 == 0) && aligned && graph_ptr && B > 0) {
+#define DGCN_SPMM_F64(L) return launch_spmm<4, L, 1>(S, graph_ptr, B, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s, true)
+        if (C <= 4) DGCN_SPMM_F64(1);
+        if (C <= 8) DGCN_SPMM_F64(2);
+        if (C <= 16) DGCN_SPMM_F64(4);
+        if (C <= 32) DGCN_SPMM_F64(8);
+        if (C <= 64) DGCN_SPMM_F64(16);
+        if (C <= 128) DGCN_SPMM_F64(32);
+#undef DGCN_SPMM_F64
+    }
+    return spmm_f64acc_plain(S, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, s);
+}
+
 }  // namespace dgcn
 
 using namespace dgcn;
 
 extern "C" int dgcn_spmm_split(int32_t C) { return C > 0 ? spmm_split_for(C) : 1; }
 
-extern "C" int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const float* Z, int32_t ldz, int32_t C, const float* Y0, int32_t ldy0,
+extern "C" int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
+                                      const float* Z, int32_t ldz, int32_t C, const float* Y0, int32_t ldy0,
                                       const float* bias, int32_t act, float* Y, int32_t ldy, void* stream) {
     if (!S || !Z || !Y || !S->row_ptr || (S->nnz > 0 && (!S->col_idx || !S->values)))
         return fail(DGCN_ERR_ARG, "dgcn_spmm_f64acc_batch: null argument");
     if (C <= 0 || ldz < C || ldy < C || (Y0 && ldy0 < C)) return fail(DGCN_ERR_ARG, "dgcn_spmm_f64acc_batch: bad strides");
-    return spmm_f64acc_dispatch(S, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, (hipStream_t)stream);
+    if (S->num_rows <= 0) return DGCN_OK;
+    return spmm_f64acc_dispatch(S, graph_ptr, num_graphs, max_nodes, Z, ldz, C, Y0, ldy0, bias, act, Y, ldy, (hipStream_t)stream);
 }
 
 extern "C" int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,

@@ -128,10 +128,58 @@ __global__ __launch_bounds__(256) void k_transform_f64acc(const float* __restric
     }
 }
 
+// The hidden 32 -> (32 | 32) case of the same contract on the f64 matrix pipe: v_mfma_f64_16x16x4_f64 is exactly the
+// ascending fma chain (tools/micro/mfma_f64.hip).  One wave = one 16-row tile x all 64 columns, eight chained MFMAs per
+// 16-column block.  Operands swapped as in fused.hip's hidden_transform_f64 (A = weights, B = activations), and since the f64
+// instruction returns row 4 * reg + (lane >> 4), lane r feeds weight column 4 * (r & 3) + (r >> 2) of the block: each lane
+// ends with four CONSECUTIVE output features of one vertex = one 16-byte store.
+using f64x4t = __attribute__((ext_vector_type(4))) double;
+__global__ __launch_bounds__(256) void k_transform_mfma_f64_32x64(const float* __restrict__ H, int ldh, int rows,
+                                                                  const float* __restrict__ W, float* __restrict__ Z, int ldz) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int rc = 4 * (r & 3) + (r >> 2);
+    float b[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + rc];
+    const int tiles = (rows + 15) >> 4;
+    for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+        const int row = t * 16 + r;
+        const int rl = row < rows ? row : rows - 1;  // (rows past the end feed the last row and store nothing)
+        float av[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) av[s] = H[(size_t)rl * ldh + 4 * s + kq];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            f64x4t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float b0 = b[s][2 * cp], b1 = b[s][2 * cp + 1], a0 = av[s];
+                asm volatile("" : "+v"(b0), "+v"(b1), "+v"(a0));  // (keeps the conversions inside the loop: 64 fewer registers)
+                const double ad = (double)a0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b0, ad, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b1, ad, acc1, 0, 0, 0);
+            }
+            if (row < rows) {
+                float* dst = Z + (size_t)row * ldz + (2 * cp) * 16 + 4 * kq;
+                *reinterpret_cast<float4*>(dst) = make_float4((float)acc0[0], (float)acc0[1], (float)acc0[2], (float)acc0[3]);
+                *reinterpret_cast<float4*>(dst + 16) = make_float4((float)acc1[0], (float)acc1[1], (float)acc1[2], (float)acc1[3]);
+            }
+        }
+    }
+}
+
 int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, int cin, const float* W, int ctot, float* Z,
                               int ldz, hipStream_t s) {
     if (rows <= 0) return DGCN_OK;
     TimedLaunch t("transform", s);
+    if (H && cin == 32 && ctot == 64 && (ldz % 4 == 0) && ((uintptr_t)Z % 16 == 0)) {
+        const int blocks = min(ceil_div(rows, 64), 256 * 8);
+        DGCN_LAUNCH(t, k_transform_mfma_f64_32x64, dim3(blocks), dim3(256), 0, s, H, ldh, rows, W, Z, ldz);
+        return check_launch("k_transform_mfma_f64_32x64");
+    }
     const long total = (long)rows * ctot;
     const int blocks = (int)min((total + 255) / 256, (long)256 * 32);
     DGCN_LAUNCH(t, k_transform_f64acc, dim3(blocks), dim3(256), 0, s, H, ldh, h_const, rows, cin, W, ctot, Z, ldz);

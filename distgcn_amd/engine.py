@@ -211,7 +211,8 @@ class Engine:
             out = t.empty((n, C_feat), dtype=t.float32, device=self.device)
         if precise:
             _lib.check(self.lib.dgcn_spmm_f64acc_batch(
-                C.byref(csr["c"]), Z.data_ptr(), ldz, C_feat, Y0.data_ptr() if Y0 is not None else None, ldy0,
+                C.byref(csr["c"]), graph_ptr.data_ptr() if graph_ptr is not None else None, num_graphs, max_nodes,
+                Z.data_ptr(), ldz, C_feat, Y0.data_ptr() if Y0 is not None else None, ldy0,
                 bias.data_ptr() if bias is not None else None, ACT_CODES[act], out.data_ptr(), int(out.shape[-1]),
                 self._stream()), "dgcn_spmm_f64acc_batch")
             return out

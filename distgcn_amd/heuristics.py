@@ -29,10 +29,11 @@ def _run_native(eng, adj, w):
     a = as_csr(adj)
     if a.shape[0] != w.size:
         raise ValueError("adjacency has %d vertices, weights %d" % (a.shape[0], w.size))
-    h = hs.solve([a.indptr], [a.indices], [w])
-    state = h["state"]
-    return {"state": state, "mwis": set(np.flatnonzero(state == 1).tolist()), "total": np.float64(h["totals"][0]),
-            "rounds": int(h["rounds"][0])}
+    with hs.lock:  # (another thread's call would overwrite the slot's result buffer)
+        h = hs.solve([a.indptr], [a.indices], [w])
+        state = h["state"].copy()
+        return {"state": state, "mwis": set(np.flatnonzero(state == 1).tolist()), "total": np.float64(h["totals"][0]),
+                "rounds": int(h["rounds"][0])}
 
 
 def _run(adj, wts, max_rounds=0, want_stats=False, want_overhead=False):

@@ -159,10 +159,11 @@ def solve_csr_lists(eng, model, indptrs, indices, weights, predict: str = "mwis"
         # the reference's call pattern - one graph (or a handful) per call: everything behind two native calls
         try:
             hs = _host_solver(eng, model, predict)
-            res = hs.solve(indptrs, indices, w64)
+            with hs.lock:  # (shared by every caller thread: the result is copied out before the next call may overwrite it)
+                res = {k: np.array(v) for k, v in hs.solve(indptrs, indices, w64).items()}
+                gp = np.zeros(len(indptrs) + 1, np.int32)
+                np.cumsum(hs._nn, out=gp[1:])
             res["scores"] = res["scores"].reshape(-1, 1)
-            gp = np.zeros(len(indptrs) + 1, np.int32)
-            np.cumsum(hs._nn, out=gp[1:])
             return res, gp
         except (TypeError, BufferError):  # mixed index widths / non-contiguous arrays: the NumPy packer handles those
             pass

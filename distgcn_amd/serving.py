@@ -216,6 +216,10 @@ class HostSolver:
                                                         C.byref(self.handle)),
                        "dgcn_host_solver_create")
         self.depth = int(depth)
+        # the process-wide one-slot instances behind heuristics.* / solve_mwis are shared by every caller thread: a call and
+        # the reading of its result (views into the slot's pinned memory) happen under this lock
+        import threading
+        self.lock = threading.RLock()
         self._p = [C.c_void_p() for _ in range(4)]
         self._i = [C.c_int32() for _ in range(3)]
         # one-call path of the CPython helper (csrc/pyptr.c): submit + result without the interpreter in between

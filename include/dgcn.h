@@ -115,17 +115,18 @@ int dgcn_pack_batch(const void* const* indptr_host, const void* const* indices_h
                     const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes,
                     void* staging_host, size_t staging_bytes, DgcnPackInfo* info, int32_t num_threads);
 
-/* The compact TRANSFER format of the same batch: what has to cross PCIe for symmetric graphs with sorted rows is the upper
- * triangle with 16-bit local column ids and a 16-bit count per vertex - a third of the bytes (C3: 3.0 MB instead of 9.2):
- *   [graph_ptr int32[B+1] | up_ptr int32[B+1] (upper entries before graph g) | updeg uint16[N] | upcol uint16[E/2] | weights float64[N]]
- * dgcn_pack_compact_layout: offsets from the ordinary DgcnPackInfo (dgcn_pack_measure).  dgcn_pack_compact_batch: writes it;
- * returns 0, < 0 (structural error), or 1 = "not compactable" - a graph that is not symmetric by count, has an unsorted /
- * repeated / self entry or more than 65 535 vertices: pack the ordinary format then (its kernels report such data faults);
- * fills info->max_degree.  dgcn_expand_compact_batch (device, one launch, graphs of <= 512 vertices): rebuilds
- * row_ptr[num_nodes + 1] and col_idx[num_edges] - entry for entry what dgcn_pack_batch writes for the same graphs; graph_ptr
- * and weights are used where they lie in the compact buffer.  dgcn_host_solver_* does all of this by itself. */
+/* The compact TRANSFER format of the same batch: 16-bit LOCAL column ids and a 16-bit degree per vertex instead of 32-bit
+ * global ids and row pointers - what crosses PCIe (and what the packing loop has to write) is about half the bytes
+ * (C3: 5.0 MB instead of 9.2):
+ *   [graph_ptr int32[B+1] | edge_ptr int32[B+1] (entries before graph g) | deg uint16[N] | col uint16[E] | weights float64[N]]
+ * dgcn_pack_compact_layout: offsets from the ordinary DgcnPackInfo (dgcn_pack_measure).  dgcn_pack_compact_batch: writes it
+ * with the same validation as dgcn_pack_batch; returns 0, < 0 (structural error), or 1 = "not compactable" (a graph of more
+ * than 65 535 vertices, a vertex of more than 65 535 neighbours): pack the ordinary format then; fills info->max_degree.
+ * dgcn_expand_compact_batch (device, one launch): rebuilds row_ptr[num_nodes + 1] and col_idx[num_edges] - entry for entry
+ * what dgcn_pack_batch writes for the same graphs, entry order included; graph_ptr and weights are used where they lie in
+ * the compact buffer.  dgcn_host_solver_* does all of this by itself for batches it copies to the device. */
 typedef struct DgcnCompactInfo {
-    int64_t off_graph_ptr, off_up_ptr, off_updeg, off_upcol, off_weights; /* byte offsets; off_weights = -1 without weights */
+    int64_t off_graph_ptr, off_edge_ptr, off_deg, off_col, off_weights; /* byte offsets; off_weights = -1 without weights */
     int64_t total_bytes;
 } DgcnCompactInfo;
 int dgcn_pack_compact_layout(const DgcnPackInfo* info, DgcnCompactInfo* compact);
@@ -183,7 +184,8 @@ int dgcn_spmm_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_grap
 /* The same aggregation with the row sum carried in double: ONE fma chain over the row's entries in CSR order starting
  * from 0.0, then (double)Y0 + sum, then + (double)bias, rounded to float32 once, activation in float32.  This is the
  * contract of LAYER INDEX 0 in every forward / solve entry point below (see "Precision" at dgcn_gcn_forward_batch). */
-int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const float* Z, int32_t ldz, int32_t C,
+int dgcn_spmm_f64acc_batch(const DgcnCsr* S, const int32_t* graph_ptr, int32_t num_graphs, int32_t max_nodes,
+                           const float* Z, int32_t ldz, int32_t C,
                            const float* Y0, int32_t ldy0, const float* bias, int32_t act,
                            float* Y, int32_t ldy, void* stream);
 

@@ -1236,11 +1236,10 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
 
 
 def test_host_solver_compact_transfer(engine, monkeypatch):
-    """Batches above the in-place threshold cross PCIe in the compact form (upper triangle, 16-bit ids: include/dgcn.h
+    """Batches above the in-place threshold cross PCIe in the compact form (16-bit local column ids + degrees: include/dgcn.h
     DgcnCompactInfo) and are expanded on the device (csrc/expand.hip): same sets / rounds / totals / scores as the ordinary
-    transfer (DGCN_HOST_COMPACT=0) and as the twin, on the BA mix (hubs, 100..300 vertices) and an ER batch; a batch holding
-    one graph with an unsorted row cannot be compacted and silently takes the ordinary format - results follow the
-    caller's entry order, as they always did."""
+    transfer (DGCN_HOST_COMPACT=0) and as the twin, on the BA mix (hubs, 100..300 vertices), an ER batch, and a batch with an
+    unsorted row (entry order is the caller's, in both forms); the plain greedy search (no model) goes the same way."""
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
     from distgcn_amd.engine import DeviceModel
@@ -1261,26 +1260,24 @@ def test_host_solver_compact_transfer(engine, monkeypatch):
             ps.append(p); cs.append(c); ws.append(hb.weights[n0:n1].copy())
         return ps, cs, ws
 
-    for hb in (datagen.ba_test2_batch(120, first_index=300), datagen.er_batch(150, 200, 0.1, first_index=7000)):
+    cases = [lists(datagen.ba_test2_batch(120, first_index=300)), lists(datagen.er_batch(150, 200, 0.1, first_index=7000)),
+             lists(datagen.er_batch(150, 200, 0.1, first_index=7000), scramble=17)]
+    for ps, cs, ws in cases:
+        hb = HostBatch.from_csr_lists(ps, cs, ws)
         ref = ctwin.solve(hb, layers)
-        got = {}
         for mode in ("1", "0"):
             monkeypatch.setenv("DGCN_HOST_COMPACT", mode)
             hs = HostSolver(engine, dm, depth=2, want_scores=True)
-            got[mode] = [hs.solve(*lists(hb)) for _ in range(2)][-1]
+            g = [hs.solve(ps, cs, ws) for _ in range(2)][-1]
             hs.close()
-        for mode in ("1", "0"):
-            g = got[mode]
             assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["rounds"], ref["rounds"]), mode
             assert np.allclose(g["totals"], ref["totals"], rtol=1e-12, atol=0)
             assert np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32)), mode
-    # not compactable: one unsorted row -> ordinary transfer, entry order as given
+    ps, cs, ws = cases[0]
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
+    want = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, hb.weights, sum_weights=hb.weights, want_stats=False)
     monkeypatch.setenv("DGCN_HOST_COMPACT", "1")
-    hb = datagen.er_batch(150, 200, 0.1, first_index=7000)
-    ps, cs, ws = lists(hb, scramble=17)
-    hbs = HostBatch.from_csr_lists(ps, cs, ws)
-    ref = ctwin.solve(hbs, layers)
-    hs = HostSolver(engine, dm, depth=2, want_scores=True)
+    hs = HostSolver(engine, None, depth=2)
     g = hs.solve(ps, cs, ws)
     hs.close()
-    assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32))
+    assert np.array_equal(g["state"], want["state"]) and np.array_equal(g["rounds"], want["rounds"])

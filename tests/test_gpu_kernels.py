@@ -830,30 +830,6 @@ def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     assert int(r["status"].cpu().numpy()[0]) & 1
 
 
-@pytest.mark.parametrize("C", [4, 16, 32, 64])
-def test_spmm_persistent_variant_bit_exact(engine, golden, C, monkeypatch):
-    """k_spmm_persist (csrc/spmm.hip): a fixed grid of workgroups walking many graphs each, the next graph's Z slice /
-    (col, val) pairs / row bounds prefetched into registers during the current graph's gathers.  Forced on for small
-    batches (DGCN_SPMM_PERSIST_MIN=0) - the ragged fixture batch, where most workgroups get one graph, and 3 000 small ER
-    graphs, where every workgroup walks five or six - and compared with the twin bit for bit, with and without epilogue."""
-    from distgcn_amd import datagen
-    from oracle import ctwin
-    monkeypatch.setenv("DGCN_SPMM_PERSIST_MIN", "0")
-    for hb in (golden.host_batch(), datagen.er_batch(3000, 60, 0.1, first_index=5000)):
-        db = engine.upload(hb)
-        lap = engine.supports(db)
-        lrp, lc, lv, _ = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)
-        rng = np.random.default_rng(C)
-        Z = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
-        Y0 = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
-        bias = rng.standard_normal(C).astype(np.float32)
-        kw = dict(graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs, max_nodes=hb.max_nodes)
-        got = engine.spmm(lap, _dev(engine, Z), C, **kw).cpu().numpy()
-        assert np.array_equal(got.view(np.uint32), ctwin.spmm(lrp, lc, lv, Z, C).view(np.uint32))
-        got = engine.spmm(lap, _dev(engine, Z), C, Y0=_dev(engine, Y0), ldy0=C, bias=_dev(engine, bias), act="leaky_relu", **kw).cpu().numpy()
-        assert np.array_equal(got.view(np.uint32), ctwin.spmm(lrp, lc, lv, Z, C, Y0=Y0, bias=bias, act=1).view(np.uint32))
-
-
 def test_precise_kernels_bit_exact(engine, golden):
     """dgcn_spmm_f64acc_batch / dgcn_transform_f64acc_batch (the contract of layer index 0 / layer index 1: chains carried in
     double, rounded once) against the twin, and against a float64 SciPy / NumPy evaluation rounded to float32 where the
@@ -870,9 +846,10 @@ def test_precise_kernels_bit_exact(engine, golden):
         Z = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
         Y0 = rng.standard_normal((hb.num_nodes, C)).astype(np.float32)
         bias = rng.standard_normal(C).astype(np.float32)
-        got = engine.spmm(lap, _dev(engine, Z), C, Y0=_dev(engine, Y0), ldy0=C, bias=_dev(engine, bias), act="leaky_relu", precise=True).cpu().numpy()
         want = ctwin.spmm(lrp, lc, lv, Z, C, Y0=Y0, bias=bias, act=1, precise=True)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), C
+        for kw in (dict(), dict(graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs, max_nodes=hb.max_nodes)):  # plain kernel / LDS-staged
+            got = engine.spmm(lap, _dev(engine, Z), C, Y0=_dev(engine, Y0), ldy0=C, bias=_dev(engine, bias), act="leaky_relu", precise=True, **kw).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (C, bool(kw))
         got = engine.spmm(lap, _dev(engine, Z), C, precise=True).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), ctwin.spmm(lrp, lc, lv, Z, C, precise=True).view(np.uint32)), C
         S = sp.csr_matrix((lv.astype(np.float64), lc, lrp), shape=(hb.num_nodes, hb.num_nodes))

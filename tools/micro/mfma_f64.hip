@@ -153,8 +153,8 @@ int main() {
             double a = 0;
             for (int g = 0; g < 256; ++g) for (int w = 0; w < waves; ++w) a += (double)c[g * 16 + w];
             a /= 256.0 * waves;
-            // s_memtime ticks at 100 MHz; shader clock ~2.4 GHz
-            printf("%2d waves/CU  %-28s %9.0f ticks  -> %.2f ticks per instruction per wave (x24 = shader cycles at 2.4 GHz), %.2f per SIMD-instruction\n",
+            // (s_memtime counts shader cycles on this part: v_mfma_f32_16x16x4_f32 reads 32.0 with one wave per SIMD)
+            printf("%2d waves/CU  %-28s %9.0f cycles  -> %.2f cycles per instruction per wave, %.2f per SIMD-instruction\n",
                    waves, names[m], a, a / (iters * per_iter[m]), a / (iters * per_iter[m]) / (waves / 4.0));
         }
     return 0;
