@@ -303,7 +303,9 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
     // (Tried in round 3 and dropped: dealing the rows so that every wave gets a full first pass from the head of the
     // descending order plus an equal share of the short rows - an N = 200 graph's 13 blocks otherwise leave three waves
     // with one pass and five with two.  208 us against 200 us per C3 launch: the waves that finish early are what lets the
-    // co-resident workgroup's transform through.)
+    // co-resident workgroup's transform through.  Also: the second workgroup of a CU handing its left-over tiles / row blocks
+    // - the 9th .. 13th of an N = 200 graph - to waves one further on, so that the SIMD with four tiles instead of three is
+    // not the same one for both: 200.4 - 201.0 against 201.0 - 202.0 us in the same build, inside the noise.)
 #pragma unroll
     for (int k = 0; k < kMaxRowBlocks; ++k) {
         // (cluster variant: workgroup cw of K owns blocks cw, cw + K, ...)
