@@ -35,6 +35,7 @@
 #include <random>
 
 #include "common.h"
+#include <type_traits>
 
 namespace dgcn {
 
@@ -57,7 +58,7 @@ struct FusedArgs {
     const int32_t* row_ptr;
     const int32_t* col_idx;
     const float* vals;         // values of the given support CSR; unused when from_adj
-    uint2* grec;               // [num_graphs][meta_cap] entry records {value bits, gather word} for the hidden aggregation
+    uint2* grec;               // [num_graphs][rec_cap] entry records {value bits, gather word} for the hidden aggregation
     float* gvals;              // k_fused<*, true>: [num_graphs][meta_cap] entry values kept in global memory
     const double* dinv_table;  // from_adj: float64 d^-1/2 table
     int32_t table_len;
@@ -75,6 +76,7 @@ struct FusedArgs {
     int32_t num_layers;
     int32_t max_nodes;
     int32_t meta_cap;
+    int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
@@ -282,48 +284,81 @@ __device__ __forceinline__ float4 lds_chunk(unsigned addr) {
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
-// What a lane needs to start on its (up to four) row blocks of the aggregation: the row, its entry range and the record
-// of its first entry.  None of it changes from layer to layer, so it is read once per graph and stays in registers: a
-// block starts with its gathers instead of three dependent round trips (perm -> rinfo -> record).
+// The hidden aggregation's entry records, block-major (round 3).  The rows of a graph go through the aggregation in
+// blocks of 16 (`perm` order: descending entry count), one block per wave pass, four entries of every row per trip.  A
+// block of T trips owns 64 T records: record 64 t + lane is entry 4 t + (lane & 3) of the row in slot lane >> 2, or the
+// neutral record {-0.0f, zero row} past the row's end - fmaf(-0.0f, +0.0f, acc) == acc for every acc, so a short row
+// rides along to the block's trip count (that of its first row) without a compare, and the last 1..3 entries of a row
+// need no code of their own.  What this buys: a trip's record load is 512 consecutive bytes behind a wave-uniform
+// base, the trip count sits in a scalar register, and the per-lane bookkeeping of the row-major records (entry index,
+// row end, compare, exec mask: 6 of 42 vector instructions per trip, on a phase that is paced by vector issue) is gone.
+// The wave that gathers a block writes its records itself (same lane, same address: no barrier between).
 constexpr int kMaxRowBlocks = 2;  // per wave: 256 vertices on 8 waves, 512 on 16 (larger graphs never get 512-thread workgroups)
-struct RowBlocks {
-    int trow[kMaxRowBlocks];     // cluster variant: row of lane & 15 in block k (the transform's lane map), -1 = none
-    int v[kMaxRowBlocks];        // row of this lane's slot in block k, -1 = none
-    unsigned ri[kMaxRowBlocks];  // rinfo of that row
-    uint2 first[kMaxRowBlocks];  // record of entry kq of the row
+struct RowBlock {
+    int v;            // row of this lane's slot in the block, -1 = none
+    int trips;        // trips of the block (wave-uniform), 0 = no such block
+    unsigned base;    // first record of the block (wave-uniform)
+    unsigned fx, fy;  // this lane's record of trip 0 {value bits, gather word}
+};
+struct RowBlocks {  // (two named members, not an array: the kernel has no scratch memory, and an array that is not split
+    RowBlock b0, b1;  // into registers early enough would sit there)
+    template <int K> __device__ __forceinline__ RowBlock& at() { if constexpr (K == 0) return b0; else return b1; }
+    template <int K> __device__ __forceinline__ const RowBlock& at() const { if constexpr (K == 0) return b0; else return b1; }
 };
 
 template <int BLOCK>
 __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                const uint2* rec, int K = 1, int cw = 0) {
+                                                const float* vals, const unsigned short* words, uint2* rec, unsigned zrow) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     constexpr int kWaves = BLOCK / 64;
-    const int blocks = (ng + 15) >> 4;
+    const int blocks = (ng + 15) >> 4;  // <= 32
+    // trips of block `lane` and the records in front of it (every wave computes the same table: one scan, once per graph)
+    const int tl = lane < blocks ? (int)(((rinfo[perm[lane * 16]] >> 16) + 3) >> 2) : 0;
+    int incl = tl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
     // (Tried in round 3 and dropped: dealing the rows so that every wave gets a full first pass from the head of the
     // descending order plus an equal share of the short rows - an N = 200 graph's 13 blocks otherwise leave three waves
     // with one pass and five with two.  208 us against 200 us per C3 launch: the waves that finish early are what lets the
     // co-resident workgroup's transform through.  Also: the second workgroup of a CU handing its left-over tiles / row blocks
     // - the 9th .. 13th of an N = 200 graph - to waves one further on, so that the SIMD with four tiles instead of three is
     // not the same one for both: 200.4 - 201.0 against 201.0 - 202.0 us in the same build, inside the noise.)
-#pragma unroll
-    for (int k = 0; k < kMaxRowBlocks; ++k) {
-        // (cluster variant: workgroup cw of K owns blocks cw, cw + K, ...)
-        const int blk = (k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave)) * K + cw;
+    const uint2 nothing = make_uint2(0x80000000u, zrow);
+    // (one call per block instead of an unrolled loop: with the record loop inside it the loop is unrolled only after the
+    // pass that turns `rb` into registers has run, and the kernel would keep it in scratch memory)
+    auto one_block = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
+        const int src = blk < blocks ? blk : 0;
+        const int trips = blk < blocks ? __shfl(tl, src) : 0;
+        const unsigned base = (unsigned)(__shfl(incl, src) - __shfl(tl, src)) * 64u;
+        RowBlock& B = rb.template at<k>();
+        B.trips = __builtin_amdgcn_readfirstlane(trips);
+        B.base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         const int slot = blk * 16 + s;
-        const int tslot = blk * 16 + (lane & 15);
-        rb.trow[k] = (blk < blocks && tslot < ng) ? (int)perm[tslot] : -1;
         const bool has = blk < blocks && slot < ng;
-        rb.v[k] = -1;
-        rb.ri[k] = 0u;
-        rb.first[k] = make_uint2(0u, 0u);
-        if (has) {
-            const int v = perm[slot];
-            rb.v[k] = v;
-            rb.ri[k] = rinfo[v];
-            rb.first[k] = rec[(rb.ri[k] & 0xffff) + kq];
+        B.v = has ? (int)perm[slot] : -1;
+        const unsigned ri = has ? rinfo[B.v] : 0u;
+        const int start = ri & 0xffff, cnt = ri >> 16;
+        uint2 r0 = nothing;
+        if (kq < cnt) r0 = make_uint2(__float_as_uint(vals[start + kq]), (unsigned)words[start + kq]);
+        B.fx = r0.x;
+        B.fy = r0.y;
+        uint2* out = rec + B.base + lane;
+        for (int t = 0; t < B.trips; ++t) {
+            const int e = 4 * t + kq;
+            uint2 r = nothing;
+            if (e < cnt) r = make_uint2(__float_as_uint(vals[start + e]), (unsigned)words[start + e]);
+            out[t * 64] = r;
         }
-    }
+    };
+    static_assert(kMaxRowBlocks == 2, "one call per row block");
+    one_block(std::integral_constant<int, 0>{});
+    one_block(std::integral_constant<int, 1>{});
 }
 
 // ---- cluster variant: one graph on K workgroups (one CU each) --------------------------------------------------
@@ -581,8 +616,9 @@ template <> struct RowAcc<true> {
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
 template <int BLOCK, int ACT, bool BIAS, bool F64 = false>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
-                                                 const uint2* rec, unsigned zrow, unsigned long long* st, bool const_rows = false) {
+                                                 const uint2* rec, const unsigned* rinfo_lds, unsigned long long* st, bool const_rows = false) {
     (void)st;
+    (void)rinfo_lds;
 #ifdef DGCN_DIAG
 #define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) st[i] += _t - bt; bt = _t; } while (0)
     unsigned long long bt = 0;
@@ -603,18 +639,19 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         biasB = *reinterpret_cast<const float4*>(bias_ptr + 4 * csecond);
     }
     (void)kWaves;
-#pragma unroll
-    for (int k = 0; k < kMaxRowBlocks; ++k) {
-        if (!__any(rb.v[k] >= 0)) continue;
-        if (rb.v[k] < 0) continue;
+    // (one call per block, not an unrolled loop: see row_blocks_init)
+    auto one_block = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const RowBlock& B = rb.template at<k>();
+        const int trips = B.trips;  // (wave-uniform: a scalar register)
+        if (trips == 0) return;
+        if (B.v < 0) return;        // (slots past the graph's last row: their lanes sit the block out)
 #ifdef DGCN_DIAG
         bt = __builtin_amdgcn_s_memtime();
 #endif
-        int v = rb.v[k];
+        int v = B.v;
         asm volatile("" : "+v"(v));  // (opaque: what derives from the row - swizzle keys, addresses - is formed here, per layer,
                                      // instead of being hoisted out of the layer loop into registers the kernel does not have)
-        const unsigned ri = rb.ri[k];
-        const int rs = ri & 0xffff, re = rs + (ri >> 16);
         RowAcc<F64> accA, accB;
         accA.clear();
         accB.clear();
@@ -626,25 +663,26 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         BSTAMP(0);
         // Entry metadata comes from GLOBAL memory, not from the LDS: the gather phase is paced by the LDS instruction
         // stream (an LDS round trip takes ~450 cycles there: 16 waves x 8 ds_read_b128 queued), and the two metadata
-        // reads per trip were a quarter of it.  A lane loads ONE 8-byte record {value, word} per trip - entry j + kq of
-        // its row, 64 distinct addresses per wave - one trip ahead; the four lanes of a row then hand their entries
-        // round with quad-broadcast DPP moves (the row's lanes are a quad).  A row's last 1..3 entries run as one more
-        // trip whose missing entries are neutralised in the owning lane: value -0.0f on the zero row, and
-        // fmaf(-0.0f, +0.0f, acc) == acc for every acc.
+        // reads per trip were a quarter of it.  A lane loads ONE 8-byte record {value, word} per trip - entry 4 t + kq of
+        // its row: record 64 t + lane of the block, 512 consecutive bytes per wave (row_blocks_init) - one trip ahead;
+        // the four lanes of a row then hand their entries round with quad-broadcast DPP moves (the row's lanes are a quad).
         // (Tried and dropped: issuing the 8 gathers of trip t + 1 before the 16 packed FMAs of trip t - uniform trip count
         // from the block's first row, ping-pong buffers, no spills: 211.8 us against 205.2 us per C3 launch.)
-        int j = rs;
-        uint2 cur = rb.first[k];
-#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, false)
-#define DGCN_TRIP(NE)                                                                                          \
+        const char* bp = reinterpret_cast<const char*>(rec + B.base);  // wave-uniform: scalar registers
+        const unsigned voff = (unsigned)lane * 8u;
+        uint2 cur = make_uint2(B.fx, B.fy);
+        asm volatile("" : "+v"(cur.x), "+v"(cur.y));  // (opaque: or the compiler merges this with the loop's load into ONE load through
+                                                      // a pointer that starts at the kernel's stack - a flat load, used at once, per trip)
+#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, true)
+#define DGCN_TRIP(R, NE)                                                                                         \
         {                                                                                                      \
             float4 zA[NE], zB[NE];                                                                             \
             float av[NE];                                                                                      \
             _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                   \
-                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(cur.y, 0) : e == 1 ? DGCN_QB(cur.y, 1)          \
-                                              : e == 2 ? DGCN_QB(cur.y, 2) : DGCN_QB(cur.y, 3));               \
-                av[e] = __int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)                 \
-                                       : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));                      \
+                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(R.y, 0) : e == 1 ? DGCN_QB(R.y, 1)          \
+                                              : e == 2 ? DGCN_QB(R.y, 2) : DGCN_QB(R.y, 3));               \
+                av[e] = __int_as_float(e == 0 ? DGCN_QB(R.x, 0) : e == 1 ? DGCN_QB(R.x, 1)                 \
+                                       : e == 2 ? DGCN_QB(R.x, 2) : DGCN_QB(R.x, 3));                      \
                 zA[e] = lds_chunk(w ^ cA);                                                                     \
                 zB[e] = lds_chunk(w ^ cB);                                                                     \
             }                                                                                                  \
@@ -655,59 +693,66 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         }
         // (chains in double: two entries' gathers in flight instead of four - with 16 accumulator registers and the
         // conversions on top, four would push the row-block state into scratch memory; once per launch, the pace does not matter)
-#define DGCN_TRIP_PAIR(E0, NE)                                                                                 \
+#define DGCN_TRIP_PAIR(R, E0, NE)                                                                                \
         {                                                                                                      \
             _Pragma("unroll") for (int e = (E0); e < (E0) + 2 && e < (NE); ++e) {                              \
-                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(cur.y, 0) : e == 1 ? DGCN_QB(cur.y, 1)          \
-                                              : e == 2 ? DGCN_QB(cur.y, 2) : DGCN_QB(cur.y, 3));               \
-                const float a1 = __int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)        \
-                                                : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));             \
+                const unsigned w = (unsigned)(e == 0 ? DGCN_QB(R.y, 0) : e == 1 ? DGCN_QB(R.y, 1)          \
+                                              : e == 2 ? DGCN_QB(R.y, 2) : DGCN_QB(R.y, 3));               \
+                const float a1 = __int_as_float(e == 0 ? DGCN_QB(R.x, 0) : e == 1 ? DGCN_QB(R.x, 1)        \
+                                                : e == 2 ? DGCN_QB(R.x, 2) : DGCN_QB(R.x, 3));             \
                 accA.add(a1, lds_chunk(w ^ cA));                                                               \
                 accB.add(a1, lds_chunk(w ^ cB));                                                               \
             }                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
+        bool walked = false;
         if constexpr (F64) {
             if (const_rows) {
                 // Constant input features (X == NULL: every reference script's case): all rows of Z1 are the SAME 32 numbers,
                 // so the chain fma(val_j, Z1[u_j][c], acc) needs the entries' values only - no gathers.  Same chain, same bits.
+                // (The neutral records do not serve here: -0.0 times a NEGATIVE feature is +0.0, and -0.0 + +0.0 is +0.0 - so
+                // the entries past the row's end are skipped by count.  A quad = one row: the test is uniform in it.)
                 const float4 fA = lds_chunk(cA), fB = lds_chunk(cB);  // row 0 of bufB (keyB(0) = 0: chunk c sits at byte 16 c)
                 const double dA[4] = {(double)fA.x, (double)fA.y, (double)fA.z, (double)fA.w};
                 const double dB[4] = {(double)fB.x, (double)fB.y, (double)fB.z, (double)fB.w};
-                for (; j + 4 <= re; j += 4) {
-                    const uint2 nxt = rec[j + 4 + kq];
+                const int cnt = (int)(rinfo_lds[v] >> 16);
+                for (int t = 0; t < trips; ++t) {
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(bp + (t + 1) * 512 + voff);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const double ad = (double)__int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1)
                                                                  : e == 2 ? DGCN_QB(cur.x, 2) : DGCN_QB(cur.x, 3));
-                        accA.add_d(ad, dA);
-                        accB.add_d(ad, dB);
+                        if (4 * t + e < cnt) {
+                            accA.add_d(ad, dA);
+                            accB.add_d(ad, dB);
+                        }
                     }
                     cur = nxt;
                 }
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {  // the row's last 1..3 entries (a quad = one row: the test is uniform in it)
-                    const double ad = (double)__int_as_float(e == 0 ? DGCN_QB(cur.x, 0) : e == 1 ? DGCN_QB(cur.x, 1) : DGCN_QB(cur.x, 2));
-                    if (j + e < re) {
-                        accA.add_d(ad, dA);
-                        accB.add_d(ad, dB);
-                    }
-                }
-                j = re;
+                walked = true;
             }
         }
-        for (; j + 4 <= re; j += 4) {
-            const uint2 nxt = rec[j + 4 + kq];  // may be the next row's entry or slack: neutralised below if so
-            if constexpr (F64) { DGCN_TRIP_PAIR(0, 4) DGCN_TRIP_PAIR(2, 4) }
-            else DGCN_TRIP(4)
-            cur = nxt;
+        if (!walked) {
+            if constexpr (F64) {
+                for (int t = 0; t < trips; ++t) {
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(bp + (t + 1) * 512 + voff);
+                    DGCN_TRIP_PAIR(cur, 0, 4) DGCN_TRIP_PAIR(cur, 2, 4)
+                    cur = nxt;
+                }
+            } else {
+                // two trips per turn, so that the record loaded ahead is used where it landed (no register moves)
+                uint2 nxt;
+                int t = 0;
+                for (; t + 1 < trips; t += 2) {
+                    nxt = *reinterpret_cast<const uint2*>(bp + (t + 1) * 512 + voff);
+                    DGCN_TRIP(cur, 4)
+                    cur = *reinterpret_cast<const uint2*>(bp + (t + 2) * 512 + voff);  // (past the last trip: the next block's first record, or slack)
+                    DGCN_TRIP(nxt, 4)
+                }
+                if (trips & 1) DGCN_TRIP(cur, 4)
+            }
         }
         BSTAMP(1);
-        if (j < re) {
-            if (j + kq >= re) cur = make_uint2(0x80000000u, zrow);
-            if constexpr (F64) { DGCN_TRIP_PAIR(0, 3) DGCN_TRIP_PAIR(2, 3) }
-            else DGCN_TRIP(3)
-        }
 #undef DGCN_TRIP_PAIR
 #undef DGCN_TRIP
 #undef DGCN_QB
@@ -720,9 +765,11 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         *ownB = oB;
         BSTAMP(3);
 #ifdef DGCN_DIAG
-        if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) { st[4] += 1; st[5] += (unsigned long long)((re - rs) >> 2); }
+        if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) { st[4] += 1; st[5] += (unsigned long long)trips; }
 #endif
-    }
+    };
+    one_block(std::integral_constant<int, 0>{});
+    one_block(std::integral_constant<int, 1>{});
 #undef BSTAMP
 }
 
@@ -779,7 +826,7 @@ __device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* b
     float4* own = reinterpret_cast<float4*>(bufA + v * kHid + ((q ^ (v & 7)) << 2));
     const float4 y = *own;  // the row's Z0 chunk, requested ahead of the gathers (registers are plentiful here)
     int j = rs;
-#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, false)
+#define DGCN_QB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, true)
 #define DGCN_PICK(x, e) ((e) == 0 ? DGCN_QB(x, 0) : (e) == 1 ? DGCN_QB(x, 1) : (e) == 2 ? DGCN_QB(x, 2) : DGCN_QB(x, 3))
     // one trip: entries 0..3 from record r0 (lane kq of the quad holds entry kq), 4..7 from r1
 #define DGCN_TRIP8C(r0, r1)                                                                          \
@@ -838,29 +885,29 @@ __device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bu
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
 template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
-                                                 unsigned zrow, bool precise, unsigned long long* st = nullptr, bool const_rows = false) {
+                                                 const unsigned* rinfo, bool precise, unsigned long long* st = nullptr, bool const_rows = false) {
     const float* bias = L.bias;
     const int act = L.act;
     if (precise) {  // layer index 0: chains in double (once per launch: not worth twelve instantiations, the bias is a runtime test there)
         if (bias) {
-            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
-            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
-            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
         } else {
-            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
-            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
-            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, true>(bias, bufA, rb, rec, zrow, nullptr, const_rows);
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
         }
         return;
     }
     if (bias) {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, zrow, st);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, zrow, st);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, zrow, st);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, rinfo, st);
     } else {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, zrow, st);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, zrow, st);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, zrow, st);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, rinfo, st);
     }
 }
 
@@ -1022,7 +1069,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
     const unsigned zrow = (unsigned)a.flags_off + 128u;  // LDS byte address of 128 zero bytes
     if (threadIdx.x < 32) wflags[32 + threadIdx.x] = 0u;
-    uint2* rec = a.grec + (size_t)g * a.meta_cap;  // (cluster variant: every workgroup of the graph writes the same records)
+    uint2* rec = a.grec + (size_t)g * a.rec_cap;  // (cluster variant: every workgroup of the graph writes the same records)
     float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
     unsigned short* words = reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
@@ -1266,20 +1313,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                           (a.wide_passes > 1 || (a.num_layers > 1 && a.layers[0].cout == kHid));
     // (cluster variant: the first 4 * kRecCache entries of every row stay in registers; rows are in descending entry
     // order, so the global copy is needed only if the first one is longer than that)
-    bool want_rec = has_wide;
-    if constexpr (CLUSTER) want_rec = has_wide && (int)(rinfo[perm[0]] >> 16) > 4 * kRecCache;
-    if (want_rec) {
-        // the support once more as 8-byte records in global memory (L2-resident: 19 layers re-read them)
-        const unsigned rl = rinfo[ng - 1];
-        const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
-        for (int j = threadIdx.x; j < used; j += BLOCK)
-            rec[j] = make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
+    if constexpr (CLUSTER) {
+        if (has_wide && (int)(rinfo[perm[0]] >> 16) > 4 * kRecCache) {
+            // the support once more as 8-byte records in global memory, row-major (L2-resident: 19 layers re-read them)
+            const unsigned rl = rinfo[ng - 1];
+            const int used = min((int)(rl & 0xffff) + (int)(rl >> 16) + 8, a.meta_cap);
+            for (int j = threadIdx.x; j < used; j += BLOCK)
+                rec[j] = make_uint2(__float_as_uint(vals[j]), (unsigned)words[j]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     RowBlocks rb;
     ClusterRows cr;
     ClusterTile ctile;
-    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, rec, K, cw);
+    // (every wave writes the block-major records of its own row blocks: read back by the same lanes, no barrier)
+    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow);
     if constexpr (CLUSTER) {
         cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
         cluster_tile_init<BLOCK>(ctile, has_wide ? ng : 0, perm, K, cw);
@@ -1321,7 +1369,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, zrow, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
+            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -1358,7 +1406,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
         } else {
-            hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
+            hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
         }
         STAMP(a, g, 4, tclk);
         if (a.layers[1].cout == kHid) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3), true);  // layer index 1: the f64 MFMA's lane map
@@ -1419,9 +1467,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
             } else {
 #ifdef DGCN_DIAG
-                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-                hidden_aggregate<BLOCK>(L, bufA, rb, rec, zrow, false);
+                hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false);
 #endif
             }
 #ifdef DGCN_DIAG
@@ -1871,6 +1919,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 
 // ---------------------------------------------------------------------------------------------
 // entry slots: the entries themselves plus at most one padding slot per row (even row starts)
+// Block-major records of a graph (row_blocks_init): 64 ceil(c_b / 4) <= 16 (c_b + 3) for block b, whose first row has c_b
+// entries; c_0 <= N, and 16 c_b for b >= 1 is at most what the 16 rows of block b - 1 hold together (descending order),
+// so everything stays under 16 N + entries + 3 (N + 15), + 64 for the load one trip ahead.  meta_cap covers the entries.
+static int fused_rec_cap(int meta_cap, int max_nodes) { return meta_cap + ((19 * max_nodes + 128 + 15) & ~15); }
 static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 16 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
 
 static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
@@ -2134,6 +2186,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace_bytes -= pad_bytes;
     }
     const int variant = fused_variant(a->max_nodes, a->meta_cap);
+    a->rec_cap = fused_rec_cap(a->meta_cap, b->max_nodes);
     if (variant < 0)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who,
                     fused_lds_bytes(a->max_nodes, a->meta_cap, true));
@@ -2148,7 +2201,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace_bytes -= need;
     }
     {
-        const size_t need = (size_t)b->num_graphs * a->meta_cap * sizeof(uint2) + 256;
+        const size_t need = (size_t)b->num_graphs * a->rec_cap * sizeof(uint2) + 256;
         if (!workspace || workspace_bytes < need)
             return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry records), got %zu", who, need,
                         workspace ? workspace_bytes : (size_t)0);
@@ -2273,7 +2326,7 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
 static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap) {
     size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
-    need += (size_t)b->num_graphs * meta_cap * sizeof(uint2) + 256;  // entry records of the hidden aggregation
+    need += (size_t)b->num_graphs * fused_rec_cap(meta_cap, b->max_nodes) * sizeof(uint2) + 256;  // entry records of the hidden aggregation
     need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
     need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);
     return need;
