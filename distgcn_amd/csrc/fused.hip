@@ -436,8 +436,8 @@ __device__ __forceinline__ void cluster_wait(unsigned long long* flags, int K, u
 // has pulled layer l (=> every other workgroup has published l and is therefore done reading l - 1) it marks its own rows
 // in the slice of layer l + 2 (= that of l - 1) unwritten again; s_waitcnt + the barrier after the gather phase put those
 // marks into L2 before its next layer's rows leave, and nobody polls for l + 2 before having seen those.
-// A workgroup's <= 4 tiles on its 8 waves: with one or two tiles a tile's four 16-column blocks go to four waves (8 MFMAs
-// each instead of 32 in a row on one SIMD), with three or four to two waves.  Every output element still sees the same
+// A workgroup's <= 8 tiles on its 8 waves: with one or two tiles a tile's four 16-column blocks go to four waves (8 MFMAs
+// each instead of 32 in a row on one SIMD), with three or four to two waves, with more a wave has a tile to itself.  Every output element still sees the same
 // eight MFMAs in the same order.
 struct ClusterTile {
     int trow;      // row of lane & 15 in this wave's tile, -1 = none
@@ -449,7 +449,7 @@ __device__ __forceinline__ void cluster_tile_init(ClusterTile& ct, int ng, const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blocks = (ng + 15) >> 4;
     const int owned = blocks > cw ? (blocks - cw + K - 1) / K : 0;
-    const int wpt = owned <= 2 ? 4 : 2;  // waves per tile
+    const int wpt = owned <= 2 ? 4 : owned <= 4 ? 2 : 1;  // waves per tile
     const int blk = (wave / wpt) * K + cw;
     const int tslot = blk * 16 + (lane & 15);
     ct.trow = (blk < blocks && tslot < ng) ? (int)perm[tslot] : -1;
@@ -780,17 +780,22 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
 // trip, and keeps the rows' records in registers for the whole layer loop (no L2 round trip inside the phase).  Same
 // per-row arithmetic: sequential fmaf chain over the entries, slot by slot.
 constexpr int kRecCache = 12;  // records per lane kept in registers: the first 48 entries of a row
-struct ClusterRows {
+struct ClusterRowSet {
     int v;                  // row of this lane's slot (lane / 8), -1 = none
     unsigned ri;            // its rinfo
     uint2 recs[kRecCache];  // entry 4i + (lane & 3) of the row
 };
+// A workgroup's <= 8 tiles on its 8 waves: wave pair p takes the rows of the workgroup's tiles p and p + 4 (lower half on
+// the even wave, upper half on the odd one).  (Two named sets, not an array: see RowBlocks.)
+struct ClusterRows {
+    ClusterRowSet s0, s1;
+};
 
-template <int BLOCK>
-__device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                  const float* vals, const unsigned short* words, int K, int cw) {
+template <int BLOCK, int SET>
+__device__ __forceinline__ void cluster_row_set_init(ClusterRowSet& cr, int ng, const unsigned* rinfo, const unsigned short* perm,
+                                                     const float* vals, const unsigned short* words, int K, int cw) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = (wave >> 1) * K + cw;                      // tile `wave / 2` of this workgroup
+    const int blk = ((wave >> 1) + 4 * SET) * K + cw;          // tile `wave / 2` (+ 4) of this workgroup
     const int slot = blk * 16 + (wave & 1) * 8 + (lane >> 3);  // its lower / upper half
     const int blocks = (ng + 15) >> 4;
     cr.v = -1;
@@ -809,9 +814,15 @@ __device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const
             }
     }
 }
+template <int BLOCK>
+__device__ __forceinline__ void cluster_rows_init(ClusterRows& cr, int ng, const unsigned* rinfo, const unsigned short* perm,
+                                                  const float* vals, const unsigned short* words, int K, int cw) {
+    cluster_row_set_init<BLOCK, 0>(cr.s0, ng, rinfo, perm, vals, words, K, cw);
+    cluster_row_set_init<BLOCK, 1>(cr.s1, ng, rinfo, perm, vals, words, K, cw);
+}
 
 template <int BLOCK, int ACT, bool F64 = false>
-__device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* bufA, const ClusterRows& cr, const uint2* rec,
+__device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* bufA, const ClusterRowSet& cr, const uint2* rec,
                                                  unsigned zrow) {
     const int lane = threadIdx.x & 63;
     const int q = lane & 7, kq = lane & 3;
@@ -867,8 +878,8 @@ __device__ __forceinline__ void aggregate_rows8c(const float* bias_ptr, float* b
 }
 
 template <int BLOCK>
-__device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bufA, const ClusterRows& cr, const uint2* rec, unsigned zrow,
-                                                  bool precise) {
+__device__ __forceinline__ void cluster_aggregate_set(const FusedLayer& L, float* bufA, const ClusterRowSet& cr, const uint2* rec,
+                                                      unsigned zrow, bool precise) {
     const float* bias = L.bias;
     const int act = L.act;
     if (precise) {  // layer index 0: chains in double
@@ -880,6 +891,12 @@ __device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bu
     if (act == DGCN_ACT_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_RELU>(bias, bufA, cr, rec, zrow);
     else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows8c<BLOCK, DGCN_ACT_LEAKY_RELU>(bias, bufA, cr, rec, zrow);
     else aggregate_rows8c<BLOCK, DGCN_ACT_LINEAR>(bias, bufA, cr, rec, zrow);
+}
+template <int BLOCK>
+__device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bufA, const ClusterRows& cr, const uint2* rec, unsigned zrow,
+                                                  bool precise) {
+    cluster_aggregate_set<BLOCK>(L, bufA, cr.s0, rec, zrow, precise);
+    cluster_aggregate_set<BLOCK>(L, bufA, cr.s1, rec, zrow, precise);  // (tiles 5 .. 8 of a workgroup: nothing to do for most graphs)
 }
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
@@ -2114,7 +2131,7 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
         K = min(8, want);
         forced = true;
     }
-    if (K < 2 || (long)gpad * K > device_cus() || (blocks + K - 1) / K > kFusedBlock / 128) return 0;  // a tile per pair of waves
+    if (K < 2 || (long)gpad * K > device_cus() || (blocks + K - 1) / K > kFusedBlock / 64) return 0;  // at most a tile per wave
     // measured (tools/cluster_check.py, 20 layers, one workgroup per graph vs cluster): N = 200: 127 vs 92 us for 1 - 16
     // graphs (K = 6 - 8; 97 with K = 4, 95 with K = 5), 129 vs 94 for 32 (K = 8), 130 vs 100 for 64 (K = 4); N = 300
     // (K = 5+): 126 vs 112; N = 150: 94 vs 82; N = 120: 74 vs 72; N = 77: 61 vs 65.  The fixed cost (every workgroup
@@ -2122,7 +2139,9 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // (tools/cluster_layers.py: N = 200 gains from 4 layers on - 44.6 vs 38.8 us at 5, 59.9 vs 47.5 at 8 -, N = 128 and
     // N = 300 from 7 - 8 on)
     const int min_layers = (blocks >= 10 && blocks <= 16) ? 5 : 8;
-    if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers)) return 0;
+    // (five to eight tiles per workgroup run - a tile per wave, two row sets per wave - but do not pay: 64 graphs of N = 500,
+    // K = 4: 183.6 against 177.1 us per residual step, 244.6 against 210.4 per rollout step; forced K only)
+    if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers || (blocks + K - 1) / K > 4)) return 0;
     return K;
 }
 

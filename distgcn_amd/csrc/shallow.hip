@@ -87,8 +87,13 @@ __device__ __forceinline__ void sh_signal_done(const ShallowArgs& a) {
     }
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
+// LONG: with the entry-parallel treatment of long rows compiled in (see `has_over` below): the host asks for it when
+// the batch's largest graph has more than 128 vertices.  Smaller graphs cannot have rows much longer than what their
+// lanes hold, and the extra uniform state costs the C2 launch 7 % (11.6 against 10.8 us, same box) even when unused.
+// (1024-thread workgroups: two per CU = 8 waves per SIMD = at most 64 VGPRs and 96 SGPRs - left to itself the compiler
+// takes 106 scalar registers and settles for 7)
+template <int BLOCK, bool LONG>
+__device__ __forceinline__ void shallow_body(const ShallowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
@@ -171,10 +176,24 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
     }
     SH_STAMP(a, g, 1, tclk);
     const int nobody = a.max_nodes;
+    // Rows longer than the kNb * lpv entries their lanes keep in registers (BA hubs: up to ~150 entries on 2 lanes) would
+    // walk the rest one entry per lane and round trip - 65 dependent trips per round for the worst graph of the C4 mix,
+    // and the launch ends with its slowest graph.  A graph that has such rows (`has_over`, uniform in the workgroup) does
+    // that work entry-parallel instead, all threads on all such entries: the entry values below, the comparisons of the
+    // greedy rounds further down.  Graphs without (ER N = 100, p = 0.1: the C2 batch, whose longest rows are a few entries
+    // over) run as before, barrier for barrier: "long" starts at kLongTrips lane trips past the registers.
+    constexpr int kNb = 8;
+    constexpr int kLongTrips = 16;  // (8: ER N = 200, p = 0.1 graphs - a row or two of 33+ entries on two lanes - lost 12 %: 26.1 against 23.3 us per launch)
+    int* rowstart = reinterpret_cast<int*>(pr);  // [ng + 1] entry offsets of the rows (until the priorities are written)
     if (mine && sub == 0) {
         dinv[vv] = dv;
         z1[vv] = z1v;
         kr[vv] = 0xFFFFu;
+        if constexpr (LONG) rowstart[vv] = rs - e0;
+    }
+    if constexpr (LONG) {  // "some row of this graph is long": one vote per wave (the round votes' first bank is free until round 2)
+        const unsigned long long m = __ballot(mine && sub == 0 && deg > (kNb + kLongTrips) * lpv);
+        if ((threadIdx.x & 63) == 0) wflags[threadIdx.x >> 6] = m != 0ull;
     }
     if (threadIdx.x == 0) {
         dinv[nobody] = 0.0;
@@ -182,13 +201,13 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
         pr[nobody] = __longlong_as_double(0x7ff8000000000000ll);
         kr[nobody] = 0;
         wflags[32] = 0u;
+        if constexpr (LONG) { wflags[34] = 0u; rowstart[ng] = e1 - e0; }
     }
     __syncthreads();
     SH_STAMP(a, g, 2, tclk);
     // ---- entry values by all lanes of the row, then the chain by its first lane (LDS operations of one wave complete in
     // order and the lpv lanes of a row sit in one wave: no barrier between the writes and the reads).  A lane keeps the ids
     // of its first kNb entries in registers for the greedy rounds below.
-    constexpr int kNb = 8;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double dvv = mine ? dinv[vv] : 0.0;
     int nb[kNb];
@@ -209,8 +228,50 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
             if (nb[i] == vv) fault |= DGCN_FAULT_SELF_LOOP;
             if (j < re) vals[j - e0] = (float)(-(dn[i] * dvv));
         }
+    }
+    // (the votes are read here, behind the register path, so that their round trip is not on every graph's critical path)
+    bool has_over = false;
+    if constexpr (LONG) {
+#pragma unroll
+        for (int wv = 0; wv < BLOCK / 64; ++wv) has_over |= wflags[wv] != 0u;
+        has_over = has_over && graph_fits;
+    }
+    if (has_over) {
+        // the rest (and, harmlessly, the first kNb * lpv entries of every row once more) entry-parallel: a thread takes eight
+        // consecutive entries, finds the row of the first by bisection over the row starts and walks on from there.  Same
+        // expression, same bits as the row-parallel form.
+        const int total = e1 - e0;
+        for (int base = threadIdx.x * 8; base < total; base += BLOCK * 8) {
+            int ids[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ids[i] = base + i < total ? (int)nbr[base + i] : 0xFFFF;
+            int lo = 0, hi = ng;  // last row whose start is <= base (rows without entries are stepped over below)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rowstart[mid] <= base) lo = mid; else hi = mid;
+            }
+            int v = lo, vend = rowstart[v + 1];
+            double dvr = dinv[v];
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {  // (four at a time: the 1024-thread variant has 64 registers)
+                double du[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) du[i] = dinv[ids[h + i] == 0xFFFF ? nobody : ids[h + i]];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = base + h + i;
+                    if (j < total) {
+                        while (j >= vend) { ++v; vend = rowstart[v + 1]; dvr = dinv[v]; }
+                        if (ids[h + i] == v) fault |= DGCN_FAULT_SELF_LOOP;
+                        vals[j] = ids[h + i] == 0xFFFF ? 0.f : (float)(-(du[i] * dvr));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    } else if (fits) {
 #pragma unroll 4
-        for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {  // long rows (BA hubs): the rest through the table
+        for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {  // (at most kLongTrips trips)
             const int u = nbr[j - e0];
             if (u == vv) fault |= DGCN_FAULT_SELF_LOOP;
             vals[j - e0] = u == 0xFFFF ? 0.f : (float)(-(dinv[u] * dvv));
@@ -272,26 +333,71 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
     // (Tried: ONE WAVE per graph with ceil(N / 64) vertices per lane and no barrier at all.  27.9 us against 12.6 us for
     // the C2 launch, 144 against 53 us on the BA mix: the phases are chains of dependent LDS round trips, and one wave has
     // nothing to issue while it waits - several waves per graph hide each other's latency.)
+    // Graphs with long rows: the entries past a row's first kNb * lpv as one flat list of (row << 16 | neighbour) words
+    // (in the space of the entry values, which nobody reads any more), compared entry-parallel in every round; a row that
+    // loses through one of them is stamped in `lostr` (in the space of z1), read back after one more barrier; a winner is
+    // stamped in `wonr`, and a third sweep-and-barrier takes its listed neighbours out.
+    unsigned* ov = reinterpret_cast<unsigned*>(vals);
+    unsigned short* lostr = reinterpret_cast<unsigned short*>(z1);  // [max_nodes + 1] round in which a row last lost through the list
+    unsigned short* wonr = lostr + mn1;                             // [max_nodes + 1] round in which a row won
+    int ovn = 0;
+    if (has_over) {
+        const int over = fits ? max(0, deg - kNb * lpv) : 0;
+        int pos = 0;
+        if (sub == 0 && over > 0) pos = (int)atomicAdd(&wflags[34], (unsigned)over);
+        pos = __shfl(pos, (int)(threadIdx.x & 63u) & ~(lpv - 1));
+        if (mine && sub == 0) { lostr[vv] = 0; wonr[vv] = 0; }
+        for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
+            const int u0 = nbr[j - e0];
+            ov[pos + (j - rs - kNb * lpv)] = ((unsigned)vv << 16) | (unsigned)(u0 == 0xFFFF ? nobody : u0);
+        }
+        __syncthreads();
+        ovn = (int)wflags[34];
+    }
     int rounds = 0;
     bool member = false;
     for (unsigned r = 1;; ++r) {
         const double pv = mine ? pr[vv] : qnan;
         const bool live = mine && (unsigned)kr[vv] >= r;
         bool lost = false;
-        unsigned ku[kNb];
+        // which register neighbours were in at the start of this round, for the winners' stamps: the stamps themselves, or
+        // (LONG: the 1024-thread variant has 64 registers) one bit each.  (The bits cost the C2 launch 0.9 us of 10.6.)
+        unsigned pres = 0u;
+        unsigned kuk[kNb];
+        (void)pres; (void)kuk;
         if (live && fits) {
             double pu[kNb];
+            unsigned ku[kNb];
 #pragma unroll
             for (int i = 0; i < kNb; ++i) { pu[i] = pr[nb[i]]; ku[i] = kr[nb[i]]; }
 #pragma unroll
-            for (int i = 0; i < kNb; ++i) lost |= (ku[i] >= r) & ((pu[i] > pv) | ((pu[i] == pv) & (nb[i] < vv)));
-#pragma unroll 4
-            for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
-                const int u0 = nbr[j - e0];
-                const int u = u0 == 0xFFFF ? nobody : u0;
-                const double q = pr[u];
-                lost |= ((unsigned)kr[u] >= r) & ((q > pv) | ((q == pv) & (u < vv)));
+            for (int i = 0; i < kNb; ++i) {
+                if constexpr (LONG) pres |= (unsigned)(ku[i] >= r) << i;
+                else kuk[i] = ku[i];
+                lost |= (ku[i] >= r) & ((pu[i] > pv) | ((pu[i] == pv) & (nb[i] < vv)));
             }
+            if (!has_over) {
+#pragma unroll 4
+                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {  // (at most kLongTrips trips)
+                    const int u0 = nbr[j - e0];
+                    const int u = u0 == 0xFFFF ? nobody : u0;
+                    const double q = pr[u];
+                    lost |= ((unsigned)kr[u] >= r) & ((q > pv) | ((q == pv) & (u < vv)));
+                }
+            }
+        }
+        if (has_over) {
+#pragma unroll 4
+            for (int k = threadIdx.x; k < ovn; k += BLOCK) {
+                const unsigned e = ov[k];
+                const int v = (int)(e >> 16), u = (int)(e & 0xffffu);
+                if ((unsigned)kr[v] >= r && (unsigned)kr[u] >= r) {
+                    const double q = pr[u], pq = pr[v];
+                    if ((q > pq) | ((q == pq) & (u < v))) lostr[v] = (unsigned short)r;
+                }
+            }
+            __syncthreads();
+            lost |= mine && (unsigned)lostr[vv] == r;
         }
         for (int off = 1; off < lpv; off <<= 1) lost |= (bool)__shfl_xor((int)lost, off);
         const bool won = live && !lost;
@@ -303,13 +409,24 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
             if (fits) {
 #pragma unroll
                 for (int i = 0; i < kNb; ++i)
-                    if (ku[i] >= r && nb[i] != nobody) kr[nb[i]] = (unsigned short)r;
-                for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {
-                    const int u = nbr[j - e0];
-                    if (u != 0xFFFF && (unsigned)kr[u] >= r) kr[u] = (unsigned short)r;
-                }
+                    if ((LONG ? ((pres >> i) & 1u) != 0u : kuk[i] >= r) && nb[i] != nobody) kr[nb[i]] = (unsigned short)r;
+                if (!has_over)
+                    for (int j = rs + sub + kNb * lpv; j < re; j += lpv) {  // (at most kLongTrips trips)
+                        const int u = nbr[j - e0];
+                        if (u != 0xFFFF && (unsigned)kr[u] >= r) kr[u] = (unsigned short)r;
+                    }
             }
+            if (has_over && sub == 0) wonr[vv] = (unsigned short)r;  // its listed neighbours leave below
             if (sub == 0) { kr[vv] = (unsigned short)r; member = true; }
+        }
+        if (has_over) {  // the winners' listed neighbours, entry-parallel (same rule: only vertices still in are stamped)
+            __syncthreads();
+#pragma unroll 4
+            for (int k = threadIdx.x; k < ovn; k += BLOCK) {
+                const unsigned e = ov[k];
+                const int v = (int)(e >> 16), u = (int)(e & 0xffffu);
+                if ((unsigned)wonr[v] == r && u != nobody && (unsigned)kr[u] >= r) kr[u] = (unsigned short)r;
+            }
         }
         __syncthreads();
         unsigned any = 0;
@@ -345,6 +462,14 @@ __global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) {
 #endif
 }
 
+// The kernels proper.  1024-thread workgroups: two per CU = 8 waves per SIMD = at most 64 VGPRs and 96 SGPRs - left to
+// itself the compiler takes 106 scalar registers and settles for 7; the smaller shapes are better off without the limit
+// (C2: 11.5 against 12.1 us with it).
+template <int BLOCK, bool LONG>
+__global__ __launch_bounds__(BLOCK) void k_shallow(ShallowArgs a) { shallow_body<BLOCK, LONG>(a); }
+template <bool LONG>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shallow_1024(ShallowArgs a) { shallow_body<1024, LONG>(a); }
+
 static size_t shallow_lds(int max_nodes, int cap) {
     return (size_t)(max_nodes + 1) * (8 + 8 + 4 + 2) + 16 * 8 + 48 * 4 + (size_t)cap * 6 + 64;
 }
@@ -361,22 +486,39 @@ bool shallow_takes(const DgcnBatch* b, const DgcnModel* m) {
     return shallow_lds(max(b->max_nodes, 64), cap) <= 96 * 1024;
 }
 
-template <int BLOCK>
-static int shallow_launch_b(ShallowArgs& a, int B, size_t lds, hipStream_t s) {
+template <int BLOCK, bool LONG>
+static int shallow_launch_bl(ShallowArgs& a, int B, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<int> raised[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!raised[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shallow<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    96 * 1024) != hipSuccess)
+            const void* kern;
+            if constexpr (BLOCK == 1024) kern = reinterpret_cast<const void*>(&k_shallow_1024<LONG>);
+            else kern = reinterpret_cast<const void*>(&k_shallow<BLOCK, LONG>);
+            if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_shallow: cannot reserve %zu bytes of LDS", lds);
             raised[dev & 63].store(1, std::memory_order_relaxed);
         }
     }
     TimedLaunch t("fused_solve", s);  // (the same timing family as k_fused: it is the same entry point's launch)
-    DGCN_LAUNCH(t, (k_shallow<BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
+    if constexpr (BLOCK == 1024) DGCN_LAUNCH(t, (k_shallow_1024<LONG>), dim3(B), dim3(BLOCK), lds, s, a);
+    else DGCN_LAUNCH(t, (k_shallow<BLOCK, LONG>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_shallow");
+}
+
+// The long-row treatment is compiled into its own kernels, for batches that can have long rows at all: largest graph above
+// 128 vertices AND at least 24 entries per vertex in the densest one (the BA mix: 37; ER N = 200, p = 0.1: 22).  Carried
+// along unused it costs 6 - 7 % (ER N = 200: 24.5 against 23.0 us; C2: 11.6 against 10.7) - scalar registers spilled to lanes.
+// Either kernel is correct for every batch: the choice is about time only.
+template <int BLOCK>
+static int shallow_launch_b(ShallowArgs& a, int B, size_t lds, hipStream_t s) {
+    if constexpr (BLOCK >= 512) {
+        bool lng = (long)a.cap >= 24L * a.max_nodes;
+        if (const char* e = getenv("DGCN_SHALLOW_LONG")) lng = atoi(e) != 0;  // tuning / tests
+        if (lng) return shallow_launch_bl<BLOCK, true>(a, B, lds, s);
+    }
+    return shallow_launch_bl<BLOCK, false>(a, B, lds, s);
 }
 
 int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,

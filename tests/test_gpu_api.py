@@ -1222,17 +1222,19 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
     from distgcn_amd.mwis_gdpg_call import DQNAgent
     agent = DQNAgent(_flags(num_layer=12), seed=4)
     agent.device_iterative = True
-    hb = datagen.er_batch(3, 200, 0.06, first_index=4400)
-    adjs = [hb.scipy_graph(g) for g in range(3)]
-    ws = [hb.weights[n0:n1] for n0, n1 in hb.graph_slices()]
-    got = {}
-    for mode in ("0", "8", None):
-        cluster_switch(mode)
-        got[mode] = agent.solve_iterative_batch(adjs, ws, which, b=8)
-        assert got[mode] is not None
-    for mode in ("8", None):
-        for a, b in zip(got["0"], got[mode]):
-            assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), (which, mode)
+    # (N = 500, the C5 size: 32 tiles - with K = 4 a workgroup owns eight, one per wave, and every wave aggregates two row sets)
+    for hb, modes in ((datagen.er_batch(3, 200, 0.06, first_index=4400), ("0", "8", None)),
+                      (datagen.er_batch(2, 500, 0.02, first_index=4410), ("0", "4", "5", None))):
+        adjs = [hb.scipy_graph(g) for g in range(hb.num_graphs)]
+        ws = [hb.weights[n0:n1] for n0, n1 in hb.graph_slices()]
+        got = {}
+        for mode in modes:
+            cluster_switch(mode)
+            got[mode] = agent.solve_iterative_batch(adjs, ws, which, b=8)
+            assert got[mode] is not None
+        for mode in modes[1:]:
+            for a, b in zip(got["0"], got[mode]):
+                assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), (which, mode, hb.num_nodes)
 
 
 def test_host_solver_compact_transfer(engine, monkeypatch):

@@ -651,7 +651,8 @@ def test_layer_fused_with_next_transform(engine, golden):
 def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch, cluster_switch):
     """k_fused<.., CLUSTER>: one graph on K workgroups that hand their Z1 rows round through L2 every layer
     (csrc/fused.hip, "cluster variant").  Forced on for K = 2, 3, 4, 8 over ragged small batches - graph sizes that do
-    not fill the last tile, single-tile graphs, an empty graph, biases, both activations - and compared bit for bit with
+    not fill the last tile, single-tile graphs, an empty graph, graphs of 300 and 500 vertices (five to eight tiles per
+    workgroup), biases, both activations - and compared bit for bit with
     the ordinary one-workgroup-per-graph launch (which the rest of this file pins against the CPU twin); also the
     automatic choice (small batch of N = 200 graphs) and repeated launches on the same buffers (progress words of
     earlier launches must not satisfy later ones)."""
@@ -666,7 +667,9 @@ def test_cluster_variant_is_bit_identical(engine, golden, layers_n, monkeypatch,
         if i < layers_n - 1 and i % 2:
             lyr["act"] = "relu"
     model = DeviceModel(layers, engine.device)
-    hbs = [datagen.er_batch(3, 200, 0.1, first_index=40), datagen.er_batch(1, 200, 0.1, first_index=41)]
+    hbs = [datagen.er_batch(3, 200, 0.1, first_index=40), datagen.er_batch(1, 200, 0.1, first_index=41),
+           datagen.er_batch(2, 500, 0.02, first_index=42),   # 32 tiles: K = 4 gives a workgroup eight (a tile per wave, two row sets)
+           datagen.er_batch(1, 300, 0.05, first_index=43)]   # 19 tiles: K = 3 gives 7, 6, 6
     parts = [datagen.er_batch(1, n, p, first_index=50 + n) for n, p in ((137, 0.08), (16, 0.3), (33, 0.2), (512, 0.01), (64, 0.1))]
     ps, cs, ws = [np.zeros(1, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0)]  # an empty graph first
     for hb in parts:
@@ -759,13 +762,13 @@ def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatc
                 assert np.array_equal(got["0"][k].view(np.uint8), got[order][k].view(np.uint8)), (layers_n, order, k)
 
 
-@pytest.mark.parametrize("case", ["ties", "features_bias", "ba", "n512", "c2"])
+@pytest.mark.parametrize("case", ["ties", "features_bias", "ba", "dense", "n512", "c2"])
 def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     """One-layer models go through the small dedicated kernel (csrc/shallow.hip: no 32-wide image, greedy rounds on the
     float64 priorities themselves instead of on ranks).  Against the twin bit for bit, and against k_fused forced on the
     same batch (DGCN_SHALLOW=0): ties everywhere (weights from a handful of values), isolated vertices, 1-vertex and
-    empty graphs, explicit features with a bias and an activation (GCN2_DQN's last layer), the BA mix with hubs, 512-vertex
-    graphs, and the C2 batch itself with the trained weights."""
+    empty graphs, explicit features with a bias and an activation (GCN2_DQN's last layer), the BA mix with hubs, dense
+    graphs whose every row is long (with ties), 512-vertex graphs, and the C2 batch itself with the trained weights."""
     import scipy.sparse as sp
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
@@ -790,6 +793,14 @@ def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     elif case == "ba":
         hb = datagen.ba_test2_batch(100)
         layers = datagen.random_model(1, 32, seed=5)
+    elif case == "dense":  # every row long (40 - 110 entries on two or four lanes), explicit features: the gathering chain
+        ps, cs, ws = [], [], []
+        for n, p_ in ((300, 0.14), (200, 0.3), (160, 0.5), (260, 0.18), (129, 0.85)):  # (<= 14 000 entries: the shallow kernel's LDS)
+            indptr, indices = datagen.er_graph(n, p_, rng)
+            ps.append(indptr); cs.append(indices); ws.append(rng.choice([0.5, 1.0, 1.0, 2.0], size=n))
+        hb = HostBatch.from_csr_lists(ps, cs, ws)
+        layers = datagen.random_model(1, 32, feature_size=4, bias=True, last_act="relu", seed=8)
+        X = rng.random((hb.num_nodes, 4)).astype(np.float32)
     elif case == "n512":
         hb = datagen.er_batch(6, 512, 0.02)
         layers = datagen.random_model(1, 32, bias=True, seed=6)
@@ -818,7 +829,16 @@ def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     old = engine.solve(db, dm, mode=1, X=Xd)
     engine.check_status(old["status"])
     monkeypatch.delenv("DGCN_SHALLOW")
-    for name, out in (("shallow", got), ("fused", old)):
+    # graphs above 128 vertices have two shallow kernels - with and without the entry-parallel treatment of long rows (hubs) -
+    # and the host picks by the batch's density: both, forced, on every case (the "ba" and "dense" cases have such rows)
+    forced = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DGCN_SHALLOW_LONG", flag)
+        out = engine.solve(db, dm, mode=1, X=Xd)
+        engine.check_status(out["status"])
+        forced.append(("shallow, DGCN_SHALLOW_LONG=" + flag, out))
+    monkeypatch.delenv("DGCN_SHALLOW_LONG")
+    for name, out in [("shallow", got), ("fused", old)] + forced:
         assert np.array_equal(out["scores"].cpu().numpy().reshape(-1).view(np.uint32), ref["scores"][:, 0].view(np.uint32)), name
         assert np.array_equal(out["state"].cpu().numpy(), ref["state"]), name
         assert np.array_equal(out["rounds"].cpu().numpy(), ref["rounds"]), name
