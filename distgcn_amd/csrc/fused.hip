@@ -314,7 +314,9 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
     constexpr int kWaves = BLOCK / 64;
     const int blocks = (ng + 15) >> 4;  // <= 32
     // trips of block `lane` and the records in front of it (every wave computes the same table: one scan, once per graph)
-    const int tl = lane < blocks ? (int)(((rinfo[perm[lane * 16]] >> 16) + 3) >> 2) : 0;
+    // (at least one trip for a block that exists: rows without a single entry - removed vertices of a residual graph, empty
+    // rows of a caller's support matrix - still get their Z0 (+ bias) through the activation)
+    const int tl = lane < blocks ? max(1, (int)(((rinfo[perm[lane * 16]] >> 16) + 3) >> 2)) : 0;
     int incl = tl;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1077,7 +1079,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     const bool stamp_wg = !CLUSTER || cw == 0;  // (DGCN_DIAG builds: phase clocks of the graph's first workgroup only)
     (void)stamp_wg;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
-    const int ng = n1 - n0;
+    int ng = n1 - n0;  // (residual-graph variant: becomes the number of REMAINING vertices once the image is built)
     // bufB (Z1) sits at LDS byte offset 0 - the kernel has no static LDS - so a gather address is the
     // metadata word xor-ed with the lane's chunk offset, with no base to add
     float* bufB = reinterpret_cast<float*>(lds_raw);
@@ -1137,19 +1139,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     int* hist = reinterpret_cast<int*>(dinv + a.max_nodes);  // [576] entry-count histogram (bufB: 128 B per row)
     float xfill = a.x_const;   // first-layer input when X is null
     bool was_alive = true;     // vertex threadIdx.x is part of the (residual) graph
+    int vid = threadIdx.x;     // the vertex thread threadIdx.x stands for (residual-graph variant: see the renumbering below)
     if constexpr (MASKED) {
         // Residual graph: rows and entries of removed vertices (state != 0) are dropped while the image is
         // built, so everything after P0 runs unchanged on the induced subgraph - the reference re-slices
         // the SciPy matrix instead (mwis_gdpg_call.py:284-285).  Row-parallel (8 lanes per row) because
         // an entry's slot depends on how many earlier entries of its row survive.
+        // Round 3: the remaining vertices are RENUMBERED 0 .. na - 1 (in index order, so every "lower index first" rule
+        // holds) and everything after P0 - tiles, row blocks, ranks, rounds - sees a graph of na vertices: a rollout search
+        // removes ~11 vertices per step, so over a search the transforms and aggregations shrink to half on average.
+        // Thread c stands for remaining vertex `vid` = orig[c] wherever a per-vertex global array is touched.
         uint8_t* al = reinterpret_cast<uint8_t*>(rowstart + 520);              // [512] 1 = in the residual graph
-        unsigned short* acount = reinterpret_cast<unsigned short*>(al + 512);  // [512] surviving neighbours
+        unsigned short* acount = reinterpret_cast<unsigned short*>(al + 512);  // [512] surviving neighbours (by new index)
+        unsigned short* cidx = acount + 512;                                   // [512] old index -> new
+        unsigned short* orig = cidx + 512;                                     // [512] new index -> old
         double* wred = reinterpret_cast<double*>(hist + 576);                  // per-wave partial maxima
+        int* wcnt = reinterpret_cast<int*>(wred + BLOCK / 64);                 // per-wave counts of remaining vertices
         const int tv0 = threadIdx.x;
         was_alive = tv0 < ng && a.state[n0 + tv0] == 0;
         const double w0 = (tv0 < ng && a.weights) ? a.weights[n0 + tv0] : 1.0;
         if (tv0 < ng) al[tv0] = was_alive;
         for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
+        // what a removed vertex reports as its score (the others write theirs after the last layer)
+        if (a.scores && tv0 < ng && !was_alive && !(a.options & DGCN_RESIDUAL_SCORES_GIVEN)) a.scores[n0 + tv0] = 0.f;
         // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286)
         if (!block_or<BLOCK>(was_alive && w0 > 0.0, wflags)) {
             if (a.scores && tv0 < ng && !(a.options & DGCN_RESIDUAL_SCORES_GIVEN)) a.scores[n0 + tv0] = 0.f;
@@ -1159,29 +1171,48 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             }
             return;
         }
-        if (a.feature_mode == 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = lane >> 3, q = lane & 7;
+        const unsigned long long alive_mask = __ballot(was_alive);
+        {
             double mx = was_alive ? w0 : -1.0 / 0.0;
-            for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
-            if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mx;
+            if (a.feature_mode == 1)
+                for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+            if (lane == 0) { wred[wave] = mx; wcnt[wave] = __popcll(alive_mask); }
         }
         __syncthreads();
-        if (a.feature_mode == 1) {
-            double mx = wred[0];
+        double wmax = wred[0];
+        int na = 0, before = 0;
 #pragma unroll
-            for (int w = 1; w < BLOCK / 64; ++w) mx = fmax(mx, wred[w]);
-            xfill = was_alive ? (float)(w0 / (mx + 1e-9)) : 0.f;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            if (w > 0) wmax = fmax(wmax, wred[w]);
+            if (w < wave) before += wcnt[w];
+            na += wcnt[w];
         }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = lane >> 3, q = lane & 7;
+        if (was_alive) {
+            const int c = before + __popcll(alive_mask & ((1ull << lane) - 1ull));
+            cidx[tv0] = (unsigned short)c;
+            orig[c] = (unsigned short)tv0;
+        }
+        __syncthreads();
+        const int ng_full = ng;
+        ng = na;
+        vid = tv0 < na ? (int)orig[tv0] : 0;
+        was_alive = tv0 < na;  // from here on: "thread tv0 stands for a vertex of the image"
+        if (a.feature_mode == 1) {
+            const double wv = (was_alive && a.weights) ? a.weights[n0 + vid] : 1.0;
+            xfill = was_alive ? (float)(wv / (wmax + 1e-9)) : 0.f;
+        }
         for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
             const int v = vb + gw;
             int cnt = 0;
-            if (v < ng && al[v]) {
-                const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+            if (v < ng) {
+                const int vo = orig[v];
+                const int rs = a.row_ptr[n0 + vo], re = a.row_ptr[n0 + vo + 1];
                 for (int j = rs + q; j < re; j += 8) {
                     const int u = a.col_idx[j] - n0;
-                    if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
+                    if (u < 0 || u >= ng_full) fault |= DGCN_FAULT_BAD_COLUMN;
                     else {
-                        if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                        if (u == vo) fault |= DGCN_FAULT_SELF_LOOP;
                         cnt += al[u];
                     }
                 }
@@ -1193,40 +1224,44 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         }
         __syncthreads();
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
-            const int rs = a.row_ptr[n0 + v];
-            const int start = ((rs - e0) + 2 * v + 1) & ~1;  // the full row's slots stay reserved
+            const int vo = orig[v];
+            const int rs = a.row_ptr[n0 + vo];
+            const int start = ((rs - e0) + 2 * vo + 1) & ~1;  // the full row's slots stay reserved
             const int deg = acount[v];
-            const int cnt = al[v] ? deg + 1 : 0;
+            const int cnt = deg + 1;
             rinfo[v] = (unsigned)start | ((unsigned)cnt << 16);
             atomicAdd(&hist[min(cnt, 575)], 1);
             double d = 0.0;
             if (deg < a.table_len) d = a.dinv_table[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
             dinv[v] = d;
-            if (al[v]) { words[start] = enc_word(v); vals[start] = 1.0f; }
+            words[start] = enc_word(v);
+            vals[start] = 1.0f;
         }
         __syncthreads();
         hist_to_offsets(hist);
         for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
             const int v = vb + gw;
-            const bool act = v < ng && al[v];
-            const int rs = act ? a.row_ptr[n0 + v] : 0, re = act ? a.row_ptr[n0 + v + 1] : 0;
+            const bool act = v < ng;
+            const int vo = act ? (int)orig[v] : 0;
+            const int rs = act ? a.row_ptr[n0 + vo] : 0, re = act ? a.row_ptr[n0 + vo + 1] : 0;
             const int start = act ? (int)(rinfo[v] & 0xffff) : 0;
             int base = 1;  // slot 0 of the row is the diagonal
             for (int j0 = rs; __any(j0 < re); j0 += 8) {
                 const int j = j0 + q;
                 int u = j < re ? a.col_idx[j] - n0 : -1;
-                const bool keep = u >= 0 && u < ng && al[u];
+                const bool keep = u >= 0 && u < ng_full && al[u];
                 const unsigned bits = (unsigned)(__ballot(keep) >> (gw * 8)) & 0xffu;
                 if (keep) {
                     const int slot = start + base + __popc(bits & ((1u << q) - 1u));
-                    words[slot] = enc_word(u);
-                    vals[slot] = (float)(-(dinv[u] * dinv[v]));
+                    const int uc = cidx[u];
+                    words[slot] = enc_word(uc);
+                    vals[slot] = (float)(-(dinv[uc] * dinv[v]));
                 }
                 base += __popc(bits);
             }
         }
         __syncthreads();
-        if constexpr (CLUSTER) rank_rows<BLOCK>(ng, rinfo, perm, ipos, reinterpret_cast<unsigned*>(rowstart + 520 + 512));  // (behind al / acount)
+        if constexpr (CLUSTER) rank_rows<BLOCK>(ng, rinfo, perm, ipos, reinterpret_cast<unsigned*>(rowstart + 520 + 512 + 512));  // (behind al / acount / cidx / orig)
         else
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int c = min((int)(rinfo[v] >> 16), 575);
@@ -1370,7 +1405,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     // ------------------------------------------------------------ layers
     float score = 0.f;  // final output of vertex threadIdx.x (ng <= block, checked by the host)
     const bool scores_given = MASKED && (a.options & DGCN_RESIDUAL_SCORES_GIVEN);
-    if (scores_given && (int)threadIdx.x < ng) score = a.scores[n0 + threadIdx.x];
+    const int voff = vid - (int)threadIdx.x;  // 0 unless the residual-graph variant renumbered the vertices
+    if (scores_given && (int)threadIdx.x < ng) score = a.scores[n0 + vid];
     float bfrag[8][4];
     const int P = a.wide_passes > 1 ? a.wide_passes : 1;  // first-layer column blocks (1 = the ordinary case)
     int l_first = 0;
@@ -1384,7 +1420,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         const int v = threadIdx.x;
         double zc0 = 0.0, zc1 = 0.0;  // (the last layer is layer index 1: its chains run in double)
         for (int p = 0; p < P; ++p) {
-            first_layer_transform<BLOCK>(a, a.layers[p], n0, ng, bufA, bufB, xfill);
+            first_layer_transform<BLOCK>(a, a.layers[p], n0 + voff, ng, bufA, bufB, xfill);
             __syncthreads();
             hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
             __syncthreads();
@@ -1415,7 +1451,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         const FusedLayer& L = a.layers[0];
         const int prio_base = (second && a.prio_second) ? 1 : 0;
         if (a.prio_second || a.prio_gather) set_prio(prio_base);
-        first_layer_transform<BLOCK>(a, L, n0, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
+        first_layer_transform<BLOCK>(a, L, n0 + voff, ng, bufA, bufB, xfill);  // (cluster variant: every row, in every workgroup)
         STAMP(a, g, 3, tclk);
         __syncthreads();
         if (a.prio_gather) set_prio(prio_base + a.prio_gather);
@@ -1544,7 +1580,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 } else {
                     for (int k = 0; k < L.cin; ++k) {
                         float h;
-                        if (l == 0) h = a.X ? a.X[(size_t)(n0 + v) * L.cin + k] : xfill;
+                        if (l == 0) h = a.X ? a.X[(size_t)(n0 + voff + v) * L.cin + k] : xfill;
                         else h = bufA[swz(v, k)];
                         z0 = fmaf(h, L.W[k * 2 + 0], z0);
                         z1 = fmaf(h, L.W[k * 2 + 1], z1);
@@ -1593,7 +1629,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     if (L.bias) o += L.bias[0];
                 }
                 score = apply_act(o, L.act);
-                if (a.scores && !(CLUSTER && a.do_lgs)) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;  // (cluster + search: below)
+                if (a.scores && !(CLUSTER && a.do_lgs)) a.scores[n0 + voff + v] = (MASKED && !was_alive) ? 0.f : score;  // (cluster + search: below)
                 if constexpr (CLUSTER) xs0[a.max_nodes + v] = score;
             }
             if constexpr (CLUSTER) {
@@ -1604,7 +1640,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 }
                 if (v < ng && !owned) score = poll_l2_scalar(xs0 + a.max_nodes + v, a.status);
                 // every output of the graph leaves from this workgroup: one place to wait for before telling the host
-                if (a.scores && v < ng) a.scores[n0 + v] = (MASKED && !was_alive) ? 0.f : score;
+                if (a.scores && v < ng) a.scores[n0 + voff + v] = (MASKED && !was_alive) ? 0.f : score;
             }
             __syncthreads();
             STAMP(a, g, 9, tclk);  // last layer
@@ -1643,7 +1679,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         double wmine = 0.0;
         if (tv < ng) {
             double p = (double)score;
-            wmine = a.weights ? a.weights[n0 + tv] : 0.0;
+            wmine = a.weights ? a.weights[n0 + voff + tv] : 0.0;
             if (a.predict_mwis && a.weights) p *= wmine;
             bad = was_alive && (p != p);
             pr[tv] = p;
@@ -1777,7 +1813,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             rounds = 1;
             __syncthreads();
         }
-        if (tv < ng && was_alive) a.state[n0 + tv] = st[tv];
+        if (tv < ng && was_alive) a.state[n0 + voff + tv] = st[tv];
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
         if (threadIdx.x == 0 && a.progress) atomicAdd(a.progress, 1);
         if (a.totals) {
@@ -1938,8 +1974,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 // entry slots: the entries themselves plus at most one padding slot per row (even row starts)
 // Block-major records of a graph (row_blocks_init): 64 ceil(c_b / 4) <= 16 (c_b + 3) for block b, whose first row has c_b
 // entries; c_0 <= N, and 16 c_b for b >= 1 is at most what the 16 rows of block b - 1 hold together (descending order),
-// so everything stays under 16 N + entries + 3 (N + 15), + 64 for the load one trip ahead.  meta_cap covers the entries.
-static int fused_rec_cap(int meta_cap, int max_nodes) { return meta_cap + ((19 * max_nodes + 128 + 15) & ~15); }
+// so everything stays under 16 N + entries + 3 (N + 15), + 64 for the load one trip ahead (+ 16 per block for the one
+// trip a block of empty rows still makes).  meta_cap covers the entries.
+static int fused_rec_cap(int meta_cap, int max_nodes) { return meta_cap + ((20 * max_nodes + 192 + 15) & ~15); }
 static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 16 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
 
 static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {

@@ -269,6 +269,42 @@ def test_forward_bias_relu_and_features(engine, golden, mode):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_forward_support_with_empty_rows(engine, mode):
+    """A caller's support matrix may have rows without a single entry (here: L with its diagonal struck out, on graphs
+    with 30 isolated vertices - two whole 16-row blocks of the fused kernel's aggregation are empty).  Such a row's output
+    is act(Z0 + bias): both paths against the twin, bit for bit."""
+    import ctypes as C
+    from distgcn_amd import datagen, _lib
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    rng = np.random.default_rng(12)
+    ps, cs, ws = [], [], []
+    for n_conn, n_iso in ((40, 30), (100, 3), (17, 40)):
+        indptr, indices = datagen.er_graph(n_conn, 0.2, rng)
+        ps.append(np.concatenate([indptr, np.full(n_iso, indptr[-1], indptr.dtype)])); cs.append(indices)
+        ws.append(np.ones(n_conn + n_iso))
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
+    db = engine.upload(hb)
+    rp, ci, va = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    rows = np.repeat(np.arange(hb.num_nodes), np.diff(rp))
+    keep = ci != rows
+    rp2 = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=hb.num_nodes))]).astype(np.int32)
+    ci2, va2 = ci[keep].astype(np.int32), va[keep].astype(np.float32)
+    assert (np.diff(rp2) == 0).sum() >= 73
+    t = engine.torch
+    d = {"row_ptr": t.from_numpy(rp2).to(engine.device), "col_idx": t.from_numpy(ci2).to(engine.device),
+         "values": t.from_numpy(va2).to(engine.device)}
+    per_graph = [int(rp2[n1] - rp2[n0]) for n0, n1 in hb.graph_slices()]
+    d["c"] = _lib.DgcnCsr(hb.num_nodes, int(ci2.size), max(per_graph), d["row_ptr"].data_ptr(), d["col_idx"].data_ptr(), d["values"].data_ptr())
+    db.lap = d
+    layers = datagen.random_model(5, 32, bias=True, seed=13)
+    got = engine.forward(db, DeviceModel(layers, engine.device), mode=mode).cpu().numpy()
+    want = ctwin.forward((rp2, ci2, va2), layers, hb.num_nodes)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def _lgs_check(res, hb, golden, variant, ids):
     state = res["state"].cpu().numpy()
     rounds = res["rounds"].cpu().numpy()
