@@ -242,6 +242,16 @@ __global__ __launch_bounds__(BLOCK) void k_spmm_lds(const int32_t* __restrict__ 
 // not mean waiting for the prefetch (vmcnt retires in order).  131 us against 105 - 109 us for the 4 000-graph launch:
 // at 64 VGPRs (two 1024-thread workgroups per CU) the prefetch registers spill, and what the one-graph-per-workgroup
 // kernel gets for free - 16 000 workgroups in every phase of their lives at once - the pipeline has to build by hand.)
+// (Second attempt, later in round 3, with what the first one lacked: ONE 1024-thread workgroup per CU (128 VGPRs: nothing
+// spilled), two LDS buffers, the next graph's Z slice by LDS-DMA (global_load_lds_dwordx4 as an asm statement - through the
+// builtin the compiler orders the gather phase's first ds_read behind the DMA with s_waitcnt vmcnt(0) -; its pairs, row
+// bounds and "+ Y0" operands through registers that nothing reads before the current graph's rows are done; waits said with
+// __builtin_amdgcn_s_waitcnt so that the compiler's bookkeeping sees them), bounds of all the workgroup's graphs fetched
+// once.  Bit-exact, and the gather phase has no vector-memory wait left in it - yet 107.3 us against 105.4 us on the
+// 4 000-graph launch and 20.0 against 18.3 us on rotating 500-graph launches (tools/runs/r03_gpu31.sh).  A graph is 87 KB in
+// and 26 KB out, two buffers are all the LDS holds (3 x 61 KB > 160 KB), so the pipeline is one graph deep: an iteration
+// lasts what one graph's loads take from issue to arrival (~5 us at a CU's share of the HBM) plus the drain of its stores,
+// not the ~3 us of its gathers - which is what two co-resident workgroups of the plain kernel already achieve between them.)
 // ---------------------------------------------------------------------------------------------
 // Global-gather variant: no graph structure needed.
 template <int VEC, int LPR, int G>

@@ -9,7 +9,7 @@ import numpy as np, torch
 from distgcn_amd import datagen
 from distgcn_amd.engine import Engine
 
-KEYS = ("DGCN_SPMM_GLOBAL", "DGCN_SPMM_ROWS", "DGCN_SPMM_BLOCK", "DGCN_SPMM_CSRCAP", "DGCN_SPMM_PAD", "DGCN_SPMM_SPLIT", "DGCN_SPMM_XCD")
+KEYS = ("DGCN_SPMM_GLOBAL", "DGCN_SPMM_ROWS", "DGCN_SPMM_BLOCK", "DGCN_SPMM_CSRCAP", "DGCN_SPMM_PAD", "DGCN_SPMM_SPLIT", "DGCN_SPMM_XCD", "DGCN_SPMM_PERSIST")
 
 
 def make(eng, hb):
