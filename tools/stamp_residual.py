@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Phase clocks of ONE step of the residual-graph kernel in the middle of a rollout search (needs the -DDGCN_DIAG build):
+   DGCN_LIB=distgcn_amd/libdgcn_diag.so python tools/stamp_residual.py [steps_before=40] [graphs=64] [n=500] [cit|rollout]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from distgcn_amd import datagen
+from distgcn_amd.api_common import get_engine
+from distgcn_amd.mwis_gdpg_call import DQNAgent
+from distgcn_amd.runtime_config import FLAGS
+
+before = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+graphs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+which = sys.argv[4] if len(sys.argv) > 4 else "rollout"
+eng = get_engine()
+hb = datagen.er_batch(graphs, n, 0.02)
+agent = DQNAgent(FLAGS.copy(feature_size=1, hidden1=32, num_layer=20, diver_num=1, max_degree=1, predict="mwis"), seed=3)
+dm = agent.model.device_model(eng)
+db = eng.upload(hb)
+greedy = eng.GREEDY_ROLLOUT if which == "rollout" else eng.GREEDY_CENTRAL
+state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
+if before > 0:
+    eng.solve_residual(db, dm, state, greedy=greedy, max_rounds=1, beam=16, max_steps=before)
+torch.cuda.synchronize()
+left = (state.cpu().numpy() == 0).reshape(graphs, n).sum(1)
+st = torch.zeros(graphs * 64, dtype=torch.int64, device="cuda")
+os.environ["DGCN_FUSED_STAMPS"] = str(st.data_ptr())
+eng.solve_residual(db, dm, state, greedy=greedy, max_rounds=1, beam=16, max_steps=1)
+torch.cuda.synchronize()
+os.environ.pop("DGCN_FUSED_STAMPS")
+s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0
+names = ["P0a states, renumbering, counts", "P0b entries", "P0c order, records", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
+         "hidden A (sum)", "barrier after A (sum)", "last layer", "ranks + greedy step (+ completions)", "tail"]
+print("%s step after %d steps: %d graphs of %d vertices, %.0f left on average (min %d, max %d)" % (which, before, graphs, n, left.mean(), left.min(), left.max()))
+print("phase clocks of wave 0, hundred cycles: mean over graphs / max")
+for i, nm in enumerate(names):
+    print("%-40s %8.2f %8.2f" % (nm, s[:, i].mean(), s[:, i].max()))
+print("%-40s %8.2f" % ("sum of means", s[:, :12].mean(axis=0).sum()))
