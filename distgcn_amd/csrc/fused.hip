@@ -20,8 +20,12 @@
 //                     at an even slot so two words / two values come with one 4- / 8-byte LDS read;
 //                     rinfo = start | count << 16; perm = rows by descending entry count, dealt to the
 //                     waves in snake order so the 8 rows a wave walks in lockstep have equal length
-// N = 200, nnzL ~ 4.2k -> ~77 KB: two workgroups per CU, so one graph's MFMA phase overlaps the
-// other's LDS-bound gather phase.
+//   (global scratch) the same entries once more as 8-byte records {value, gather word}, block-major and padded to the trip
+//                     count of each 16-row block (row_blocks_init): what the 32-wide aggregations walk
+// N = 200, nnzL ~ 4.2k -> ~79 KB: two workgroups per CU.  (Measured in round 3, tools/ablate_fused.py: the two do NOT hide
+// each other's phases - fp32 MFMA keeps the other waves' vector instructions out of the SIMD - but each one's image build
+// and greedy rounds run under the other's layers.)
+// The residual-graph variant (MASKED) builds this image on the vertices that are still undecided, renumbered 0 .. na - 1.
 //
 // Arithmetic is the library-wide contract (include/dgcn.h): transform = k-ordered fmaf chain (fp32 MFMA
 // 16x16x4 is exactly that), aggregate = fmaf chain in entry order from 0, then Z0 + sum, + bias,
