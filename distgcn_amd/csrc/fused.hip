@@ -312,9 +312,19 @@ struct RowBlocks {  // (two named members, not an array: the kernel has no scrat
 
 template <int BLOCK>
 __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
-                                                const float* vals, const unsigned short* words, uint2* rec, unsigned zrow) {
+                                                const float* vals, const unsigned short* words, uint2* rec, unsigned zrow,
+                                                bool diag_parity = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
+    // (DGCN_DIAG builds, DGCN_FUSED_DIAG bit 4: every neighbour's parity forced to what makes its 16-lane bank group
+    // conflict-free - wrong results, a timing experiment: what would the aggregation cost without LDS bank conflicts?)
+    auto fix_word = [&](unsigned w) -> unsigned {
+        if (!diag_parity) return w;
+        const int u = (int)(w >> 7);
+        int u2 = (u & ~1) | ((s >> 2) & 1);
+        if (u2 >= ng) u2 = u;
+        return (unsigned)enc_word(u2);
+    };
     constexpr int kWaves = BLOCK / 64;
     const int blocks = (ng + 15) >> 4;  // <= 32
     // trips of block `lane` and the records in front of it (every wave computes the same table: one scan, once per graph)
@@ -351,14 +361,14 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
         const unsigned ri = has ? rinfo[B.v] : 0u;
         const int start = ri & 0xffff, cnt = ri >> 16;
         uint2 r0 = nothing;
-        if (kq < cnt) r0 = make_uint2(__float_as_uint(vals[start + kq]), (unsigned)words[start + kq]);
+        if (kq < cnt) r0 = make_uint2(__float_as_uint(vals[start + kq]), fix_word((unsigned)words[start + kq]));
         B.fx = r0.x;
         B.fy = r0.y;
         uint2* out = rec + B.base + lane;
         for (int t = 0; t < B.trips; ++t) {
             const int e = 4 * t + kq;
             uint2 r = nothing;
-            if (e < cnt) r = make_uint2(__float_as_uint(vals[start + e]), (unsigned)words[start + e]);
+            if (e < cnt) r = make_uint2(__float_as_uint(vals[start + e]), fix_word((unsigned)words[start + e]));
             out[t * 64] = r;
         }
     };
@@ -1383,7 +1393,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     ClusterRows cr;
     ClusterTile ctile;
     // (every wave writes the block-major records of its own row blocks: read back by the same lanes, no barrier)
-    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow);
+    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, DIAG_ON(a, 4) != 0);
     if constexpr (CLUSTER) {
         cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
         cluster_tile_init<BLOCK>(ctile, has_wide ? ng : 0, perm, K, cw);

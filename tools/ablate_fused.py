@@ -17,7 +17,8 @@ for _ in range(200):
     eng.solve_fused(db, model, out=out)
 torch.cuda.synchronize()
 rows = [("everything", 0), ("no aggregation (hidden layers)", 1), ("no transform (hidden layers)", 2), ("neither", 3),
-        ("neither, no weight fetch", 11), ("no greedy rounds", 4), ("layers only: neither + no greedy", 7)]
+        ("neither, no weight fetch", 11), ("no greedy rounds", 4), ("layers only: neither + no greedy", 7),
+        ("neighbour parities forced conflict-free", 16), ("... and no transform", 18)]
 for pad in ("0", "40000"):
     os.environ["DGCN_FUSED_LDS_PAD"] = pad
     print("workgroups per CU: %s" % ("2" if pad == "0" else "1 (LDS padded)"))
