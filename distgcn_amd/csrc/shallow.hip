@@ -330,6 +330,9 @@ __device__ __forceinline__ void shallow_body(const ShallowArgs a) {
     // neighbour), 0xFFFF while it is in: in round r a vertex counts as present iff kr >= r, so what a fast wave removes in
     // round r does not change what a slow wave still reads in round r - ONE barrier per round (which also carries the
     // "anybody still in?" votes) instead of two.  Priorities never change.
+    // (Tried: priority and stamp of a vertex side by side in one 16-byte word, ONE ds_read_b128 per neighbour instead of a
+    // ds_read_b64 and a ds_read_u16: 10.8 - 11.8 against 10.7 - 11.3 us for the C2 launch on one box - the round is a chain of
+    // round trips, not a count of LDS instructions.)
     // (Tried: ONE WAVE per graph with ceil(N / 64) vertices per lane and no barrier at all.  27.9 us against 12.6 us for
     // the C2 launch, 144 against 53 us on the BA mix: the phases are chains of dependent LDS round trips, and one wave has
     // nothing to issue while it waits - several waves per graph hide each other's latency.)
