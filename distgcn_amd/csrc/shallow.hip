@@ -330,6 +330,10 @@ __device__ __forceinline__ void shallow_body(const ShallowArgs a) {
     // neighbour), 0xFFFF while it is in: in round r a vertex counts as present iff kr >= r, so what a fast wave removes in
     // round r does not change what a slow wave still reads in round r - ONE barrier per round (which also carries the
     // "anybody still in?" votes) instead of two.  Priorities never change.
+    // (Tried: sixteen register neighbours per lane in the long-row kernels - ids packed two to a register, compared four at a
+    // time to stay inside 64 registers -, which cuts the listed entries of the densest graphs to a quarter: 43.4 - 43.6 against
+    // 41.2 - 41.4 us for the C4 share, the serialised compares cost more than the shorter sweeps save.  Weight and priority
+    // fetched again for the totals instead of carried through the rounds (4 registers): inside the noise on C2, + 1 % on C4.)
     // (Tried: priority and stamp of a vertex side by side in one 16-byte word, ONE ds_read_b128 per neighbour instead of a
     // ds_read_b64 and a ds_read_u16: 10.8 - 11.8 against 10.7 - 11.3 us for the C2 launch on one box - the round is a chain of
     // round trips, not a count of LDS instructions.)
