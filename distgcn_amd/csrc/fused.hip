@@ -311,9 +311,9 @@ struct RowBlocks {  // (two named members, not an array: the kernel has no scrat
 };
 
 template <int BLOCK>
-__device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
+__device__ __forceinline__ bool row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
                                                 const float* vals, const unsigned short* words, uint2* rec, unsigned zrow,
-                                                bool diag_parity = false) {
+                                                int rec_cap, bool diag_parity = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane >> 2, kq = lane & 3;
     // (DGCN_DIAG builds, DGCN_FUSED_DIAG bit 4: every neighbour's parity forced to what makes its 16-lane bank group
@@ -343,6 +343,11 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
     // co-resident workgroup's transform through.  Also: the second workgroup of a CU handing its left-over tiles / row blocks
     // - the 9th .. 13th of an N = 200 graph - to waves one further on, so that the SIMD with four tiles instead of three is
     // not the same one for both: 200.4 - 201.0 against 201.0 - 202.0 us in the same build, inside the noise.)
+    // The slice holds what fused_rec_cap() proves for a graph whose longest row has at most N entries.  A row longer than
+    // that (repeated columns in the caller's matrix) could outgrow it: such a graph gets no records - and a fault bit from
+    // the caller of this function - instead of writing past its slice.
+    const int total = blocks > 0 ? __shfl(incl, blocks - 1) : 0;
+    const bool fits_slice = total * 64 + 192 <= rec_cap;
     const uint2 nothing = make_uint2(0x80000000u, zrow);
     // (one call per block instead of an unrolled loop: with the record loop inside it the loop is unrolled only after the
     // pass that turns `rb` into registers has run, and the kernel would keep it in scratch memory)
@@ -350,7 +355,7 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
         constexpr int k = decltype(kc)::value;
         const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
         const int src = blk < blocks ? blk : 0;
-        const int trips = blk < blocks ? __shfl(tl, src) : 0;
+        const int trips = (blk < blocks && fits_slice) ? __shfl(tl, src) : 0;
         const unsigned base = (unsigned)(__shfl(incl, src) - __shfl(tl, src)) * 64u;
         RowBlock& B = rb.template at<k>();
         B.trips = __builtin_amdgcn_readfirstlane(trips);
@@ -375,6 +380,7 @@ __device__ __forceinline__ void row_blocks_init(RowBlocks& rb, int ng, const uns
     static_assert(kMaxRowBlocks == 2, "one call per row block");
     one_block(std::integral_constant<int, 0>{});
     one_block(std::integral_constant<int, 1>{});
+    return fits_slice;
 }
 
 // ---- cluster variant: one graph on K workgroups (one CU each) --------------------------------------------------
@@ -1393,7 +1399,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     ClusterRows cr;
     ClusterTile ctile;
     // (every wave writes the block-major records of its own row blocks: read back by the same lanes, no barrier)
-    if constexpr (!CLUSTER) row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, DIAG_ON(a, 4) != 0);
+    if constexpr (!CLUSTER) {
+        if (!row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, a.rec_cap, DIAG_ON(a, 4) != 0))
+            fault |= DGCN_FAULT_DEGREE_RANGE;  // (a row with more entries than the graph has vertices: results invalid)
+    }
     if constexpr (CLUSTER) {
         cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
         cluster_tile_init<BLOCK>(ctile, has_wide ? ng : 0, perm, K, cw);

@@ -41,7 +41,7 @@ enum { DGCN_ACT_LINEAR = 0, DGCN_ACT_LEAKY_RELU = 1, DGCN_ACT_RELU = 2 };
 enum {
     DGCN_FAULT_SELF_LOOP = 1,    /* adjacency has a diagonal entry (heuristics.py:94 would loop forever) */
     DGCN_FAULT_NAN_PRIORITY = 2, /* NaN priority (heuristics.py:103-111 never selects it: infinite loop) */
-    DGCN_FAULT_DEGREE_RANGE = 4, /* vertex degree >= dinv_table length */
+    DGCN_FAULT_DEGREE_RANGE = 4, /* vertex degree >= dinv_table length, or a row with (many) more entries than its graph has vertices */
     DGCN_FAULT_BAD_COLUMN = 8,   /* column id outside the owning graph's node range */
     DGCN_FAULT_CLUSTER = 16      /* small batches only (one graph on several workgroups): the workgroups of a graph did not
                                     end up on one XCD, or one of them never arrived - results are not valid; rerun with the

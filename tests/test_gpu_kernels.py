@@ -305,6 +305,35 @@ def test_forward_support_with_empty_rows(engine, mode):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_row_longer_than_its_graph_is_a_fault_not_a_stray_write(engine):
+    """The fused kernel's entry records live in a per-graph slice sized for rows of at most N entries.  A caller's matrix
+    with a column repeated hundreds of times in one row (nothing validates that on the way in) must not write past the
+    slice: the graph gets DGCN_FAULT_DEGREE_RANGE, its neighbours in the batch their usual results."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    rng = np.random.default_rng(3)
+    good = datagen.er_batch(2, 64, 0.1, first_index=900)
+    ps, cs, ws = [], [], []
+    for n0, n1 in good.graph_slices():
+        e0, e1 = int(good.row_ptr[n0]), int(good.row_ptr[n1])
+        ps.append((good.row_ptr[n0:n1 + 1] - e0).astype(np.int64)); cs.append((good.col_idx[e0:e1] - n0).astype(np.int64)); ws.append(good.weights[n0:n1])
+    n = 64
+    rows = [[1] * 400] + [[0]] + [[] for _ in range(n - 2)]  # vertex 0: column 1, four hundred times
+    ps.append(np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64))
+    cs.append(np.array([c for r in rows for c in r], dtype=np.int64)); ws.append(np.ones(n))
+    hb = HostBatch.from_csr_lists(ps, cs, ws)
+    dm = DeviceModel(datagen.random_model(6, 32, seed=2), engine.device)
+    for order in (0, 1):  # the bad graph last, then first
+        if order:
+            hb = HostBatch.from_csr_lists(ps[::-1], cs[::-1], ws[::-1])
+        res = engine.solve(engine.upload(hb), dm, mode=1)
+        engine.torch.cuda.synchronize()
+        assert int(res["status"].cpu().numpy()[0]) & 4
+    alone = engine.solve(engine.upload(good), dm, mode=1)
+    assert int(alone["status"].cpu().numpy()[0]) == 0
+
+
 def _lgs_check(res, hb, golden, variant, ids):
     state = res["state"].cpu().numpy()
     rounds = res["rounds"].cpu().numpy()
