@@ -18,7 +18,7 @@ FAULT_SELF_LOOP, FAULT_NAN_PRIORITY, FAULT_DEGREE_RANGE, FAULT_BAD_COLUMN = 1, 2
 FAULT_NAMES = {
     FAULT_SELF_LOOP: "adjacency has a self-loop (heuristics.py:94 would never terminate)",
     FAULT_NAN_PRIORITY: "NaN priority (heuristics.py:103-111 would never terminate)",
-    FAULT_DEGREE_RANGE: "vertex degree outside the d^-1/2 table",
+    FAULT_DEGREE_RANGE: "vertex degree outside the d^-1/2 table, or a row with more entries than its graph has vertices (repeated columns)",
     FAULT_BAD_COLUMN: "column index outside its graph's vertex range",
     16: "the workgroups of a graph lost each other (cluster variant of the fused kernel; now switched off for this process: call again)",
 }
