@@ -1222,21 +1222,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             const double wv = (was_alive && a.weights) ? a.weights[n0 + vid] : 1.0;
             xfill = was_alive ? (float)(wv / (wmax + 1e-9)) : 0.f;
         }
-        for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
-            const int v = vb + gw;
-            int cnt = 0;
+        // Rows are walked 8 lanes to a row, BLOCK / 8 rows at a time, twice: to count the remaining neighbours and, once the
+        // slots are known, to write the entries.  Every lane asks for the bounds of ALL its rows and then for the first 16
+        // columns of each before it looks at any of them (one dependent pair of round trips instead of one per 128 rows and
+        // pass: 18 -> 9 us of a 500-vertex step), and keeps them for the second walk.
+        constexpr int kRowsPerIt = BLOCK / 8;
+        constexpr int kIt = (kFusedMaxNodes + kRowsPerIt - 1) / kRowsPerIt;  // 4 (1024 threads) or 8
+        int r_s[kIt], r_e[kIt], r_o[kIt], c0[kIt], c1[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int v = wave * 8 + gw + it * kRowsPerIt;
+            r_s[it] = r_e[it] = 0;
+            r_o[it] = 0;
             if (v < ng) {
-                const int vo = orig[v];
-                const int rs = a.row_ptr[n0 + vo], re = a.row_ptr[n0 + vo + 1];
-                for (int j = rs + q; j < re; j += 8) {
-                    const int u = a.col_idx[j] - n0;
-                    if (u < 0 || u >= ng_full) fault |= DGCN_FAULT_BAD_COLUMN;
-                    else {
-                        if (u == vo) fault |= DGCN_FAULT_SELF_LOOP;
-                        cnt += al[u];
-                    }
-                }
+                r_o[it] = orig[v];
+                r_s[it] = a.row_ptr[n0 + r_o[it]];
+                r_e[it] = a.row_ptr[n0 + r_o[it] + 1];
             }
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            c0[it] = r_s[it] + q < r_e[it] ? a.col_idx[r_s[it] + q] - n0 : -1;
+            c1[it] = r_s[it] + 8 + q < r_e[it] ? a.col_idx[r_s[it] + 8 + q] - n0 : -1;
+        }
+        auto count_one = [&](int u, int vo, bool present) -> int {
+            if (!present) return 0;
+            if (u < 0 || u >= ng_full) { fault |= DGCN_FAULT_BAD_COLUMN; return 0; }
+            if (u == vo) fault |= DGCN_FAULT_SELF_LOOP;
+            return (int)al[u];
+        };
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int v = wave * 8 + gw + it * kRowsPerIt;
+            if (wave * 8 + it * kRowsPerIt >= ng) break;  // wave-uniform
+            const int rs = r_s[it], re = r_e[it], vo = r_o[it];
+            int cnt = count_one(c0[it], vo, rs + q < re) + count_one(c1[it], vo, rs + 8 + q < re);
+            for (int j = rs + 16 + q; j < re; j += 8) cnt += count_one(a.col_idx[j] - n0, vo, true);
             cnt += __shfl_xor(cnt, 1);
             cnt += __shfl_xor(cnt, 2);
             cnt += __shfl_xor(cnt, 4);
@@ -1259,16 +1280,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         }
         __syncthreads();
         hist_to_offsets(hist);
-        for (int vb = wave * 8; vb < ng; vb += BLOCK / 8) {
-            const int v = vb + gw;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int v = wave * 8 + gw + it * kRowsPerIt;
+            if (wave * 8 + it * kRowsPerIt >= ng) break;  // wave-uniform
             const bool act = v < ng;
-            const int vo = act ? (int)orig[v] : 0;
-            const int rs = act ? a.row_ptr[n0 + vo] : 0, re = act ? a.row_ptr[n0 + vo + 1] : 0;
+            const int rs = r_s[it], re = r_e[it];
             const int start = act ? (int)(rinfo[v] & 0xffff) : 0;
             int base = 1;  // slot 0 of the row is the diagonal
-            for (int j0 = rs; __any(j0 < re); j0 += 8) {
-                const int j = j0 + q;
-                int u = j < re ? a.col_idx[j] - n0 : -1;
+            auto place = [&](int u) {  // (every lane of the wave comes through here together: the ballot)
                 const bool keep = u >= 0 && u < ng_full && al[u];
                 const unsigned bits = (unsigned)(__ballot(keep) >> (gw * 8)) & 0xffu;
                 if (keep) {
@@ -1278,6 +1298,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     vals[slot] = (float)(-(dinv[uc] * dinv[v]));
                 }
                 base += __popc(bits);
+            };
+            place(c0[it]);  // (-1 where the row has no such entry)
+            if (__any(rs + 8 < re)) place(c1[it]);
+            for (int j0 = rs + 16; __any(j0 < re); j0 += 8) {
+                const int j = j0 + q;
+                place(j < re ? a.col_idx[j] - n0 : -1);
             }
         }
         __syncthreads();
