@@ -39,7 +39,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1500: ~0.3 s of timed region on C3; C5: 20 complete searches)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; C5: 2)")
-    ap.add_argument("--graphs", type=int, default=500, help="graphs per GPU (weak scaling) or in the whole job (strong)")
+    ap.add_argument("--graphs", type=int, default=None, help="graphs per GPU (weak scaling) or in the whole job (strong); default 500 (C5: 64, or any number given here: 256 puts one search on every CU)")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--p", type=float, default=0.1)
     ap.add_argument("--family", choices=["er", "ba"], default="er",
@@ -75,7 +75,9 @@ def parse(argv=None):
     elif args.config == "C4-share":
         args.family, args.graphs = "ba", 500
     elif args.config == "C5":
-        args.family, args.graphs, args.nodes, args.p, args.layers = "er", 64, 500, 0.02, 20
+        args.family, args.graphs, args.nodes, args.p, args.layers = "er", (args.graphs or 64), 500, 0.02, 20
+    if args.graphs is None:
+        args.graphs = 500
     if args.steps is None:
         args.steps = 20 if args.config == "C5" else 1500
     if args.warmup is None:
