@@ -61,6 +61,18 @@ struct DoneHook {
 };
 extern thread_local DoneHook g_done_hook;
 
+// The batch of the next dgcn_solve_batch of this thread is in the compact transfer form (include/dgcn.h: DgcnCompactInfo):
+// b->row_ptr / b->col_idx are null, the fused kernel takes degrees + 16-bit local columns straight into its image build
+// (host_solver.hip: no expansion launch between the copy and the solve).  Consumed (cleared) by that call; only set for
+// (batch, model) pairs that go to the deep-stack kernel (not the one-layer kernel, not the plain greedy search).
+struct CompactHook {
+    const int32_t* edge_ptr = nullptr;       // [num_graphs + 1] first entry of every graph
+    const unsigned short* deg = nullptr;     // [num_nodes] entries per row
+    const unsigned short* col = nullptr;     // [num_edges] column ids, local to their graph
+};
+extern thread_local CompactHook g_compact_hook;
+bool shallow_takes(const DgcnBatch* b, const DgcnModel* m);  // shallow.hip: one-layer models go to k_shallow
+
 // dgcn_pack_batch with one more check for callers whose kernel cannot report it (pack.hip)
 int pack_batch(const void* const* indptr_host, const void* const* indices_host, const double* const* weights_host,
                const int32_t* num_nodes_host, int32_t num_graphs, int32_t index_bytes, void* staging_host,

@@ -94,6 +94,9 @@ struct FusedArgs {
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
     const int32_t* order;  // null, or the graph of workgroup i (largest graphs first: k_graph_rank)
+    const int32_t* cedge;          // compact batch (common.h CompactHook), or null: first entry of every graph,
+    const unsigned short* cdeg;    // entries per row,
+    const unsigned short* ccol;    // column ids local to their graph (row_ptr / col_idx are null then)
     int32_t* done_flag;    // see DoneHook (common.h); null = no completion word
     uint32_t* done_count;
     uint32_t done_target;
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         a.stamps[(size_t)g * 64 + 14] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
+    const int e0 = (!MASKED && a.ccol) ? a.cedge[g] : a.row_ptr[n0], e1 = (!MASKED && a.ccol) ? a.cedge[g + 1] : a.row_ptr[n1];
     int fault = 0;
 
     // ------------------------------------------------------------ P0: the support matrix into LDS
@@ -1319,8 +1322,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
     __syncthreads();
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
+    // (compact batch: the row bounds are a block-wide exclusive scan of the degrees - one vertex per thread, ng <= BLOCK)
+    int crs = 0, cdg = 0;
+    if (a.ccol) {
+        int* wsum = rowstart + 520;  // [BLOCK / 64] wave totals (scratch like rowstart itself)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        cdg = (int)threadIdx.x < ng ? (int)a.cdeg[n0 + threadIdx.x] : 0;
+        int inc = cdg;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) before += w < wave ? wsum[w] : 0;
+        crs = e0 + before + inc - cdg;
+    }
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
-        const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+        const int rs = a.ccol ? crs : a.row_ptr[n0 + v], re = a.ccol ? crs + cdg : a.row_ptr[n0 + v + 1];
         const int start = ((rs - e0) + v * extra + v + 1) & ~1;
         rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
         rowstart[v] = rs - e0;
@@ -1355,7 +1377,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 c[i] = 0;
                 gv[i] = 0.f;
                 if (i < chunk && j < total) {
-                    c[i] = a.col_idx[e0 + j];
+                    c[i] = a.ccol ? (int)a.ccol[e0 + j] + n0 : a.col_idx[e0 + j];
                     if (!a.from_adj) gv[i] = a.vals[e0 + j];
                 }
             }
@@ -2131,26 +2153,29 @@ static size_t fused_pad_bytes(const DgcnModel* m) {
 // largest first, 358 us smallest first (tools/order_probe.py).  One tiny launch turns sizes into a dispatch order:
 // key = entries + 16 * vertices (the ratio of the two phases' costs), position = rank under (key desc, index asc).
 // key and index in one word, larger = earlier: (entries + 16 * vertices) << gbits | (all ones - index)
-__device__ __forceinline__ unsigned graph_key(const int32_t* graph_ptr, const int32_t* row_ptr, int g, int gbits, unsigned kmax) {
+__device__ __forceinline__ unsigned graph_key(const int32_t* graph_ptr, const int32_t* row_ptr, const int32_t* edge_ptr, int g, int gbits,
+                                              unsigned kmax) {
     const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    const unsigned entries = edge_ptr ? (unsigned)(edge_ptr[g + 1] - edge_ptr[g]) : (unsigned)(row_ptr[n1] - row_ptr[n0]);
     // (clamped to what the batch descriptor promises: whatever the data, the result is a permutation)
-    const unsigned key = min((unsigned)(row_ptr[n1] - row_ptr[n0]) + 16u * (unsigned)(n1 - n0), kmax);
+    const unsigned key = min(entries + 16u * (unsigned)(n1 - n0), kmax);
     return (key << gbits) | (((1u << gbits) - 1u) - (unsigned)g);
 }
 
 constexpr int kRankBlock = 256, kRankTile = 1024;
 __global__ __launch_bounds__(kRankBlock) void k_graph_rank(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr,
-                                                            int B, int gbits, unsigned kmax, int32_t* __restrict__ order) {
+                                                            const int32_t* __restrict__ edge_ptr, int B, int gbits, unsigned kmax,
+                                                            int32_t* __restrict__ order) {
     __shared__ unsigned tile[kRankTile];
     const int g = blockIdx.x * kRankBlock + threadIdx.x;
-    const unsigned kg = g < B ? graph_key(graph_ptr, row_ptr, g, gbits, kmax) : 0u;
+    const unsigned kg = g < B ? graph_key(graph_ptr, row_ptr, edge_ptr, g, gbits, kmax) : 0u;
     int pos = 0;
     for (int base = 0; base < B; base += kRankTile) {  // (every workgroup works out all keys itself: one launch, not two)
         unsigned ku[kRankTile / kRankBlock];
 #pragma unroll
         for (int i = 0; i < kRankTile / kRankBlock; ++i) {  // independent loads: two dependent round trips for the whole tile
             const int u = base + i * kRankBlock + threadIdx.x;
-            ku[i] = u < B ? graph_key(graph_ptr, row_ptr, u, gbits, kmax) : 0u;  // (padding: a key nobody is behind)
+            ku[i] = u < B ? graph_key(graph_ptr, row_ptr, edge_ptr, u, gbits, kmax) : 0u;  // (padding: a key nobody is behind)
         }
         __syncthreads();
 #pragma unroll
@@ -2323,7 +2348,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
                         workspace ? workspace_bytes : (size_t)0);
         int32_t* order = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
         const int blocks = (b->num_graphs + kRankBlock - 1) / kRankBlock;
-        hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(kRankBlock), 0, stream, b->graph_ptr, a->row_ptr, b->num_graphs,
+        hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(kRankBlock), 0, stream, b->graph_ptr, a->row_ptr, a->cedge, b->num_graphs,
                            fused_order_bits(b), (unsigned)(b->max_graph_edges + 16 * b->max_nodes), order);
         if (int rc = check_launch("k_graph_rank")) return rc;
         a->order = order;
@@ -2461,7 +2486,6 @@ int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, co
     return fused_launch(args, b->num_graphs, lds, "fused_forward", s, false, gvals);
 }
 
-bool shallow_takes(const DgcnBatch* b, const DgcnModel* m);
 int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
                   float x_const, const double* weights, int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds,
                   double* totals, int32_t* status, const DoneHook& hook, hipStream_t s);
@@ -2491,17 +2515,24 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
                                 void* workspace, size_t workspace_bytes, void* stream) {
     const DoneHook hook = g_done_hook;  // (host_solver.hip's completion word: this call's, whatever becomes of it)
     g_done_hook = DoneHook{};
+    const CompactHook compact = g_compact_hook;  // (... and its compact batch)
+    g_compact_hook = CompactHook{};
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
     if (b->num_graphs <= 0) return DGCN_OK;
     // one-layer models: the small dedicated kernel (shallow.hip) - same results, a fraction of the dependent chain
-    if (shallow_takes(b, m))
+    if (shallow_takes(b, m)) {
+        if (compact.col) return fail(DGCN_ERR_ARG, "dgcn_solve_batch: the one-layer kernel takes expanded batches only");
         return shallow_solve(b, m, dinv_table, table_len, X, x_const, weights, predict_mwis, scores, state, rounds, totals, status, hook,
                              (hipStream_t)stream);
+    }
     FusedArgs args = {};
     args.row_ptr = b->row_ptr;
     args.col_idx = b->col_idx;
+    args.cedge = compact.edge_ptr;
+    args.cdeg = compact.deg;
+    args.ccol = compact.col;
     args.vals = nullptr;
     args.dinv_table = dinv_table;
     args.table_len = table_len;

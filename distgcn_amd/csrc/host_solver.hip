@@ -30,6 +30,10 @@ struct DgcnHostSolver {
         void* in_dev = nullptr;
         size_t in_cap = 0;
         void* exp_dev = nullptr;  // compact transfers: the expanded row_ptr | col_idx (expand.hip)
+        bool compact_direct = false;  // ... or the batch goes to the fused kernel as it is:
+        const int32_t* c_edge = nullptr;
+        const unsigned short* c_deg = nullptr;
+        const unsigned short* c_col = nullptr;
         size_t exp_cap = 0;
         void* out_host = nullptr;  // pinned: totals | rounds | status | state
         void* out_host_dev = nullptr;
@@ -169,6 +173,11 @@ static int launch_slot(DgcnHostSolver* h, DgcnHostSolver::Slot& s) {
                             reinterpret_cast<int32_t*>(ob + s.off_rounds), nullptr, nullptr, wdev,
                             reinterpret_cast<double*>(ob + s.off_totals), reinterpret_cast<int32_t*>(ob + s.off_status), s.stream);
     else {
+        if (s.compact_direct) {
+            g_compact_hook.edge_ptr = s.c_edge;
+            g_compact_hook.deg = s.c_deg;
+            g_compact_hook.col = s.c_col;
+        }
         if (s.done_total) {  // the finishing workgroups count themselves; the last one writes the word beside the status
             g_done_hook.flag = reinterpret_cast<int32_t*>(ob + s.off_status + 8);
             g_done_hook.count = s.done_count;
@@ -304,12 +313,28 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     b.max_nodes = info.max_nodes;
     b.max_graph_edges = info.max_graph_edges;
     size_t exp_col_off = 0;
+    // A compact batch for the deep-stack kernel stays compact: the kernel's image build reads degrees and 16-bit local
+    // columns itself (no expansion launch, which - starved of CUs by the previous batch's solve - ended with that solve and
+    // left 17 us between two solves; nor its 8.4 MB of row pointers and columns).  The one-layer kernel and the plain greedy
+    // search take the expanded form.
+    s.compact_direct = false;
     if (compact) {
-        exp_col_off = align16(((size_t)info.num_nodes + 1) * 4);
-        if ((rc = ensure_exp(s, exp_col_off + align16((size_t)std::max(info.num_edges, 1) * 4)))) return rc;
         b.graph_ptr = reinterpret_cast<const int32_t*>(base + ci.off_graph_ptr);
-        b.row_ptr = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev));
-        b.col_idx = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off);
+        b.row_ptr = nullptr;
+        b.col_idx = nullptr;
+        const char* direct_env = getenv("DGCN_HOST_COMPACT_DIRECT");  // (per call, like DGCN_HOST_COMPACT: tests switch it)
+        const bool direct_ok = !direct_env || atoi(direct_env) != 0;
+        s.compact_direct = direct_ok && !h->lgs_only && !shallow_takes(&b, &h->model);
+        if (s.compact_direct) {
+            s.c_edge = reinterpret_cast<const int32_t*>(base + ci.off_edge_ptr);
+            s.c_deg = reinterpret_cast<const unsigned short*>(base + ci.off_deg);
+            s.c_col = reinterpret_cast<const unsigned short*>(base + ci.off_col);
+        } else {
+            exp_col_off = align16(((size_t)info.num_nodes + 1) * 4);
+            if ((rc = ensure_exp(s, exp_col_off + align16((size_t)std::max(info.num_edges, 1) * 4)))) return rc;
+            b.row_ptr = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev));
+            b.col_idx = reinterpret_cast<const int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off);
+        }
     } else {
         b.graph_ptr = reinterpret_cast<const int32_t*>(base + info.off_graph_ptr);
         b.row_ptr = reinterpret_cast<const int32_t*>(base + info.off_row_ptr);
@@ -347,7 +372,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
             hipStream_t in_stream = h->slots.size() == 1 ? s.stream : h->copy_stream;
             if (hipMemcpyAsync(s.in_dev, s.in_host, copy_bytes, hipMemcpyHostToDevice, in_stream) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "dgcn_host_solver_submit: host-to-device copy failed");
-            if (compact && (rc = expand_compact(s.in_dev, &ci, info.num_graphs, info.num_nodes, info.max_nodes,
+            if (compact && !s.compact_direct && (rc = expand_compact(s.in_dev, &ci, info.num_graphs, info.num_nodes, info.max_nodes,
                                                 static_cast<int32_t*>(s.exp_dev), reinterpret_cast<int32_t*>(static_cast<char*>(s.exp_dev) + exp_col_off),
                                                 in_stream)))
                 return rc;

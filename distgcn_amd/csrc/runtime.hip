@@ -10,6 +10,7 @@ namespace dgcn {
 
 static thread_local char g_err[512] = "";
 thread_local DoneHook g_done_hook;
+thread_local CompactHook g_compact_hook;
 
 void set_error(const char* fmt, ...) {
     va_list ap;

@@ -1240,7 +1240,7 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
 def test_host_solver_compact_transfer(engine, monkeypatch):
     """Batches above the in-place threshold cross PCIe in the compact form (16-bit local column ids + degrees: include/dgcn.h
     DgcnCompactInfo) and are expanded on the device (csrc/expand.hip): same sets / rounds / totals / scores as the ordinary
-    transfer (DGCN_HOST_COMPACT=0) and as the twin, on the BA mix (hubs, 100..300 vertices), an ER batch, and a batch with an
+    transfer (DGCN_HOST_COMPACT=0), as the expanded-on-the-device form (DGCN_HOST_COMPACT_DIRECT=0) and as the twin, on the BA mix (hubs, 100..300 vertices), an ER batch, and a batch with an
     unsorted row (entry order is the caller's, in both forms); the plain greedy search (no model) goes the same way."""
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
@@ -1267,14 +1267,17 @@ def test_host_solver_compact_transfer(engine, monkeypatch):
     for ps, cs, ws in cases:
         hb = HostBatch.from_csr_lists(ps, cs, ws)
         ref = ctwin.solve(hb, layers)
-        for mode in ("1", "0"):
+        # compact + read by the fused kernel as it is (the default), compact + expanded on the device first, ordinary transfer
+        for mode, direct in (("1", "1"), ("1", "0"), ("0", "1")):
             monkeypatch.setenv("DGCN_HOST_COMPACT", mode)
+            monkeypatch.setenv("DGCN_HOST_COMPACT_DIRECT", direct)
             hs = HostSolver(engine, dm, depth=2, want_scores=True)
             g = [hs.solve(ps, cs, ws) for _ in range(2)][-1]
             hs.close()
-            assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["rounds"], ref["rounds"]), mode
+            assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["rounds"], ref["rounds"]), (mode, direct)
             assert np.allclose(g["totals"], ref["totals"], rtol=1e-12, atol=0)
-            assert np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32)), mode
+            assert np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32)), (mode, direct)
+        monkeypatch.delenv("DGCN_HOST_COMPACT_DIRECT")
     ps, cs, ws = cases[0]
     hb = HostBatch.from_csr_lists(ps, cs, ws)
     want = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, hb.weights, sum_weights=hb.weights, want_stats=False)
