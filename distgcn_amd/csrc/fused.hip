@@ -22,9 +22,9 @@
 //                     waves in snake order so the 8 rows a wave walks in lockstep have equal length
 //   (global scratch) the same entries once more as 8-byte records {value, gather word}, block-major and padded to the trip
 //                     count of each 16-row block (row_blocks_init): what the 32-wide aggregations walk
-// N = 200, nnzL ~ 4.2k -> ~79 KB: two workgroups per CU.  (Measured in round 3, tools/ablate_fused.py: the two do NOT hide
-// each other's phases - fp32 MFMA keeps the other waves' vector instructions out of the SIMD - but each one's image build
-// and greedy rounds run under the other's layers.)
+// N = 200, nnzL ~ 4.2k -> ~79 KB: two workgroups per CU.  (Measured in round 3, tools/ablate_fused.py, one against two per
+// CU: the two hide each other's image build and greedy rounds almost completely, each other's layer phases only by a fifth -
+// fp32 MFMA keeps the other waves' vector instructions out of the SIMD.)
 // The residual-graph variant (MASKED) builds this image on the vertices that are still undecided, renumbered 0 .. na - 1.
 //
 // Arithmetic is the library-wide contract (include/dgcn.h): transform = k-ordered fmaf chain (fp32 MFMA
