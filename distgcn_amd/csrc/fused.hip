@@ -1082,7 +1082,9 @@ __device__ __forceinline__ void signal_done(const FusedArgs& a) {
     }
 }
 
-template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false>
+// COMPACT: the batch comes in the compact transfer form (common.h CompactHook): a kernel of its own, also by name - what a
+// profile of the host-to-host path shows (solves of consecutive batches overlapping) does not mix into the resident launch's row.
+template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false, bool COMPACT = false>
 // (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         a.stamps[(size_t)g * 64 + 14] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const int e0 = (!MASKED && a.ccol) ? a.cedge[g] : a.row_ptr[n0], e1 = (!MASKED && a.ccol) ? a.cedge[g + 1] : a.row_ptr[n1];
+    const int e0 = COMPACT ? a.cedge[g] : a.row_ptr[n0], e1 = COMPACT ? a.cedge[g + 1] : a.row_ptr[n1];
     int fault = 0;
 
     // ------------------------------------------------------------ P0: the support matrix into LDS
@@ -1324,7 +1326,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     const int extra = a.from_adj ? 1 : 0;            // the diagonal entry is synthesised from the adjacency
     // (compact batch: the row bounds are a block-wide exclusive scan of the degrees - one vertex per thread, ng <= BLOCK)
     int crs = 0, cdg = 0;
-    if (a.ccol) {
+    if constexpr (COMPACT) {
         int* wsum = rowstart + 520;  // [BLOCK / 64] wave totals (scratch like rowstart itself)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         cdg = (int)threadIdx.x < ng ? (int)a.cdeg[n0 + threadIdx.x] : 0;
@@ -1342,7 +1344,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         crs = e0 + before + inc - cdg;
     }
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
-        const int rs = a.ccol ? crs : a.row_ptr[n0 + v], re = a.ccol ? crs + cdg : a.row_ptr[n0 + v + 1];
+        const int rs = COMPACT ? crs : a.row_ptr[n0 + v], re = COMPACT ? crs + cdg : a.row_ptr[n0 + v + 1];
         const int start = ((rs - e0) + v * extra + v + 1) & ~1;
         rinfo[v] = (unsigned)start | ((unsigned)(re - rs + extra) << 16);
         rowstart[v] = rs - e0;
@@ -1377,7 +1379,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 c[i] = 0;
                 gv[i] = 0.f;
                 if (i < chunk && j < total) {
-                    c[i] = a.ccol ? (int)a.ccol[e0 + j] + n0 : a.col_idx[e0 + j];
+                    c[i] = COMPACT ? (int)a.ccol[e0 + j] + n0 : a.col_idx[e0 + j];
                     if (!a.from_adj) gv[i] = a.vals[e0 + j];
                 }
             }
@@ -2384,7 +2386,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     return DGCN_OK;
 }
 
-template <bool MASKED, bool GVALS, int BLOCK>
+template <bool MASKED, bool GVALS, int BLOCK, bool COMPACT = false>
 static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         // raise the kernel's dynamic-LDS limit once per device and size (the attribute call is a driver round trip)
@@ -2393,43 +2395,43 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
         (void)hipGetDevice(&dev);
         std::atomic<size_t>& have = reserved[dev & 63];
         if (lds > have.load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK, false, COMPACT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
             if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
             have.store(kLdsLimit, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
 }
 
 // An image above half the LDS leaves its graph alone on a CU: 16 waves instead of 8 then work on it
 // (at 128 VGPRs both fit the register file exactly).  DGCN_FUSED_BLOCK=512|1024 overrides (tuning / tests).
-template <bool MASKED, bool GVALS>
+template <bool MASKED, bool GVALS, bool COMPACT = false>
 static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     // ... and so does every graph of a batch that has no more graphs than the device has CUs
     const int ncu = device_cus();
     bool big = ((lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
     if (const char* e = getenv("DGCN_FUSED_BLOCK"))
         big = (atoi(e) == kFusedBlockBig && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
-    return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig>(a, B, lds, family, s)
-               : fused_launch_b<MASKED, GVALS, kFusedBlock>(a, B, lds, family, s);
+    return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig, COMPACT>(a, B, lds, family, s)
+               : fused_launch_b<MASKED, GVALS, kFusedBlock, COMPACT>(a, B, lds, family, s);
 }
 
-template <bool MASKED, bool GVALS>
+template <bool MASKED, bool GVALS, bool COMPACT = false>
 static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     static std::atomic<size_t> reserved[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 64 * 1024 && lds > reserved[dev & 63].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, kFusedBlock, true>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, kFusedBlock, true, COMPACT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
         reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, kFusedBlock, true>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, kFusedBlock, true, COMPACT>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
     return check_launch("k_fused (cluster)");
 }
 
@@ -2443,11 +2445,15 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
     a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
     a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
 #endif
+    const bool compact = a.ccol != nullptr;
+    if (compact && masked) return fail(DGCN_ERR_ARG, "k_fused: the residual-graph variant takes expanded batches only");
     if (a.cluster > 1) {
         if (masked) return gvals ? fused_launch_cluster<true, true>(a, B, lds, family, s) : fused_launch_cluster<true, false>(a, B, lds, family, s);
+        if (compact) return gvals ? fused_launch_cluster<false, true, true>(a, B, lds, family, s) : fused_launch_cluster<false, false, true>(a, B, lds, family, s);
         return gvals ? fused_launch_cluster<false, true>(a, B, lds, family, s) : fused_launch_cluster<false, false>(a, B, lds, family, s);
     }
     if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
+    if (compact) return gvals ? fused_launch_t<false, true, true>(a, B, lds, family, s) : fused_launch_t<false, false, true>(a, B, lds, family, s);
     return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
 }
 
