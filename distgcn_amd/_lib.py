@@ -26,7 +26,7 @@ FAULT_NAMES = {
 # every symbol include/dgcn.h declares; tests/test_cabi.py checks the library exports them all
 SYMBOLS = (
     "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_pack_compact_layout", "dgcn_pack_compact_batch", "dgcn_expand_compact_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_set_cluster", "dgcn_get_cluster", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
-    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
+    "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_path", "dgcn_set_general", "dgcn_get_general", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_host_solver_create", "dgcn_host_solver_destroy", "dgcn_host_solver_submit", "dgcn_host_solver_result",
     "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
 )
@@ -146,6 +146,12 @@ def load():
     lib.dgcn_lgs_masked_batch.argtypes = [C.POINTER(DgcnBatch), vp, C.c_int64, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.dgcn_solve_supported.restype = C.c_int
     lib.dgcn_solve_supported.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel)]
+    lib.dgcn_solve_path.restype = C.c_int
+    lib.dgcn_solve_path.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel)]
+    lib.dgcn_set_general.restype = None
+    lib.dgcn_set_general.argtypes = [i32]
+    lib.dgcn_get_general.restype = i32
+    lib.dgcn_get_general.argtypes = []
     lib.dgcn_solve_batch.restype = C.c_int
     lib.dgcn_solve_workspace.restype = C.c_size_t
     lib.dgcn_solve_workspace.argtypes = [C.POINTER(DgcnBatch), C.POINTER(DgcnModel)]

@@ -19,6 +19,8 @@ int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, 
 int layer32_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_nodes, const float* Z, const float* bias, int act,
                      const float* Wn, int ctot_next, float* Zn, hipStream_t s);
 size_t fused_workspace(const DgcnBatch* b, const DgcnModel* m);
+int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const DgcnModel* m, const float* X, float x_const, float* scores,
+                    void* workspace, hipStream_t s);  // (also called by general.hip)
 int fused_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const,
                   float* scores, void* ws, size_t ws_bytes, hipStream_t s);
 
@@ -162,8 +164,8 @@ extern "C" size_t dgcn_gcn_forward_workspace(const DgcnBatch* b, const DgcnModel
 // Layer-by-layer forward over the supports [I, T_1, .., T_k] (k = num_supports - 1 CSR matrices given).
 // Per layer: Z = H.[W_0 | .. | W_k]; out = Z_0 + T_1.Z_1 (+ T_2.Z_2 ...) in support order - tf.add_n sums
 // left to right (gcn/layers.py:208) - then bias, activation in the last aggregation's epilogue.
-static int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const DgcnModel* m, const float* X,
-                           float x_const, float* scores, void* workspace, hipStream_t s) {
+int dgcn::layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const DgcnModel* m, const float* X,
+                          float x_const, float* scores, void* workspace, hipStream_t s) {
     int mo;
     layered_dims(m, &mo);
     const int K = m->num_supports;

@@ -2496,6 +2496,18 @@ int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
                   float x_const, const double* weights, int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds,
                   double* totals, int32_t* status, const DoneHook& hook, hipStream_t s);
 
+// general.hip: the same solvers for graphs of any size (compaction + layer-by-layer forward + greedy kernels)
+size_t general_workspace(const DgcnBatch* b, const DgcnModel* m);
+int general_takes(const DgcnBatch* b, const DgcnModel* m);
+int general_setting();
+int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
+                  float x_const, const double* weights, int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds,
+                  double* totals, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s);
+int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
+                     float x_const, int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t greedy_mode,
+                     int32_t max_rounds, int32_t beam, int32_t options, float* scores, uint8_t* state, int32_t* rounds,
+                     double* totals, int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 }  // namespace dgcn
 
 using namespace dgcn;
@@ -2510,8 +2522,16 @@ extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {
     return fused_variant(max(b->max_nodes, 64), cap) >= 0;
 }
 
+// 1 = the per-graph fused kernels (k_fused / k_shallow), 2 = the any-size path of general.hip, 0 = neither
+extern "C" int dgcn_solve_path(const DgcnBatch* b, const DgcnModel* m) {
+    if (!b || !m || !m->layers_host) return 0;
+    if (general_setting() != 1 && dgcn_solve_supported(b, m)) return 1;
+    return general_takes(b, m) ? 2 : 0;
+}
+
 extern "C" size_t dgcn_solve_workspace(const DgcnBatch* b, const DgcnModel* m) {
     if (!b || !m) return 0;
+    if (m->layers_host && dgcn_solve_path(b, m) == 2) return general_workspace(b, m);
     return fused_scratch(b, m, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
 }
 
@@ -2527,6 +2547,12 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
     if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
     if (b->num_graphs <= 0) return DGCN_OK;
+    // graphs whose image does not fit a CU's LDS (or models wider than the fused kernel's 32): the any-size path, same results
+    if (dgcn_solve_path(b, m) != 1) {
+        if (compact.col) return fail(DGCN_ERR_ARG, "dgcn_solve_batch: the any-size path takes expanded batches only");
+        return general_solve(b, m, dinv_table, table_len, X, x_const, weights, predict_mwis, scores, state, rounds, totals, status,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+    }
     // one-layer models: the small dedicated kernel (shallow.hip) - same results, a fraction of the dependent chain
     if (shallow_takes(b, m)) {
         if (compact.col) return fail(DGCN_ERR_ARG, "dgcn_solve_batch: the one-layer kernel takes expanded batches only");
@@ -2581,6 +2607,10 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     if (feature_mode == 1 && (!weights || X))
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: feature_mode 1 derives X from the weights");
     if (b->num_graphs <= 0) return DGCN_OK;
+    if (dgcn_solve_path(b, m) != 1)
+        return general_residual(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, greedy_mode, max_rounds,
+                                beam, options, scores, state, rounds, totals, progress, status, workspace, workspace_bytes,
+                                (hipStream_t)stream);
     FusedArgs args = {};
     args.row_ptr = b->row_ptr;
     args.col_idx = b->col_idx;

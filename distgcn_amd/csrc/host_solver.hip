@@ -10,8 +10,8 @@
 //     dgcn_host_solver_result  = wait for the slot's event -> pointers into its pinned result
 // (a batch of up to 2 MB skips both copies: the kernel works on the pinned buffers directly)
 // with no interpreter, allocator or framework call in between; several slots overlap packing, copies and kernels of
-// consecutive batches.  Only shapes the fused kernel takes (dgcn_solve_supported); other shapes return
-// DGCN_ERR_UNSUPPORTED and go through the separate calls.  No device code in this file.
+// consecutive batches.  Shapes the fused kernel does not take go through dgcn_solve_batch's any-size path (general.hip),
+// same calls, same results.  No device code in this file.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -324,7 +324,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
         b.col_idx = nullptr;
         const char* direct_env = getenv("DGCN_HOST_COMPACT_DIRECT");  // (per call, like DGCN_HOST_COMPACT: tests switch it)
         const bool direct_ok = !direct_env || atoi(direct_env) != 0;
-        s.compact_direct = direct_ok && !h->lgs_only && !shallow_takes(&b, &h->model);
+        s.compact_direct = direct_ok && !h->lgs_only && dgcn_solve_path(&b, &h->model) == 1 && !shallow_takes(&b, &h->model);
         if (s.compact_direct) {
             s.c_edge = reinterpret_cast<const int32_t*>(base + ci.off_edge_ptr);
             s.c_deg = reinterpret_cast<const unsigned short*>(base + ci.off_deg);
@@ -340,8 +340,8 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
         b.row_ptr = reinterpret_cast<const int32_t*>(base + info.off_row_ptr);
         b.col_idx = reinterpret_cast<const int32_t*>(base + info.off_col_idx);
     }
-    if (!h->lgs_only && !dgcn_solve_supported(&b, &h->model))
-        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_host_solver_submit: this model / batch shape is outside the fused kernel");
+    if (!h->lgs_only && !dgcn_solve_path(&b, &h->model))
+        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_host_solver_submit: this model / batch shape is outside the fused kernel and outside the any-size path");
     if ((rc = ensure_out(s, info.num_nodes, info.num_graphs, h->want_scores != 0))) return rc;
     if (!h->lgs_only) {
         const size_t need = dgcn_solve_workspace(&b, &h->model);
@@ -360,7 +360,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
             st[0] = 0;
             // the latency path (one slot, nothing else to do meanwhile): a completion word written by the kernel itself
             static const bool word_ok = [] { const char* e = getenv("DGCN_HOST_DONE_WORD"); return !e || atoi(e) != 0; }();
-            if (word_ok && h->slots.size() == 1 && !h->lgs_only && s.done_count) {
+            if (word_ok && h->slots.size() == 1 && !h->lgs_only && s.done_count && dgcn_solve_path(&b, &h->model) == 1) {
                 s.done_base += (uint32_t)info.num_graphs;
                 s.done_total = s.done_base;
                 st[2] = 0;

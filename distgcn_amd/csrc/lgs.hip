@@ -43,6 +43,8 @@ struct LgsArgs {
     const uint8_t* init_state;  // non-zero = vertex does not take part (kept as given in the output)
     int num_graphs, num_nodes;
     long prio_stride;
+    const int32_t* active;      // [num_graphs] or null: 0 = leave this graph alone (rounds 0, total 0, state untouched) -
+                                // the "nothing left / no positive weight left" graphs of a residual step (general.hip)
 };
 
 template <bool COLS_LDS>
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
         if (a.prio) a.prio += (size_t)inst * a.prio_stride;
     }
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
-    const int ng = n1 - n0;
+    const int ng = (a.active && !a.active[g]) ? 0 : n1 - n0;
     // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | i32 row offsets | u8 st | u8 nw | u16 cols]
     double* pr = reinterpret_cast<double*>(lds_raw);
     double* red = pr + a.max_nodes;
@@ -242,20 +244,26 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
             if (a.stats) { a.stats[2 * g] = 0; a.stats[2 * g + 1] = 0; }
             if (a.totals) a.totals[g] = 0.0;
         }
-        for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = 0;
+        for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = a.init_state ? a.init_state[n0 + v] : (uint8_t)0;
         return;
     }
     if (cols_lds) lgs_rounds<LPV, STATS, true>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
     else lgs_rounds<LPV, STATS, false>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
 
-    for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = st[v];
-    if (a.totals) {
-        // fixed-shape reduction: strided partials, then a binary tree over the 256 slots
+    {
+        // totals: fixed-shape reduction - strided partials, then a binary tree over the 256 slots.  A vertex that was given
+        // as a member already (init_state 1: the residual steps of general.hip pass the running state) is not counted:
+        // the total is what joined in THIS search.  (init_state may alias state: read before the write, same thread.)
         const double* sw = a.sum_weights;
         double part = 0.0;
-        for (int v = threadIdx.x; v < ng; v += 256)
-            if (st[v] == 1) part += sw ? sw[n0 + v] : pr[v];
+        for (int v = threadIdx.x; v < ng; v += 256) {
+            const uint8_t s1 = st[v];
+            if (a.totals && s1 == 1 && !(a.init_state && a.init_state[n0 + v] == 1)) part += sw ? sw[n0 + v] : pr[v];
+            a.state[n0 + v] = s1;
+        }
         red[threadIdx.x] = part;
+    }
+    if (a.totals) {
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
             if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
@@ -346,10 +354,12 @@ extern "C" int dgcn_margin_risk_batch(const DgcnBatch* b, const double* prio, co
     return check_launch("k_margin_risk");
 }
 
-static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
-                             const double* weights, const uint8_t* init_state, int32_t num_instances,
-                             int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
-                             const double* sum_weights, double* totals, int32_t* status, void* stream);
+namespace dgcn {
+int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
+                      const double* weights, const uint8_t* init_state, int32_t num_instances,
+                      int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                      const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active = nullptr);
+}
 
 extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const float* scores, const double* weights,
                               int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
@@ -368,10 +378,10 @@ extern "C" int dgcn_lgs_masked_batch(const DgcnBatch* b, const double* prio, int
                              rounds, nullptr, nullptr, sum_weights, totals, status, stream);
 }
 
-static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
-                             const double* weights, const uint8_t* init_state, int32_t num_instances,
-                             int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
-                             const double* sum_weights, double* totals, int32_t* status, void* stream) {
+int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
+                            const double* weights, const uint8_t* init_state, int32_t num_instances,
+                            int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
+                            const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active) {
     if (!b || !state || !status) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: null argument");
     if (!prio && !scores) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: need prio or scores");
     if (b->num_graphs <= 0) return DGCN_OK;
@@ -390,6 +400,7 @@ static int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_s
     a.num_graphs = b->num_graphs;
     a.num_nodes = b->num_nodes;
     a.prio_stride = prio_stride;
+    a.active = active;
     // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
     // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
     int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;

@@ -372,7 +372,14 @@ class Engine:
         return res
 
     def solve_supported(self, b: DeviceBatch, model: DeviceModel) -> bool:
+        """Does the per-graph fused kernel (one workgroup, one graph, everything in LDS) take this batch?"""
         return bool(self.lib.dgcn_solve_supported(C.byref(b.c), C.byref(model.c)))
+
+    def solve_path(self, b: DeviceBatch, model: DeviceModel) -> int:
+        """What ``solve_fused`` / ``solve_residual`` (``dgcn_solve_batch`` / ``dgcn_solve_residual_batch``) will run:
+        1 = the fused kernels, 2 = the any-size device path (``csrc/general.hip``: graphs beyond 512 vertices or one
+        CU's LDS, layer stacks wider than 32), 0 = neither."""
+        return int(self.lib.dgcn_solve_path(C.byref(b.c), C.byref(model.c)))
 
     def solve_buffers(self, b: DeviceBatch, want_scores: bool = True, cap_nodes: int = 0, cap_graphs: int = 0):
         """Output buffers of ``solve_fused`` for a batch, for callers that re-use them across calls

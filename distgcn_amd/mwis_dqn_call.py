@@ -227,7 +227,9 @@ def solve_host_batch(eng, model, hb: HostBatch, predict: str = "mwis", mode: str
     fused_ok = eng.solve_supported(db, dm)
     if mode == "fused" and not fused_ok:
         raise _lib.DgcnError("this model / batch shape is outside the fused kernel; use mode='layered'")
-    use_fused = fused_ok if mode == "auto" else (mode == "fused")
+    # "auto": ONE C call either way - dgcn_solve_batch runs the fused kernel, or for larger graphs / wider models its
+    # any-size path (supports + layer-by-layer forward + greedy search); "layered" composes the separate entry points here
+    use_fused = (hb.num_nodes > 0 and eng.solve_path(db, dm) != 0) if mode == "auto" else (mode == "fused")
     from .engine import MODE_FUSED, MODE_LAYERED
     if use_fused and hb.num_nodes > 0:  # one launch, one device-to-host copy
         for attempt in (0, 1):

@@ -101,10 +101,11 @@ class MWISSolver(object):
 
 
     # ---- iterative solvers on the same kernels ------------------------------
-    # Shapes the fused kernel handles run entirely on the device (solve_iterative_batch: the residual
-    # graph is a mask applied while the LDS image is built).  Other shapes re-slice the residual graph
-    # on the host exactly as the reference does (SciPy) and run every forward pass, greedy round and
-    # rollout completion on the device.
+    # Every shape runs entirely on the device (solve_iterative_batch): graphs the fused kernel takes with the residual
+    # graph as a mask applied while the LDS image is built, larger ones with the residual graph re-sliced by the
+    # any-size path (csrc/general.hip).  The host loop below - SciPy re-slicing exactly as the reference does, with every
+    # forward pass, greedy round and rollout completion on the device - remains for ``device_iterative = False``,
+    # ``reference_ties`` and models with more than two supports.
     def _residual_scores(self, adj_nn, wts_nn):
         """(DeviceBatch, device scores [n,1]) of one residual graph: ``makestate`` + ``act``."""
         eng = get_engine()
@@ -137,8 +138,8 @@ class MWISSolver(object):
 
     def solve_iterative_batch(self, adjs: Sequence, wts_list: Sequence, which: str = "dit", b: int = 16):
         """``solve_mwis_dit`` / ``_cit`` / ``_rollout`` (and ``rollout00`` / ``rollout0`` / ``rollout1``) for
-        many graphs at once, one launch per step for the whole batch (``Engine.solve_residual``); None when
-        the shapes are outside the fused kernel."""
+        many graphs at once, one step of the whole batch per call of ``dgcn_solve_residual_batch``
+        (``Engine.solve_residual``); None when neither the fused kernel nor the any-size path takes the shapes."""
         import torch
         csrs = [as_csr(a) for a in adjs]
         hb = HostBatch.from_csr_lists([c.indptr for c in csrs],
@@ -147,7 +148,8 @@ class MWISSolver(object):
         eng = get_engine()
         db = eng.upload(hb)
         dm = self.model.device_model(eng)
-        if hb.num_nodes == 0 or not eng.solve_supported(db, dm) or (which.startswith("rollout") and not 1 <= b <= 64):
+        path = eng.solve_path(db, dm) if hb.num_nodes else 0  # 1 fused kernel, 2 any-size device path (same results)
+        if path == 0 or (which.startswith("rollout") and not 1 <= b <= 64):
             return None
         greedy = eng.GREEDY_ROLLOUT if which.startswith("rollout") else \
             {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL}[which]
@@ -155,7 +157,7 @@ class MWISSolver(object):
         options, scores = (eng.COMPLETE_BY_PRIORITY if by_prio else 0), None
         if not rescore:  # one forward pass on the full graphs; every step re-uses its scores
             options |= eng.SCORES_GIVEN
-            scores = self.model.forward_batch(eng, db, X=self._features(hb), mode=1)
+            scores = self.model.forward_batch(eng, db, X=self._features(hb), mode=1 if eng.solve_supported(db, dm) else 0)
         state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
         res = eng.solve_residual(db, dm, state, predict=self.flags.predict, greedy=greedy, max_rounds=1, beam=b,
                                  weight_features=self.flags.predict != "mwis", options=options, scores=scores)

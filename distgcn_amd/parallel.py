@@ -124,7 +124,7 @@ def solve_sharded_device(engine, model, hb: HostBatch, predict: str = "mwis", gr
     # Every rank decides on the shape of the WHOLE batch (largest graph, densest graph), which they all hold: a decision
     # taken per shard could differ between ranks, and a rank that raised here would leave the others waiting in the
     # collective below.
-    if hb.num_nodes and not engine.solve_supported(engine.upload(_shape_probe(hb)), dm):
+    if hb.num_nodes and engine.solve_path(engine.upload(_shape_probe(hb)), dm) == 0:
         raise _lib.DgcnError("solve_sharded_device: this model / batch shape is outside the fused kernel")
     if sub.num_nodes:
         engine.solve_fused(db, dm, predict=predict, want_scores=False, out=out)

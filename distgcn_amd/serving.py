@@ -99,9 +99,9 @@ class SolvePipeline:
                               base + int(info.off_col_idx))
 
     def supported(self, slot: _Slot, info) -> bool:
-        """Does the fused kernel take this (packed) batch with this model?"""
+        """Does ``dgcn_solve_batch`` (fused kernel or any-size path) take this (packed) batch with this model?"""
         return (int(info.max_degree) < self.table.numel() and
-                bool(self.lib.dgcn_solve_supported(C.byref(self._batch_struct(slot, info)), C.byref(self.model.c))))
+                int(self.lib.dgcn_solve_path(C.byref(self._batch_struct(slot, info)), C.byref(self.model.c))) != 0)
 
     def _launch(self, slot: _Slot, info) -> _Slot:
         """Device stage: one copy in, one fused launch, one copy out, all on the slot's stream; returns at once."""
@@ -113,7 +113,7 @@ class SolvePipeline:
         total = int(info.total_bytes)
         base = slot.dev.data_ptr()
         bc = self._batch_struct(slot, info)
-        if not self.lib.dgcn_solve_supported(C.byref(bc), C.byref(self.model.c)):
+        if not self.lib.dgcn_solve_path(C.byref(bc), C.byref(self.model.c)):
             raise _lib.DgcnError("this model / batch shape is outside the fused kernel: use mwis_dqn_call.solve_host_batch")
         need = int(self.lib.dgcn_solve_workspace(C.byref(bc), C.byref(self.model.c)))
         if slot.ws is None or slot.ws.numel() < need:

@@ -179,8 +179,8 @@ def simulate(adjs: Sequence, traffics: Sequence[Dict[str, np.ndarray]], algo: st
     tot_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
     cnt_out = t.zeros((T, I), dtype=t.float64, device=eng.device)
     dm = agent.model.device_model(eng) if algo != "Greedy" else None
-    if dm is not None and not eng.solve_supported(db, dm):
-        raise NotImplementedError("conflict graphs / model outside the fused kernel (<= 512 vertices, hidden <= 32)")
+    if dm is not None and hb.num_nodes and eng.solve_path(db, dm) == 0:  # (1: fused kernels, 2: the any-size device path)
+        raise NotImplementedError("conflict graphs / model outside the device solvers (graphs beyond 9 600 vertices, max_degree > 1)")
     out = eng.solve_buffers(db, False) if dm is not None else None
     state = t.zeros(max(hb.num_nodes, 1), dtype=t.uint8, device=eng.device)
     zero_w = t.zeros(hb.num_nodes, dtype=t.float64, device=eng.device)

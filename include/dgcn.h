@@ -294,6 +294,17 @@ int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t pr
  * scores (float[num_nodes]), rounds, totals may be NULL.  weights NULL or predict_mwis = 0: the
  * priority is the score itself (mwis_dqn_call.py:234). */
 int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
+/* Graphs beyond that (the multi-channel joint conflict graphs of wireless_dqn_test_mc.py:161 have K * nflows vertices;
+ * ER(500, 0.1) already has more entries than one CU's LDS holds) and layer stacks wider than 32 take the ANY-SIZE path
+ * inside the same two entry points: the residual graph is re-sliced on the device (renumbered, with its own support),
+ * the forward pass runs layer by layer (mode 0's kernels: same bits), the greedy step in kernels of its own - nothing
+ * returns to the host, nothing changes in the results.  dgcn_solve_path: 1 = fused kernels, 2 = any-size path (graphs
+ * up to 9 600 vertices, [I, L] models with one output per vertex), 0 = neither (DGCN_ERR_UNSUPPORTED).
+ * dgcn_set_general(1) sends every shape down the any-size path (tests, A/B runs); -1 = automatic (default; initialised
+ * once from the environment variable DGCN_GENERAL). */
+int dgcn_solve_path(const DgcnBatch* batch, const DgcnModel* model);
+void dgcn_set_general(int32_t setting);
+int32_t dgcn_get_general(void);
 /* The several-workgroups-per-graph launch variant (small batches): -1 = chosen automatically (default), 0 = off,
  * K >= 2 = forced.  Process-wide, atomic; initialised once from the environment variable DGCN_FUSED_CLUSTER.  The
  * library's own recovery from DGCN_FAULT_CLUSTER calls dgcn_set_cluster(0). */
@@ -301,7 +312,8 @@ void dgcn_set_cluster(int32_t setting);
 int32_t dgcn_get_cluster(void);
 /* Bytes of device scratch dgcn_solve_batch / dgcn_solve_residual_batch need for this batch.  Graphs whose
  * whole image fits the LDS need a token amount; larger ones (e.g. 500 vertices, 5 000 edges) keep their
- * entry values in this scratch (one float per entry slot) and only states + gather words in LDS. */
+ * entry values in this scratch (one float per entry slot) and only states + gather words in LDS; the any-size
+ * path keeps the re-sliced batch, its support, the layer-by-layer buffers and up to 64 rollout instances here. */
 size_t dgcn_solve_workspace(const DgcnBatch* batch, const DgcnModel* model);
 int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table, int32_t table_len,
                      const float* X, float x_const, const double* weights, int32_t predict_mwis,
@@ -326,8 +338,8 @@ int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const doubl
  * untouched; otherwise *progress += 1.  The caller repeats the launch until *progress stays 0.
  * options: DGCN_RESIDUAL_* bits (the rollout variants mwis_gdpg_call.py:413-594).
  * rounds[g]: rounds run by this launch; totals[g]: weight (or priority) of the vertices that joined in
- * THIS launch; scores: residual-graph scores (0 for removed vertices).  Same shape limits as
- * dgcn_solve_batch. */
+ * THIS launch; scores: residual-graph scores (0 for removed vertices).  Same shapes as
+ * dgcn_solve_batch (dgcn_solve_path). */
 #define DGCN_RESIDUAL_SCORES_GIVEN 1        /* `scores` is an INPUT (one forward pass on the full graph, done by the
                                               caller): no forward pass here - solve_mwis_rollout00 / rollout0 */
 #define DGCN_RESIDUAL_COMPLETE_BY_PRIORITY 2 /* rollout completions ordered by priority instead of weight

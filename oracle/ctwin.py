@@ -17,8 +17,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "dgcn_oracle.c")
-    if force or not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("dgcn_oracle.c", "f32_orders.c", "Makefile")]
+    if force or not os.path.isfile(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "_build/liboracle.so"], check=True, capture_output=True)
     return _SO
 
@@ -26,8 +26,7 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.isfile(_SO):
-            build()
+        build()  # (re)built when a source is newer than the library
         _lib = C.CDLL(_SO)
     return _lib
 

@@ -918,7 +918,7 @@ def test_native_host_solver(engine, golden):
     """dgcn_host_solver_* (csrc/host_solver.hip) through distgcn_amd.serving.HostSolver: the whole host-to-host call in
     native code.  Same sets / rounds / totals / scores as the twin for ragged batches and for single graphs, two batches
     in flight, a slot must be read before re-use and cannot be read twice, data faults surface at result() and the object
-    recovers, shapes outside the fused kernel are refused, empty graphs are fine."""
+    recovers, shapes outside the fused kernel take the any-size path, empty graphs are fine."""
     from distgcn_amd import datagen
     from distgcn_amd._lib import DgcnError
     from distgcn_amd.engine import DeviceModel
@@ -956,9 +956,10 @@ def test_native_host_solver(engine, golden):
     with pytest.raises(DgcnError, match="NaN"):
         hs.solve(*bad)
     assert np.array_equal(hs.solve(*batches[2])["state"], refs[2]["state"])  # recovers
-    big = datagen.er_batch(1, 600, 0.01, first_index=77)
-    with pytest.raises(DgcnError, match="outside the fused kernel"):
-        hs.solve(*lists(big))
+    big = datagen.er_batch(1, 600, 0.01, first_index=77)  # beyond the fused kernel: dgcn_solve_batch's any-size path, same calls
+    gb, rb = hs.solve(*lists(big)), ctwin.solve(big, layers)
+    assert np.array_equal(gb["state"], rb["state"]) and np.array_equal(gb["rounds"], rb["rounds"])
+    assert np.array_equal(gb["scores"].view(np.uint32), np.asarray(rb["scores"], np.float32).ravel().view(np.uint32))
     empty = (np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
     g = hs.solve([empty[0], batches[3][0][0]], [empty[1], batches[3][1][0]], [empty[2], batches[3][2][0]])
     assert g["state"].size == 1 and g["totals"].size == 2 and g["totals"][0] == 0.0 and g["rounds"][0] == 0

@@ -1,0 +1,350 @@
+"""GPU: the any-size device path (csrc/general.hip) - what dgcn_solve_batch / dgcn_solve_residual_batch run for conflict
+graphs beyond the fused kernel's 512 vertices / one CU's LDS (the multi-channel joint graphs of
+wireless_dqn_test_mc.py:161, 244-289 have K * nflows vertices) and for layer stacks wider than 32.
+
+Three kinds of checks: (1) forced onto shapes the fused kernel takes too (dgcn_set_general(1)), every step must equal
+the fused kernel's bit for bit; (2) at N = 600 / 900 / 1 500 and on ER(500, 0.1) against the twin and the oracle's
+solvers (oracle/ref_numpy.py, pinned by the executed reference) fed with the twin's scores; (3) the slot loop on a
+K = 3 x 300-flow joint graph with all five schedulers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _flags(**kw):
+    from distgcn_amd.runtime_config import FLAGS
+    base = dict(feature_size=1, hidden1=32, num_layer=20, diver_num=1, max_degree=1, predict="mwis")
+    base.update(kw)
+    return FLAGS.copy(**base)
+
+
+def _twin_scores_fn(layers):
+    from distgcn_amd.batch import HostBatch
+    from oracle import ctwin
+    import scipy.sparse as sp
+
+    def fn(adj_nn, wts_nn):
+        a = sp.csr_matrix(adj_nn)
+        a.sort_indices()
+        hb = HostBatch.from_csr_lists([a.indptr.astype(np.int64)], [a.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        return ctwin.forward(lap, layers, hb.num_nodes)
+    return fn
+
+
+@pytest.fixture
+def general_switch():
+    """dgcn_set_general for the duration of a test: 1 = every shape down the any-size path, None = automatic."""
+    from distgcn_amd import _lib
+    lib = _lib.load()
+    initial = int(lib.dgcn_get_general())
+
+    def set_to(value):
+        lib.dgcn_set_general(-1 if value is None else int(value))
+    yield set_to
+    lib.dgcn_set_general(initial)
+
+
+def _scipy(hb, g):
+    m = hb.scipy_graph(g).tocsr()
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("shape", [(3, 32, False), (1, 32, False), (4, 16, True), (2, 48, False), (20, 32, False), (3, 64, True)])
+def test_plain_solve_equals_fused_and_twin(engine, golden, general_switch, shape):
+    """dgcn_solve_batch down the any-size path on fixture graphs: scores, sets, rounds, totals bit-equal to the fused
+    kernel's (where it takes the model) and to the twin's."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    num_layer, hidden, bias = shape
+    layers = datagen.random_model(num_layer, hidden, bias=bias, seed=11 + num_layer)
+    hb = golden.host_batch([0, 3, 9, 12, 5, 1])
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    ref = ctwin.solve(hb, layers)
+    general_switch(None)
+    fused = None
+    if engine.solve_path(db, dm) == 1:
+        r = engine.solve_fused(db, dm)
+        engine.check_status(r["status"])
+        fused = {k: r[k].cpu().numpy() for k in ("state", "scores", "rounds", "totals")}
+    general_switch(1)
+    assert engine.solve_path(db, dm) == 2
+    r = engine.solve_fused(db, dm)
+    engine.check_status(r["status"])
+    got = {k: r[k].cpu().numpy() for k in ("state", "scores", "rounds", "totals")}
+    assert np.array_equal(got["scores"].ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(got["state"], ref["state"])
+    assert np.array_equal(got["rounds"], ref["rounds"])
+    assert np.allclose(got["totals"], ref["totals"], rtol=1e-12)
+    if fused is not None:
+        assert np.array_equal(got["scores"].ravel().view(np.uint32), fused["scores"].ravel().view(np.uint32))
+        assert np.array_equal(got["state"], fused["state"]) and np.array_equal(got["rounds"], fused["rounds"])
+        assert np.allclose(got["totals"], fused["totals"], rtol=1e-12)
+
+
+STEPPERS = {  # which -> (greedy mode name, max_rounds, options: scores given / completions by priority, predict)
+    "dit": ("GREEDY_ROUNDS", 1, (False, False), "mwis"),
+    "lgs_all": ("GREEDY_ROUNDS", 0, (False, False), "mwis"),
+    "cit": ("GREEDY_CENTRAL", 1, (False, False), "mwis"),
+    "rollout": ("GREEDY_ROLLOUT", 1, (False, False), "mwis"),
+    "rollout00": ("GREEDY_ROLLOUT", 1, (True, False), "mwis"),
+    "rollout0": ("GREEDY_ROLLOUT", 1, (True, True), "mwis"),
+    "rollout1": ("GREEDY_ROLLOUT", 1, (False, True), "mwis"),
+    "dit_mis": ("GREEDY_ROUNDS", 1, (False, False), "mis"),
+    "rollout_mis": ("GREEDY_ROLLOUT", 1, (False, False), "mis"),
+}
+
+
+@pytest.mark.parametrize("which", sorted(STEPPERS))
+def test_residual_steps_equal_the_fused_kernel(engine, golden, general_switch, which):
+    """One call of dgcn_solve_residual_batch = one solver step of the whole batch.  Step by step, from a start with
+    decided vertices, a graph with nothing left and a graph without positive weight, the any-size path must leave the
+    same state bytes, scores (bits), rounds and totals as the fused residual-graph kernel, and stop after as many steps."""
+    import torch
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    mode_name, max_rounds, (given, by_prio), predict = STEPPERS[which]
+    agent = DQNAgent(_flags(num_layer=3, predict=predict), seed=9)
+    rng = np.random.default_rng(5)
+    for k in agent.model.vars:  # non-zero biases
+        if k.endswith("/bias"):
+            agent.model.vars[k] = rng.uniform(-0.2, 0.2, agent.model.vars[k].shape).astype(np.float32)
+    agent.model._device_model = None
+    hb = golden.host_batch([2, 7, 1, 0, 12, 8])
+    sl = hb.graph_slices()
+    hb.weights[sl[4][0]:sl[4][1]] = 0.0            # a graph without positive weight: left alone
+    hb.weights[sl[2][0]:sl[2][0] + 5] = 0.0        # some zero weights inside a live graph
+    db = engine.upload(hb)
+    dm = agent.model.device_model(engine)
+    init = np.where(rng.random(hb.num_nodes) < 0.2, rng.integers(1, 3, hb.num_nodes), 0).astype(np.uint8)
+    init[sl[3][0]:sl[3][1]] = 2                    # a graph with nothing left
+    greedy = getattr(engine, mode_name)
+    options = (engine.SCORES_GIVEN if given else 0) | (engine.COMPLETE_BY_PRIORITY if by_prio else 0)
+    full_scores = None
+    if given:
+        general_switch(None)
+        full_scores = agent.model.forward_batch(engine, db, X=agent._features(hb), mode=1).clone()
+    states, outs = {}, {}
+    for path in (None, 1):
+        general_switch(path)
+        assert engine.solve_path(db, dm) == (1 if path is None else 2)
+        states[path] = torch.from_numpy(init.copy()).to(engine.device)
+        outs[path] = engine.solve_buffers(db, True)
+    steps = 0
+    while True:
+        snap = {}
+        for path in (None, 1):
+            general_switch(path)
+            res = engine.solve_residual(db, dm, states[path], predict=predict, greedy=greedy, max_rounds=max_rounds, beam=6,
+                                        weight_features=predict != "mwis", want_scores=True, max_steps=1, out=outs[path],
+                                        options=options, scores=None if full_scores is None else full_scores.clone())
+            engine.check_status(res["status"])
+            snap[path] = (states[path].cpu().numpy().copy(), outs[path]["rounds"].cpu().numpy().copy(),
+                          outs[path]["totals"].cpu().numpy().copy(),
+                          None if given else outs[path]["scores"].cpu().numpy().ravel().copy())
+        a, b = snap[None], snap[1]
+        assert np.array_equal(a[0], b[0]), (which, steps)
+        assert np.array_equal(a[1], b[1]), (which, steps, a[1], b[1])
+        assert np.allclose(a[2], b[2], rtol=1e-12, atol=0), (which, steps)
+        if not given:
+            assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), (which, steps)
+        steps += 1
+        if not a[1].any():  # no graph ran a round: the search is over
+            break
+        assert steps < 400
+    assert steps > 1
+    st = snap[1][0]
+    assert np.array_equal(st[sl[4][0]:sl[4][1]], init[sl[4][0]:sl[4][1]])  # the weightless graph was left alone
+    for path in (None, 1):  # and the host loop (progress words) stops after the same number of steps on both paths
+        general_switch(path)
+        s0 = torch.from_numpy(init.copy()).to(engine.device)
+        res = engine.solve_residual(db, dm, s0, predict=predict, greedy=greedy, max_rounds=max_rounds, beam=6,
+                                    weight_features=predict != "mwis", options=options,
+                                    scores=None if full_scores is None else full_scores.clone())
+        assert res["steps"] == steps - 1 and np.array_equal(s0.cpu().numpy(), st), (which, path, res["steps"], steps)
+
+
+BIG = [(600, 0.01), (500, 0.1), (900, 0.02), (1500, 0.004)]
+
+
+@pytest.mark.parametrize("n,p", BIG)
+def test_big_graphs_plain_solve_vs_twin(engine, n, p):
+    """Graphs the fused kernel cannot hold: ER(500, 0.1) (25 000 entries), 600, 900 and 1 500 vertices - one call of
+    dgcn_solve_batch, scores / sets / rounds equal to the twin bit for bit, through the agent API and the host solver."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.mwis_dqn_call import DQNAgent, solve_csr_lists
+    from oracle import ctwin
+    hb = datagen.er_batch(3, n, p, first_index=40)
+    agent = DQNAgent(1, flags=_flags(num_layer=4))
+    dm = DeviceModel(agent.model.layers, engine.device)
+    db = engine.upload(hb)
+    assert not engine.solve_supported(db, dm) and engine.solve_path(db, dm) == 2
+    ref = ctwin.solve(hb, agent.model.layers)
+    r = engine.solve_fused(db, dm)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(r["rounds"].cpu().numpy(), ref["rounds"])
+    assert np.allclose(r["totals"].cpu().numpy(), ref["totals"], rtol=1e-12)
+    # the reference's call pattern: per-graph CSR arrays in, sets out (HostSolver -> dgcn_solve_batch)
+    ps = [hb.row_ptr[hb.graph_ptr[g]:hb.graph_ptr[g + 1] + 1].astype(np.int64) - int(hb.row_ptr[hb.graph_ptr[g]]) for g in range(3)]
+    cs = [hb.col_idx[hb.row_ptr[hb.graph_ptr[g]]:hb.row_ptr[hb.graph_ptr[g + 1]]].astype(np.int64) - int(hb.graph_ptr[g]) for g in range(3)]
+    ws = [hb.weights[hb.graph_ptr[g]:hb.graph_ptr[g + 1]] for g in range(3)]
+    res, gp = solve_csr_lists(engine, agent.model, ps, cs, ws, "mwis", "auto")
+    assert np.array_equal(res["state"], ref["state"])
+    assert np.array_equal(np.asarray(res["scores"]).ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+
+
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout", "rollout1"])
+def test_big_graph_iterative_solvers_vs_oracle(engine, which):
+    """solve_mwis_dit / _cit / _rollout on a 600-vertex graph and on ER(500, 0.1): entirely on the device (the any-size
+    path), decisions equal to the oracle's solvers fed with the twin's scores."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(_flags(num_layer=3), seed=21)
+    fn = _twin_scores_fn(agent.model.layers)
+    cases = [(600, 0.01, 3)] + ([(500, 0.1, 4)] if which != "cit" else [])
+    for n, p, seed in cases:
+        rng = np.random.default_rng(20230800 + seed)
+        indptr, indices = datagen.er_graph(n, p, rng)
+        adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+        w = rng.random(n)
+        got = agent.solve_iterative_batch([adj], [w], which, b=4)
+        assert got is not None  # ran through dgcn_solve_residual_batch
+        if which == "dit":
+            want = orc.solve_mwis_dit(fn, adj, w)
+        elif which == "cit":
+            want = orc.solve_mwis_cit(fn, adj, w)
+        else:
+            want = orc.solve_mwis_rollout(fn, adj, w, b=4, by_priority=which == "rollout1")
+        assert got[0][0] == want[0], (which, n)
+        assert np.allclose(got[0][1], want[1], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,p", [(900, 0.01), (1500, 0.004)])
+def test_big_graph_iterative_solvers_vs_host_reslicing(engine, n, p):
+    """N = 900 and 1 500, three graphs advanced together: the device-resident solvers against the reference's own
+    control flow (SciPy re-slicing per step on the host, mwis_gdpg_call.py:278-318, 343-384, 596-659, with every forward
+    pass and completion on the device) - same sets, same totals."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=3), seed=2)
+    adjs, wts = [], []
+    for g in range(3):
+        rng = np.random.default_rng(20230900 + g)
+        indptr, indices = datagen.er_graph(n - 7 * g, p, rng)  # ragged
+        adjs.append(sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n - 7 * g,) * 2))
+        wts.append(rng.random(n - 7 * g))
+    for which, host in (("dit", "solve_mwis_dit"), ("cit", "solve_mwis_cit"), ("rollout", "solve_mwis_rollout")):
+        agent.device_iterative = True
+        got = agent.solve_iterative_batch(adjs, wts, which, b=3)
+        assert got is not None and len(got) == 3
+        agent.device_iterative = False
+        for g in ((0, 2) if which == "dit" else (1,)):
+            want = getattr(agent, host)(adjs[g], wts[g], b=3) if which == "rollout" else getattr(agent, host)(adjs[g], wts[g])
+            assert got[g][0] == want[0], (which, g)
+            assert np.allclose(got[g][1], want[1], rtol=1e-12)
+        for (sel, _), adj in zip(got, adjs):  # independent and maximal
+            m = np.zeros(adj.shape[0], bool); m[list(sel)] = True
+            assert not (adj[m][:, m]).nnz and np.all((adj @ m.astype(np.float64) > 0) | m)
+
+
+@pytest.mark.parametrize("algo", ["Greedy", "DGCN-LGS", "DGCN-LGS-it", "CGCN-CGS", "DGCN-RS"])
+def test_wireless_joint_multichannel_graph_900(engine, algo):
+    """The multi-channel experiment's shape (bash/twc_major_wireless_mc_test.sh: num_channels = 3): 300 flows, the joint
+    conflict graph on 3 x 300 vertices built by wireless.multichannel_conflict_graph (wireless_rollout_test_flood.py:98-133),
+    two instances in lockstep, every scheduler of wireless_dqn_test_mc.py:236-289 - against the per-instance restatement of
+    the slot loop with the oracle's solvers (DGCN-RS: the agent's host re-slicing control flow) as schedulers."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen, wireless
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.mwis_dqn_call import DQNAgent as DqnAgent
+    from distgcn_amd.mwis_gdpg_call import DQNAgent as GdpgAgent
+    from oracle import ctwin, ref_numpy as orc, ref_wireless
+    nflows, K, T = 300, 3, 4
+    adjs, traffics = [], []
+    for i in range(2):
+        rng = np.random.default_rng(500 + i)
+        indptr, indices = datagen.er_graph(nflows, 0.02, rng)
+        base = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(nflows, nflows))
+        chans = wireless.multichannel_conflict_simulate(base, k=K, p=0.8, rng=np.random.RandomState(7 + i))
+        _, joint = wireless.multichannel_conflict_graph(chans)
+        assert joint.shape == (K * nflows, K * nflows)
+        adjs.append(joint)
+        traffics.append(wireless.make_traffic(nflows, T, 0.05, n_ch=K, seed=30 + i))
+    if algo in ("Greedy", "DGCN-LGS"):
+        agent = DqnAgent(1, flags=_flags(num_layer=3))
+    else:
+        agent = GdpgAgent(_flags(num_layer=3), seed=4)
+    layers = agent.model.layers
+    fn = _twin_scores_fn(layers)
+
+    def greedy_fn(adj, w):
+        st, _ = orc.lgs_vectorised(adj.indptr, adj.indices, w)
+        return set(np.flatnonzero(st == 1).tolist())
+
+    def dgcn_fn(adj, w):  # mwis_dqn_call.py:198-241: prune zero weights, GCN, priority, local greedy, map back
+        keep = np.flatnonzero(w > 0)
+        if keep.size == 0:
+            return set()
+        sub = sp.csr_matrix(adj[keep][:, keep])
+        sub.sort_indices()
+        hb = HostBatch.from_csr_lists([sub.indptr.astype(np.int64)], [sub.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        prio = ctwin.forward(lap, layers, hb.num_nodes)[:, 0].astype(np.float64) * w[keep]
+        st, _ = orc.lgs_vectorised(sub.indptr, sub.indices, prio)
+        return set(keep[np.flatnonzero(st == 1)].tolist())
+
+    def rs_fn(adj, w):
+        if not w.size:
+            return set()
+        agent.device_iterative = False
+        try:
+            return agent.solve_mwis_rollout_wrap(adj, w, b=16)[0]
+        finally:
+            agent.device_iterative = True
+
+    solver = {"Greedy": greedy_fn, "DGCN-LGS": dgcn_fn,
+              "DGCN-LGS-it": lambda a, w: orc.solve_mwis_dit(fn, a, w)[0] if w.size else set(),
+              "CGCN-CGS": lambda a, w: orc.solve_mwis_cgs_train(fn, a, w)[0] if w.size else set(),
+              "DGCN-RS": rs_fn}[algo]
+    got = wireless.simulate(adjs, traffics, algo=algo, agent=agent, wt_sel="qr")
+    for i in range(len(adjs)):
+        want = ref_wireless.simulate_one(adjs[i], traffics[i]["arrival_pkts"], traffics[i]["link_rates"], solver, "qr")
+        assert np.array_equal(got[i]["queue"], want["queue"]), (algo, i)
+        assert np.array_equal(got[i]["depart"], want["depart"]), (algo, i)
+        assert np.allclose(got[i]["total_wt"], want["total_wt"], rtol=1e-12)
+        assert got[i]["depart"].sum() > 0
+
+
+def test_wide_deep_model_runs_on_the_device(engine, golden):
+    """A deep stack with hidden width 64 (outside k_fused's 32): dgcn_solve_batch and the residual solvers take the
+    any-size path instead of returning to the host; same bits as the twin / the oracle."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ctwin, ref_numpy as orc
+    layers = datagen.random_model(5, 64, seed=3)
+    hb = golden.host_batch([2, 7, 1])
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    assert engine.solve_path(db, dm) == 2
+    ref = ctwin.solve(hb, layers)
+    r = engine.solve_fused(db, dm)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), ref["state"])
+    agent = DQNAgent(_flags(num_layer=4, hidden1=48), seed=3)
+    fn = _twin_scores_fn(agent.model.layers)
+    adj, w = golden.scipy(2), golden.csr(2)[2]
+    got = agent.solve_iterative_batch([adj], [w], "cit")
+    assert got is not None
+    want = orc.solve_mwis_cit(fn, adj, w)
+    assert got[0][0] == want[0]
