@@ -35,6 +35,12 @@ int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, 
                       int64_t* stats, int32_t* overhead, const double* sum_weights, double* totals, int32_t* status, void* stream,
                       const int32_t* active);  // lgs.hip
 
+// big.hip: the hidden stack of a deep c32 model in one launch (graphs up to 976 vertices); same bits as layered_forward
+int big_takes(const DgcnBatch* b, const DgcnModel* m);
+size_t big_workspace(const DgcnBatch* b, const DgcnModel* m);
+int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const, float* scores,
+                void* lws, void* bws, int32_t* status, hipStream_t s);
+
 constexpr int kResBlock = 256;
 constexpr int kMaxBeam = 64;
 
@@ -491,7 +497,7 @@ size_t general_workspace(const DgcnBatch* b, const DgcnModel* m) {
     need += al256(n * (size_t)model_in_dim(m) * 4);                      // features of the compact batch
     need += al256(n * 4) + al256(n * 4);                                 // compact scores, full scores when the caller wants none
     need += al256(n * 8);                                                // priorities
-    need += al256(layered_bytes(b, m));
+    need += al256(layered_bytes(b, m)) + al256(big_workspace(b, m));
     need += al256(B * kMaxBeam * 4) + 2 * al256((size_t)kMaxBeam * n) + al256((size_t)kMaxBeam * B * 4) + al256((size_t)kMaxBeam * B * 8);
     return need;
 }
@@ -525,13 +531,15 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     float* sc = scores ? scores : w.take<float>(n);
     const size_t fbytes = layered_bytes(b, m);
     char* fws = w.take<char>(fbytes);
+    const bool big = big_takes(b, m) != 0;
+    char* bws = big ? w.take<char>(big_workspace(b, m)) : nullptr;
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
     int rc = dgcn_supports_batch(b, dinv_table, table_len, lrow, lcol, lval, status, s);
     if (rc) return rc;
     DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, lrow, lcol, lval};
     const DgcnCsr* sup[1] = {&L};
-    if ((rc = layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
+    if ((rc = big ? big_forward(b, &L, m, X, x_const, sc, fws, bws, status, s) : layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
     return lgs_launch_common(b, nullptr, 0, sc, (predict_mwis && weights) ? weights : nullptr, nullptr, 1, 0, state, rounds, nullptr,
                              nullptr, weights, totals, status, s, nullptr);
 }
@@ -566,6 +574,8 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     a.prio = w.take<double>(n);
     const size_t fbytes = layered_bytes(b, m);
     char* fws = w.take<char>(fbytes);
+    const bool big = big_takes(b, m) != 0;
+    char* bws = big ? w.take<char>(big_workspace(b, m)) : nullptr;
     a.cid = w.take<int32_t>(B * kMaxBeam);
     uint8_t* inst_state = nullptr;
     int32_t* inst_rounds = nullptr;
@@ -605,7 +615,8 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         cb.col_idx = nullptr;
         DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, a.lrow, a.lcol, a.lval};
         const DgcnCsr* sup[1] = {&L};
-        if (int rc = layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s)) return rc;
+        if (int rc = big ? big_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s) : layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s))
+            return rc;
     }
     {
         TimedLaunch t("general_prepare", s);

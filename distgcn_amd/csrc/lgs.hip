@@ -65,10 +65,10 @@ __device__ __forceinline__ void nbr_test(int u, int v, double pv, const uint8_t*
     }
 }
 
-template <int LPV, bool STATS, bool COLS_LDS>
+template <int LPV, bool STATS, bool COLS_LDS, int BLOCK>
 __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int ng, int e0, double* pr, uint8_t* st,
                                            uint8_t* nw, const uint16_t* cl, unsigned long long* acc64, const int* ro) {
-    constexpr int kVerts = 256 / LPV;
+    constexpr int kVerts = BLOCK / LPV;
     const int lane = threadIdx.x & 63;
     const int slot = threadIdx.x / LPV, sub = threadIdx.x % LPV;
     const int gshift = lane & ~(LPV - 1);
@@ -81,7 +81,7 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
         if (threadIdx.x == 0) acc64[2] = 0;
         __syncthreads();
         int c = 0;
-        for (int v = threadIdx.x; v < ng; v += 256) c += st[v] == 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) c += st[v] == 0;
         if (c) atomicAdd(&acc64[2], (unsigned long long)c);
         __syncthreads();
         remaining = (int)acc64[2];
@@ -142,7 +142,7 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
         }
         __syncthreads();
         int mine = 0;
-        for (int v = threadIdx.x; v < ng; v += 256) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             if (st[v] == 0) {
                 if (nw[v]) st[v] = 1; else ++mine;
             }
@@ -167,7 +167,7 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
         __syncthreads();
         if (p2p) atomicAdd(&acc64[0], p2p);
         int members = 0;
-        for (int v = threadIdx.x; v < ng; v += 256) members += st[v] == 1;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) members += st[v] == 1;
         if (members) atomicAdd(&acc64[1], (unsigned long long)members);
         __syncthreads();
         if (threadIdx.x == 0 && a.stats) {
@@ -177,8 +177,8 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
     }
 }
 
-template <int LPV, bool STATS>
-__global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
+template <int LPV, bool STATS, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void k_lgs(LgsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int inst = blockIdx.x / a.num_graphs;
     const int g = blockIdx.x - inst * a.num_graphs;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | i32 row offsets | u8 st | u8 nw | u16 cols]
     double* pr = reinterpret_cast<double*>(lds_raw);
     double* red = pr + a.max_nodes;
-    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 256);
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 1024);
     int* rol = reinterpret_cast<int*>(acc64 + 4);
     uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
     uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
         return;
     }
     int bad = 0;
-    for (int v = threadIdx.x; v < ng; v += 256) {
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
         double p;
         if (a.prio) p = a.prio[n0 + v];
         else if (a.weights) p = (double)a.scores[n0 + v] * a.weights[n0 + v];
@@ -225,15 +225,15 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     }
     const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
     const bool cols_lds = (e1 - e0) <= a.cols_cap && ng <= 65536;
-    for (int v = threadIdx.x; v <= ng; v += 256) rol[v] = a.row_ptr[n0 + v];  // row bounds: read once, not per round
+    for (int v = threadIdx.x; v <= ng; v += BLOCK) rol[v] = a.row_ptr[n0 + v];  // row bounds: read once, not per round
     if (cols_lds) {
-        for (int base = e0 + threadIdx.x; base < e1; base += 256 * 4) {  // 4 loads in flight per thread
+        for (int base = e0 + threadIdx.x; base < e1; base += BLOCK * 4) {  // 4 loads in flight per thread
             int c[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) c[i] = (base + i * 256 < e1) ? a.col_idx[base + i * 256] : 0;
+            for (int i = 0; i < 4; ++i) c[i] = (base + i * BLOCK < e1) ? a.col_idx[base + i * BLOCK] : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (base + i * 256 < e1) cl[base + i * 256 - e0] = (uint16_t)(c[i] - n0);
+                if (base + i * BLOCK < e1) cl[base + i * BLOCK - e0] = (uint16_t)(c[i] - n0);
         }
     }
     if (__syncthreads_or(bad)) {
@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
             if (a.stats) { a.stats[2 * g] = 0; a.stats[2 * g + 1] = 0; }
             if (a.totals) a.totals[g] = 0.0;
         }
-        for (int v = threadIdx.x; v < ng; v += 256) a.state[n0 + v] = a.init_state ? a.init_state[n0 + v] : (uint8_t)0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = a.init_state ? a.init_state[n0 + v] : (uint8_t)0;
         return;
     }
-    if (cols_lds) lgs_rounds<LPV, STATS, true>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
-    else lgs_rounds<LPV, STATS, false>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+    if (cols_lds) lgs_rounds<LPV, STATS, true, BLOCK>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+    else lgs_rounds<LPV, STATS, false, BLOCK>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
 
     {
         // totals: fixed-shape reduction - strided partials, then a binary tree over the 256 slots.  A vertex that was given
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
         // the total is what joined in THIS search.  (init_state may alias state: read before the write, same thread.)
         const double* sw = a.sum_weights;
         double part = 0.0;
-        for (int v = threadIdx.x; v < ng; v += 256) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const uint8_t s1 = st[v];
             if (a.totals && s1 == 1 && !(a.init_state && a.init_state[n0 + v] == 1)) part += sw ? sw[n0 + v] : pr[v];
             a.state[n0 + v] = s1;
@@ -265,6 +265,16 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
     }
     if (a.totals) {
         __syncthreads();
+        // (the partial of thread i covers vertices i, i + BLOCK, ..; folded to 256 slots - slot j = partials j, j + 256, .. added
+        // in order - and then the same tree: a fixed shape per block size, float64 sums equal to 1e-16 relative either way)
+        if (BLOCK > 256) {
+            if (threadIdx.x < 256) {
+                double acc = red[threadIdx.x];
+                for (int k2 = 256; k2 < BLOCK; k2 += 256) acc += red[threadIdx.x + k2];
+                red[threadIdx.x] = acc;
+            }
+            __syncthreads();
+        }
         for (int off = 128; off > 0; off >>= 1) {
             if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
             __syncthreads();
@@ -276,18 +286,18 @@ __global__ __launch_bounds__(256) void k_lgs(LgsArgs a) {
 static size_t lgs_lds_bytes(int max_nodes, int cols_cap) {
     const size_t pad = (size_t)((max_nodes + 15) & ~15);
     const size_t ro = (size_t)((max_nodes + 1 + 3) & ~3) * 4;
-    return (size_t)max_nodes * 8 + 256 * 8 + 4 * 8 + ro + 2 * pad + (size_t)cols_cap * 2;
+    return (size_t)max_nodes * 8 + 1024 * 8 + 4 * 8 + ro + 2 * pad + (size_t)cols_cap * 2;
 }
 
-template <int LPV, bool STATS>
+template <int LPV, bool STATS, int BLOCK = 256>
 static int launch_lgs(const LgsArgs& a, int B, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lgs<LPV, STATS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lgs<LPV, STATS, BLOCK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_lgs: cannot reserve %zu bytes of LDS", lds);
     }
     TimedLaunch t("lgs", s);
-    DGCN_LAUNCH(t, (k_lgs<LPV, STATS>), dim3(B), dim3(256), lds, s, a);
+    DGCN_LAUNCH(t, (k_lgs<LPV, STATS, BLOCK>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_lgs");
 }
 
@@ -412,6 +422,17 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     const char* lpv_s = getenv("DGCN_LGS_LPV");  // tuning / test knob
     const int lpv_env = lpv_s ? atoi(lpv_s) : 0;
     int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 512 ? 4 : 1);  // measured: 4 lanes per vertex wins at N ~ 200
+    // graphs beyond the fused kernel's sizes (the any-size path, general.hip): 1 024 threads per graph - a vertex's lanes in
+    // every pass instead of a quarter of the graph per pass (ER(500, 0.1), 256 graphs: 118 us with 256 threads; the search is a chain
+    // of LDS round trips, more waves hide more of them).  Same decisions, same totals (the reduction tree is fixed).
+    const char* blk_s = getenv("DGCN_LGS_BLOCK");
+    const bool wide = blk_s ? atoi(blk_s) == 1024 : (b->max_nodes > 384 && !want_stats);
+    if (wide && lpv_env <= 0) lpv = b->max_nodes <= 256 ? 4 : (b->max_nodes <= 512 ? 2 : 1);
+    if (wide) {
+        if (lpv == 1) return launch_lgs<1, false, 1024>(a, b->num_graphs * num_instances, lds, s);
+        if (lpv == 2) return launch_lgs<2, false, 1024>(a, b->num_graphs * num_instances, lds, s);
+        if (lpv == 4) return launch_lgs<4, false, 1024>(a, b->num_graphs * num_instances, lds, s);
+    }
 #define DGCN_LGS_CASE(L)                                                      \
     if (lpv == L) return want_stats ? launch_lgs<L, true>(a, b->num_graphs * num_instances, lds, s) \
                                     : launch_lgs<L, false>(a, b->num_graphs * num_instances, lds, s)

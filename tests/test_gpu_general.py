@@ -107,7 +107,7 @@ def test_residual_steps_equal_the_fused_kernel(engine, golden, general_switch, w
     import torch
     from distgcn_amd.mwis_gdpg_call import DQNAgent
     mode_name, max_rounds, (given, by_prio), predict = STEPPERS[which]
-    agent = DQNAgent(_flags(num_layer=3, predict=predict), seed=9)
+    agent = DQNAgent(_flags(num_layer=5, predict=predict), seed=9)  # (three hidden aggregations: the one-launch stack of big.hip)
     rng = np.random.default_rng(5)
     for k in agent.model.vars:  # non-zero biases
         if k.endswith("/bias"):
