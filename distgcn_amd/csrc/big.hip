@@ -18,8 +18,10 @@
 //   one 1 024-thread workgroup per graph; a wave owns the tiles t = wave, wave + 16, ... (rows in descending entry-count
 //   order, so the 16 rows a wave walks in lockstep have similar lengths), two barriers per layer.
 //
-// The first layer (F -> 32, chains in double), the second layer's transform (double) and the last layer (32 -> 1) are the
-// layer-by-layer kernels' (forward.hip): this kernel takes Z of layer index 1 and returns the last hidden activations.
+// The first layer on constant input features (the reference's row-normalised ones, gcn/utils.py:98-106) and the second
+// layer's transform - the two chains the contract carries in double - run inside the launch too (values-only walk, f64 MFMA),
+// and so does the last layer (32 -> 1: two fmaf chains round the row's four lanes, then a width-1 walk over the records).
+// With explicit features the caller runs layer 0 and the transform of layer 1 with the layer-by-layer kernels first.
 // Arithmetic as everywhere (include/dgcn.h): transform = k-ordered fmaf chain (v_mfma_f32_16x16x4_f32), aggregation = fmaf
 // chain over the row's entries in storage order from 0, then Z0 + sum, + bias, activation: bit-identical to mode 0.
 //
@@ -41,6 +43,7 @@ constexpr int kBigMaxLayers = 64;
 constexpr int kBH = 32;
 
 using bf32x4 = __attribute__((ext_vector_type(4))) float;
+using bf64x4 = __attribute__((ext_vector_type(4))) double;
 
 struct BigLayer {
     const float* bias;   // of the aggregation this entry stands for, or null
@@ -48,13 +51,26 @@ struct BigLayer {
     int32_t act, pad;
 };
 
+struct BigFront {          // layer index 0 on constant features + the transform of layer index 1 (both with chains in double)
+    const float* W0;       // [cin][64]
+    const float* bias0;
+    const float* W1;       // [32][64]
+    float x_const;
+    int32_t cin, act0, pad;
+};
+
 struct BigArgs {
     const int32_t* graph_ptr;
     const int32_t* lrow;   // support L: row pointers, diagonal first
     const int32_t* lcol;   // global column ids
     const float* lval;
-    const float* Zin;      // [num_nodes][64] Z0 | Z1 of the first aggregation
-    float* Hout;           // [num_nodes][32] last hidden activations (row-major)
+    const float* Zin;      // front == 0: [num_nodes][64] Z0 | Z1 of layer index 1 (explicit input features: the caller ran
+                           // layer 0 and the transform of layer 1 with the layer-by-layer kernels)
+    BigFront first;        // front == 1
+    const float* Wlast;    // [32][2] the last layer's weights (w0 | w1)
+    const float* bias_last;
+    float* scores;         // [num_nodes]
+    int32_t front, act_last;
     uint2* rec;            // [num_graphs][rec_cap]
     int32_t* status;
     int32_t rec_cap, max_nodes, num_hidden;
@@ -84,9 +100,12 @@ __device__ __forceinline__ void big_load_group(BigRec4& G, const char* p) {
     G.r3 = *reinterpret_cast<const uint2*>(p + 1536);
 }
 
-__device__ __forceinline__ void big_load_bfrag(const float* W, float (&b)[8][4]) {
+// `f64map`: fragments for the f64 MFMA, which returns rows 4 * reg + (lane >> 4) where the f32 one returns 4 * (lane >> 4) + reg:
+// lane r feeds column 4 * (r & 3) + (r >> 2) of the tile and the accumulator again holds four CONSECUTIVE features per lane
+__device__ __forceinline__ void big_load_bfrag(const float* W, float (&b)[8][4], bool f64map) {
     const int lane = threadIdx.x & 63;
-    const int r = lane & 15, kq = lane >> 4;
+    const int r0 = lane & 15, kq = lane >> 4;
+    const int r = f64map ? 4 * (r0 & 3) + (r0 >> 2) : r0;
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         cnt[v] = (unsigned short)min(c, 65535u);
         atomicAdd(&hist[min((int)c, 575)], 1);
     }
-    for (int idx = threadIdx.x; idx < ng * 8; idx += kBigBlock) {
+    for (int idx = threadIdx.x; idx < (a.front ? 0 : ng * 8); idx += kBigBlock) {
         const int v = idx >> 3, c = idx & 7;
         const float4 z = *reinterpret_cast<const float4*>(a.Zin + (size_t)(n0 + v) * 64 + kBH + 4 * c);
         *reinterpret_cast<float4*>(bufB + v * kBH + ((c ^ big_key(v)) << 2)) = z;
@@ -194,105 +213,231 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     float* stg = reinterpret_cast<float*>(big_lds + a.lds_stage_off) + wave * 512;  // [16 rows][32], 16-byte chunks XOR-swizzled by row & 7
     float bfrag[8][4];
     float pz[kBigTilesPerWave][8];
-    // Z0 of the first aggregation: from the caller's Z (row-major, Z0 | Z1), in the aggregation's layout
+    const unsigned voff = (unsigned)lane * 8u;
+    BigRec4 A = {};
+#define DGCN_BQB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, true)
+#define DGCN_BQBF(x, e) __int_as_float(DGCN_BQB(__float_as_int(x), e))
+    // the tile of slot k of this wave: t, its trips and records, the wave's next tile's records
+#define DGCN_BTILE_HEAD                                                                                                  \
+        const int t = wave + kBigWaves * k;                                                                            \
+        const int tn = t + kBigWaves;                                                                                  \
+        const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);                                                   \
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);                                 \
+        const bool have_next = k + 1 < kBigTilesPerWave && tn < tiles;                                                 \
+        const unsigned base_n = have_next ? (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[tn]) : 0u;            \
+        const int slot = t * 16 + s16;                                                                                 \
+        const bool has = slot < ng;                                                                                    \
+        const char* bp = reinterpret_cast<const char*>(rec + base) + voff;                                             \
+        (void)has;
+    // walks the tile's records; every trip needs a record from global memory (L2 / MALL: 500 .. 2 000 cycles), so they are
+    // requested a GROUP of four trips ahead - the next group of this tile, or the first group of the wave's next tile
+#define DGCN_BWALK(TRIP)                                                                                                 \
+        for (int g0 = 0; g0 < trips; g0 += 4) { /* (trips is wave-uniform: scalar branches) */                         \
+            BigRec4 Bn = A;                                                                                            \
+            if (g0 + 4 < trips) big_load_group(Bn, bp + (size_t)(g0 + 4) * 512); /* (its last trips may lie past the tile: never walked) */ \
+            else if (have_next) big_load_group(Bn, reinterpret_cast<const char*>(rec + base_n) + voff);                \
+            TRIP(A.r0, g0)                                                                                             \
+            if (g0 + 1 < trips) TRIP(A.r1, g0 + 1)                                                                     \
+            if (g0 + 2 < trips) TRIP(A.r2, g0 + 2)                                                                     \
+            if (g0 + 3 < trips) TRIP(A.r3, g0 + 3)                                                                     \
+            A = Bn;                                                                                                    \
+        }
+#define DGCN_BFIRST_GROUP                                                                                                \
+        if (wave < tiles) {                                                                                            \
+            const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[wave]);                         \
+            big_load_group(A, reinterpret_cast<const char*>(rec + base0) + voff);                                      \
+        }
+    // aggregation layout (row s16, chunks cfirst / csecond: oA, oB) -> the MFMA's operand layout (lane 16 q + r: H[r][4 s + q])
+#define DGCN_BSTAGE_TO_OPERAND(OA, OB)                                                                                   \
+        *reinterpret_cast<float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2)) = OA;                                \
+        *reinterpret_cast<float4*>(stg + s16 * kBH + ((csecond ^ (s16 & 7)) << 2)) = OB;                               \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                           \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) pz[k][s] = stg[mr * kBH + (((s ^ (mr & 7)) << 2) | mq)];         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        __builtin_amdgcn_wave_barrier(); /* (the staging tile is rewritten by the next tile) */
+    // MFMA output layout (row mr, chunks mq and 4 + mq: O0, O1) -> aggregation layout, into pz[k]
+#define DGCN_BSTAGE_TO_AGG(O0, O1)                                                                                       \
+        *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = O0;                                      \
+        *reinterpret_cast<float4*>(stg + mr * kBH + (((4 + mq) ^ (mr & 7)) << 2)) = O1;                                \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+        {                                                                                                              \
+            const float4 yA = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2));        \
+            const float4 yB = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((csecond ^ (s16 & 7)) << 2));       \
+            pz[k][0] = yA.x; pz[k][1] = yA.y; pz[k][2] = yA.z; pz[k][3] = yA.w;                                        \
+            pz[k][4] = yB.x; pz[k][5] = yB.y; pz[k][6] = yB.z; pz[k][7] = yB.w;                                        \
+        }                                                                                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < kBigTilesPerWave; ++k) {
+    for (int k = 0; k < kBigTilesPerWave; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pz[k][j] = 0.f;
-        const int slot = (wave + kBigWaves * k) * 16 + s16;
-        if (slot < ng) {
-            const float* zr = a.Zin + (size_t)(n0 + (int)perm[slot]) * 64;
-            const float4 yA = *reinterpret_cast<const float4*>(zr + 4 * cfirst), yB = *reinterpret_cast<const float4*>(zr + 4 * csecond);
-            pz[k][0] = yA.x; pz[k][1] = yA.y; pz[k][2] = yA.z; pz[k][3] = yA.w;
-            pz[k][4] = yB.x; pz[k][5] = yB.y; pz[k][6] = yB.z; pz[k][7] = yB.w;
+
+    if (a.front) {
+        // -------- layer index 0 on constant input features (X == NULL: what every script of the reference feeds,
+        // gcn/utils.py:98-106) and the transform of layer index 1, the two places whose chains run in double (include/dgcn.h).
+        // Every row of Z = x.[W0 | W1] is the same 64 numbers, so the aggregation's chain fma(val_j, Z1[u_j][c], acc) needs
+        // the entries' VALUES only - no gathers (fused.hip's const_rows).  The neutral records do not serve here (-0.0 times a
+        // negative feature is +0.0, and -0.0 + +0.0 is +0.0): entries past the row's end are skipped by count.
+        const BigFront& F = a.first;
+        double z1d[8];
+        float z0c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = (j < 4 ? 4 * cfirst : 4 * csecond) + (j & 3);
+            float q0 = 0.f, q1 = 0.f;
+            for (int kk = 0; kk < F.cin; ++kk) {
+                q0 = fmaf(F.x_const, F.W0[kk * 64 + c], q0);
+                q1 = fmaf(F.x_const, F.W0[kk * 64 + kBH + c], q1);
+            }
+            z0c[j] = q0;
+            z1d[j] = (double)q1;
+        }
+        DGCN_BFIRST_GROUP
+#pragma unroll
+        for (int k = 0; k < kBigTilesPerWave; ++k) {
+            if (wave + kBigWaves * k < tiles) {  // (wave-uniform)
+                DGCN_BTILE_HEAD
+                const int crow = has ? (int)cnt[perm[slot]] : 0;
+                double accd[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accd[j] = 0.0;
+#define DGCN_BTRIP_FRONT(R, TT)                                                                                          \
+                {                                                                                                      \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+                        const double ad = (double)__int_as_float(e == 0 ? DGCN_BQB(R.x, 0) : e == 1 ? DGCN_BQB(R.x, 1) : e == 2 ? DGCN_BQB(R.x, 2) : DGCN_BQB(R.x, 3)); \
+                        if (4 * (TT) + e < crow) {                                                                     \
+                            _Pragma("unroll") for (int j = 0; j < 8; ++j) accd[j] = fma(ad, z1d[j], accd[j]);          \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }
+                DGCN_BWALK(DGCN_BTRIP_FRONT)
+#undef DGCN_BTRIP_FRONT
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    double d = (double)z0c[j] + accd[j];
+                    if (F.bias0) d += (double)F.bias0[(j < 4 ? 4 * cfirst : 4 * csecond) + (j & 3)];
+                    o[j] = big_act((float)d, F.act0);
+                }
+                const float4 oA = make_float4(o[0], o[1], o[2], o[3]), oB = make_float4(o[4], o[5], o[6], o[7]);
+                DGCN_BSTAGE_TO_OPERAND(oA, oB)
+            }
+        }
+        // transform of layer index 1: every chain in double, rounded once (v_mfma_f64_16x16x4_f64 = the ascending fma chain;
+        // its output register i of lane (q, r) holds row 4 i + q: the weight fragments are loaded accordingly, fused.hip)
+        big_load_bfrag(F.W1, bfrag, true);
+#pragma unroll
+        for (int k = 0; k < kBigTilesPerWave; ++k) {
+            const int t = wave + kBigWaves * k;
+            if (t < tiles) {
+                float4 zo[4];
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    bf64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const double ad = (double)pz[k][s];
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bfrag[s][2 * cp], ad, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bfrag[s][2 * cp + 1], ad, acc1, 0, 0, 0);
+                    }
+                    zo[2 * cp] = make_float4((float)acc0[0], (float)acc0[1], (float)acc0[2], (float)acc0[3]);
+                    zo[2 * cp + 1] = make_float4((float)acc1[0], (float)acc1[1], (float)acc1[2], (float)acc1[3]);
+                }
+                const int mslot = t * 16 + mr;
+                if (mslot < ng) {
+                    const int v = (int)perm[mslot];
+                    *reinterpret_cast<float4*>(bufB + v * kBH + ((mq ^ big_key(v)) << 2)) = zo[2];
+                    *reinterpret_cast<float4*>(bufB + v * kBH + (((4 + mq) ^ big_key(v)) << 2)) = zo[3];
+                }
+                DGCN_BSTAGE_TO_AGG(zo[0], zo[1])
+            }
+        }
+        __syncthreads();  // Z1 of layer index 1 is complete
+    } else {
+        // Z0 of the first aggregation: from the caller's Z (row-major, Z0 | Z1), in the aggregation's layout
+#pragma unroll
+        for (int k = 0; k < kBigTilesPerWave; ++k) {
+            const int slot = (wave + kBigWaves * k) * 16 + s16;
+            if (slot < ng) {
+                const float* zr = a.Zin + (size_t)(n0 + (int)perm[slot]) * 64;
+                const float4 yA = *reinterpret_cast<const float4*>(zr + 4 * cfirst), yB = *reinterpret_cast<const float4*>(zr + 4 * csecond);
+                pz[k][0] = yA.x; pz[k][1] = yA.y; pz[k][2] = yA.z; pz[k][3] = yA.w;
+                pz[k][4] = yB.x; pz[k][5] = yB.y; pz[k][6] = yB.z; pz[k][7] = yB.w;
+            }
         }
     }
-    const unsigned voff = (unsigned)lane * 8u;
+    float zz0[kBigTilesPerWave], zz1[kBigTilesPerWave];  // the last layer's (width 1) z0 / z1 of this lane's row
+#pragma unroll
+    for (int k = 0; k < kBigTilesPerWave; ++k) zz0[k] = zz1[k] = 0.f;
     for (int i = 0; i < a.num_hidden; ++i) {
         const BigLayer& L = a.layers[i];
         const bool last = i == a.num_hidden - 1;
-        // -------- aggregation: H' = act(Z0 + L.Z1 + b), 4 lanes x 2 float4 per row, 16 rows per pass.  Every trip needs a
-        // record from global memory (L2 / MALL: 500 .. 2 000 cycles), so the records are requested a GROUP of four trips
-        // ahead - the next group of this tile, or the first group of the wave's next tile.
-        {
-            BigRec4 A = {};
-            if (wave < tiles) {
-                const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[wave]);
-                big_load_group(A, reinterpret_cast<const char*>(rec + base0) + voff);
-            }
-#define DGCN_BQB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, true)
-#define DGCN_BTRIP(R)                                                                                                   \
-            {                                                                                                          \
-                float4 zA[4], zB[4];                                                                                   \
-                float av[4];                                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
-                    const unsigned w = (unsigned)(e == 0 ? DGCN_BQB(R.y, 0) : e == 1 ? DGCN_BQB(R.y, 1) : e == 2 ? DGCN_BQB(R.y, 2) : DGCN_BQB(R.y, 3)); \
-                    av[e] = __int_as_float(e == 0 ? DGCN_BQB(R.x, 0) : e == 1 ? DGCN_BQB(R.x, 1) : e == 2 ? DGCN_BQB(R.x, 2) : DGCN_BQB(R.x, 3)); \
-                    zA[e] = big_lds_chunk(w ^ cA);                                                                     \
-                    zB[e] = big_lds_chunk(w ^ cB);                                                                     \
-                }                                                                                                      \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
-                    accA = big_fma4(av[e], zA[e], accA);                                                               \
-                    accB = big_fma4(av[e], zB[e], accB);                                                               \
-                }                                                                                                      \
-            }
+        // -------- aggregation: H' = act(Z0 + L.Z1 + b), 4 lanes x 2 float4 per row, 16 rows per pass
+        DGCN_BFIRST_GROUP
 #pragma unroll
-            for (int k = 0; k < kBigTilesPerWave; ++k) {
-                const int t = wave + kBigWaves * k;
-                if (t < tiles) {  // (wave-uniform)
-                    const int tn = t + kBigWaves;
-                    const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);
-                    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);
-                    const unsigned base_n = (k + 1 < kBigTilesPerWave && tn < tiles) ? (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[tn]) : 0u;
-                    const int slot = t * 16 + s16;
-                    const bool has = slot < ng;
-                    float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
-                    const char* bp = reinterpret_cast<const char*>(rec + base) + voff;
-                    for (int g0 = 0; g0 < trips; g0 += 4) {  // (trips is wave-uniform: scalar branches)
-                        BigRec4 Bn = A;
-                        if (g0 + 4 < trips) big_load_group(Bn, bp + (size_t)(g0 + 4) * 512);  // (its last trips may lie past the tile: never walked)
-                        else if (k + 1 < kBigTilesPerWave && tn < tiles) big_load_group(Bn, reinterpret_cast<const char*>(rec + base_n) + voff);
-                        DGCN_BTRIP(A.r0)
-                        if (g0 + 1 < trips) DGCN_BTRIP(A.r1)
-                        if (g0 + 2 < trips) DGCN_BTRIP(A.r2)
-                        if (g0 + 3 < trips) DGCN_BTRIP(A.r3)
-                        A = Bn;
+        for (int k = 0; k < kBigTilesPerWave; ++k) {
+            if (wave + kBigWaves * k < tiles) {  // (wave-uniform)
+                DGCN_BTILE_HEAD
+                float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
+#define DGCN_BTRIP(R, TT)                                                                                                \
+                {                                                                                                      \
+                    float4 zA[4], zB[4];                                                                               \
+                    float av[4];                                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+                        const unsigned w = (unsigned)(e == 0 ? DGCN_BQB(R.y, 0) : e == 1 ? DGCN_BQB(R.y, 1) : e == 2 ? DGCN_BQB(R.y, 2) : DGCN_BQB(R.y, 3)); \
+                        av[e] = __int_as_float(e == 0 ? DGCN_BQB(R.x, 0) : e == 1 ? DGCN_BQB(R.x, 1) : e == 2 ? DGCN_BQB(R.x, 2) : DGCN_BQB(R.x, 3)); \
+                        zA[e] = big_lds_chunk(w ^ cA);                                                                 \
+                        zB[e] = big_lds_chunk(w ^ cB);                                                                 \
+                    }                                                                                                  \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+                        accA = big_fma4(av[e], zA[e], accA);                                                           \
+                        accB = big_fma4(av[e], zB[e], accB);                                                           \
+                    }                                                                                                  \
+                }
+                DGCN_BWALK(DGCN_BTRIP)
+#undef DGCN_BTRIP
+                float4 oA = make_float4(pz[k][0] + accA.x, pz[k][1] + accA.y, pz[k][2] + accA.z, pz[k][3] + accA.w);
+                float4 oB = make_float4(pz[k][4] + accB.x, pz[k][5] + accB.y, pz[k][6] + accB.z, pz[k][7] + accB.w);
+                if (L.bias) {  // (fetched here, not kept through the walk: eight registers the kernel does not have)
+                    const float4 biasA = *reinterpret_cast<const float4*>(L.bias + 4 * cfirst);
+                    const float4 biasB = *reinterpret_cast<const float4*>(L.bias + 4 * csecond);
+                    oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
+                    oB.x += biasB.x; oB.y += biasB.y; oB.z += biasB.z; oB.w += biasB.w;
+                }
+                oA.x = big_act(oA.x, L.act); oA.y = big_act(oA.y, L.act); oA.z = big_act(oA.z, L.act); oA.w = big_act(oA.w, L.act);
+                oB.x = big_act(oB.x, L.act); oB.y = big_act(oB.y, L.act); oB.z = big_act(oB.z, L.act); oB.w = big_act(oB.w, L.act);
+                if (last) {
+                    // the last layer (32 -> 1): z = H'.[w0 | w1], two fmaf chains over k = 0..31 - the row's features sit in its
+                    // four lanes, chunk c in lane c & 3 (as its first or its second float4): the chains go round the quad
+                    const float* Wl = a.Wlast;
+                    float q0 = 0.f, q1 = 0.f;
+#define DGCN_BLAST_STEP(C)                                                                                               \
+                    {                                                                                                  \
+                        const float4 o = (cfirst == (C)) ? oA : oB;                                                    \
+                        float t0 = q0, t1 = q1;                                                                        \
+                        t0 = fmaf(o.x, Wl[(4 * (C) + 0) * 2], t0); t1 = fmaf(o.x, Wl[(4 * (C) + 0) * 2 + 1], t1);      \
+                        t0 = fmaf(o.y, Wl[(4 * (C) + 1) * 2], t0); t1 = fmaf(o.y, Wl[(4 * (C) + 1) * 2 + 1], t1);      \
+                        t0 = fmaf(o.z, Wl[(4 * (C) + 2) * 2], t0); t1 = fmaf(o.z, Wl[(4 * (C) + 2) * 2 + 1], t1);      \
+                        t0 = fmaf(o.w, Wl[(4 * (C) + 3) * 2], t0); t1 = fmaf(o.w, Wl[(4 * (C) + 3) * 2 + 1], t1);      \
+                        q0 = DGCN_BQBF(t0, (C) & 3);                                                                   \
+                        q1 = DGCN_BQBF(t1, (C) & 3);                                                                   \
                     }
-                    float4 oA = make_float4(pz[k][0] + accA.x, pz[k][1] + accA.y, pz[k][2] + accA.z, pz[k][3] + accA.w);
-                    float4 oB = make_float4(pz[k][4] + accB.x, pz[k][5] + accB.y, pz[k][6] + accB.z, pz[k][7] + accB.w);
-                    if (L.bias) {  // (fetched here, not kept through the walk: eight registers the kernel does not have)
-                        const float4 biasA = *reinterpret_cast<const float4*>(L.bias + 4 * cfirst);
-                        const float4 biasB = *reinterpret_cast<const float4*>(L.bias + 4 * csecond);
-                        oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
-                        oB.x += biasB.x; oB.y += biasB.y; oB.z += biasB.z; oB.w += biasB.w;
-                    }
-                    oA.x = big_act(oA.x, L.act); oA.y = big_act(oA.y, L.act); oA.z = big_act(oA.z, L.act); oA.w = big_act(oA.w, L.act);
-                    oB.x = big_act(oB.x, L.act); oB.y = big_act(oB.y, L.act); oB.z = big_act(oB.z, L.act); oB.w = big_act(oB.w, L.act);
-                    if (last) {
-                        if (has && trips > 0) {
-                            float* dst = a.Hout + (size_t)(n0 + (int)perm[slot]) * kBH;
-                            *reinterpret_cast<float4*>(dst + 4 * cfirst) = oA;
-                            *reinterpret_cast<float4*>(dst + 4 * csecond) = oB;
-                        }
-                    } else {
-                        // aggregation layout -> operand layout of the next transform (lane 16 q + r: H'[r][4 s + q], s = 0..7)
-                        *reinterpret_cast<float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2)) = oA;
-                        *reinterpret_cast<float4*>(stg + s16 * kBH + ((csecond ^ (s16 & 7)) << 2)) = oB;
-                        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int s = 0; s < 8; ++s) pz[k][s] = stg[mr * kBH + (((s ^ (mr & 7)) << 2) | mq)];
-                        __builtin_amdgcn_s_waitcnt(0xC07F);
-                        __builtin_amdgcn_wave_barrier();  // (the staging tile is rewritten by the next tile)
-                    }
+                    DGCN_BLAST_STEP(0) DGCN_BLAST_STEP(1) DGCN_BLAST_STEP(2) DGCN_BLAST_STEP(3)
+                    DGCN_BLAST_STEP(4) DGCN_BLAST_STEP(5) DGCN_BLAST_STEP(6) DGCN_BLAST_STEP(7)
+#undef DGCN_BLAST_STEP
+                    zz0[k] = q0;
+                    zz1[k] = q1;
+                } else {
+                    DGCN_BSTAGE_TO_OPERAND(oA, oB)
                 }
             }
-#undef DGCN_BTRIP
-#undef DGCN_BQB
         }
         if (last) break;
         // the next layer's weight fragments: requested here, they land while this wave waits at the barrier
-        big_load_bfrag(L.Wnext, bfrag);
+        big_load_bfrag(L.Wnext, bfrag, false);
         __syncthreads();  // every gather of this layer has read Z1
         // -------- transform of the next layer: Z0 | Z1 = H'.[W0 | W1], v_mfma_f32_16x16x4_f32, operands swapped (D^T = W^T.H^T)
         // so that a lane ends with four consecutive features of one vertex; Z1 -> bufB, Z0 -> registers (aggregation layout)
@@ -307,30 +452,63 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfrag[s][ct], pz[k][s], acc[ct], 0, 0, 0);
-                const int slot = t * 16 + mr;
-                if (slot < ng) {
-                    const int v = (int)perm[slot];
+                const int mslot = t * 16 + mr;
+                if (mslot < ng) {
+                    const int v = (int)perm[mslot];
 #pragma unroll
                     for (int ct = 2; ct < 4; ++ct) {
                         const int chunk = (ct & 1) * 4 + mq;
                         *reinterpret_cast<float4*>(bufB + v * kBH + ((chunk ^ big_key(v)) << 2)) = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
                     }
                 }
-                // Z0: MFMA layout (row mr, chunks mq and 4 + mq) -> aggregation layout (row s16, chunks cfirst / csecond)
-                *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-                *reinterpret_cast<float4*>(stg + mr * kBH + (((4 + mq) ^ (mr & 7)) << 2)) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_wave_barrier();
-                const float4 yA = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2));
-                const float4 yB = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((csecond ^ (s16 & 7)) << 2));
-                pz[k][0] = yA.x; pz[k][1] = yA.y; pz[k][2] = yA.z; pz[k][3] = yA.w;
-                pz[k][4] = yB.x; pz[k][5] = yB.y; pz[k][6] = yB.z; pz[k][7] = yB.w;
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_wave_barrier();
+                const float4 o0 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]), o1 = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+                DGCN_BSTAGE_TO_AGG(o0, o1)
             }
         }
         __syncthreads();  // Z1 of the next layer is complete
     }
+    // -------- the last layer's aggregation at width 1: score = act(z0 + sum_j val_j z1[u_j] + b), an fmaf chain in storage
+    // order like every other; z1 of the whole graph as a float array over bufB (the record's word >> 7 is the neighbour)
+    __syncthreads();  // every gather of the last hidden aggregation has read Z1
+    float* zl = bufB;
+#pragma unroll
+    for (int k = 0; k < kBigTilesPerWave; ++k) {
+        const int slot = (wave + kBigWaves * k) * 16 + s16;
+        if (slot < ng && kq4 == 0) zl[perm[slot]] = zz1[k];
+    }
+    if (threadIdx.x == 0) zl[a.max_nodes] = 0.f;  // the neutral record's neighbour
+    __syncthreads();
+    DGCN_BFIRST_GROUP
+#pragma unroll
+    for (int k = 0; k < kBigTilesPerWave; ++k) {
+        if (wave + kBigWaves * k < tiles) {
+            DGCN_BTILE_HEAD
+            float accs = 0.f;
+#define DGCN_BTRIP_TAIL(R, TT)                                                                                           \
+            {                                                                                                          \
+                float zs[4], av[4];                                                                                    \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
+                    const unsigned w = (unsigned)(e == 0 ? DGCN_BQB(R.y, 0) : e == 1 ? DGCN_BQB(R.y, 1) : e == 2 ? DGCN_BQB(R.y, 2) : DGCN_BQB(R.y, 3)); \
+                    av[e] = __int_as_float(e == 0 ? DGCN_BQB(R.x, 0) : e == 1 ? DGCN_BQB(R.x, 1) : e == 2 ? DGCN_BQB(R.x, 2) : DGCN_BQB(R.x, 3)); \
+                    zs[e] = zl[w >> 7];                                                                                \
+                }                                                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) accs = fmaf(av[e], zs[e], accs);                         \
+            }
+            DGCN_BWALK(DGCN_BTRIP_TAIL)
+#undef DGCN_BTRIP_TAIL
+            float o = zz0[k] + accs;
+            if (a.bias_last) o += a.bias_last[0];
+            o = big_act(o, a.act_last);
+            if (has && kq4 == 0 && trips > 0) a.scores[n0 + (int)perm[slot]] = o;
+        }
+    }
+#undef DGCN_BSTAGE_TO_AGG
+#undef DGCN_BSTAGE_TO_OPERAND
+#undef DGCN_BFIRST_GROUP
+#undef DGCN_BWALK
+#undef DGCN_BTILE_HEAD
+#undef DGCN_BQBF
+#undef DGCN_BQB
     if (fault) atomicOr(a.status, fault);
 }
 
@@ -388,8 +566,8 @@ size_t big_workspace(const DgcnBatch* b, const DgcnModel* m) {
     return 256 + b256(B * (size_t)big_rec_cap(b) * 8);
 }
 
-// The forward pass with the hidden stack in one launch: layer 0 and the transform of layer 1 (chains in double) and the
-// last layer (32 -> 1) by the layer-by-layer kernels, exactly as layered_forward runs them; layers 1 .. L-2 by k_big.
+// The forward pass in one launch (constant input features: X == NULL), or - explicit features - layer 0 and the transform
+// of layer 1 by the layer-by-layer kernels exactly as layered_forward runs them, then everything else in one launch.
 // `lws`: dgcn_gcn_forward_workspace(b, m, 0) bytes (Z twice, H), `bws`: big_workspace(b, m) bytes.
 int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const, float* scores,
                 void* lws, void* bws, int32_t* status, hipStream_t s) {
@@ -403,17 +581,26 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
     uint2* rec = reinterpret_cast<uint2*>(w1);
     const DgcnLayer& L0 = m->layers_host[0];
     const DgcnLayer& L1 = m->layers_host[1];
-    int rc = transform_dispatch(X, L0.in_dim, x_const, b->num_nodes, L0.in_dim, L0.weights, 2 * kBH, Zbuf, 2 * kBH, s);
-    if (rc) return rc;
-    rc = spmm_f64acc_dispatch(lap, b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + kBH, 2 * kBH, kBH, Zbuf, 2 * kBH, L0.bias, L0.act,
-                              Hbuf, kBH, s);
-    if (rc) return rc;
-    rc = transform_f64acc_dispatch(Hbuf, kBH, x_const, b->num_nodes, kBH, L1.weights, 2 * kBH, Zbuf, 2 * kBH, s);
-    if (rc) return rc;
+    const DgcnLayer& LL = m->layers_host[Lc - 1];
+    int rc = DGCN_OK;
+    const bool front = X == nullptr && L0.in_dim <= 64;  // constant input features: layer 0 and the transform of layer 1 inside the launch
+    if (!front) {
+        rc = transform_dispatch(X, L0.in_dim, x_const, b->num_nodes, L0.in_dim, L0.weights, 2 * kBH, Zbuf, 2 * kBH, s);
+        if (rc) return rc;
+        rc = spmm_f64acc_dispatch(lap, b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + kBH, 2 * kBH, kBH, Zbuf, 2 * kBH, L0.bias, L0.act,
+                                  Hbuf, kBH, s);
+        if (rc) return rc;
+        rc = transform_f64acc_dispatch(Hbuf, kBH, x_const, b->num_nodes, kBH, L1.weights, 2 * kBH, Zbuf, 2 * kBH, s);
+        if (rc) return rc;
+    }
     BigArgs a = {};
     a.graph_ptr = b->graph_ptr;
     a.lrow = lap->row_ptr; a.lcol = lap->col_idx; a.lval = lap->values;
-    a.Zin = Zbuf; a.Hout = Hbuf; a.rec = rec; a.status = status;
+    a.Zin = Zbuf; a.rec = rec; a.status = status;
+    a.front = front ? 1 : 0;
+    a.first.W0 = L0.weights; a.first.bias0 = L0.bias; a.first.W1 = L1.weights; a.first.x_const = x_const;
+    a.first.cin = L0.in_dim; a.first.act0 = L0.act;
+    a.Wlast = LL.weights; a.bias_last = LL.bias; a.act_last = LL.act; a.scores = scores;
     a.rec_cap = big_rec_cap(b);
     a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
     a.num_hidden = Lc - 2;
@@ -436,14 +623,11 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
         }
     }
     {
-        TimedLaunch t("big_stack", s);
+        TimedLaunch t("big_forward", s);
         DGCN_LAUNCH(t, k_big, dim3((unsigned)b->num_graphs), dim3(kBigBlock), lds, s, a);
         if ((rc = check_launch("k_big"))) return rc;
     }
-    const DgcnLayer& LL = m->layers_host[Lc - 1];
-    rc = transform_dispatch(Hbuf, kBH, x_const, b->num_nodes, kBH, LL.weights, 2, Zbuf, 2, s);
-    if (rc) return rc;
-    return spmm_dispatch(lap, b->graph_ptr, b->num_graphs, b->max_nodes, Zbuf + 1, 2, 1, Zbuf, 2, LL.bias, LL.act, scores, 1, s);
+    return DGCN_OK;
 }
 
 }  // namespace dgcn

@@ -3,7 +3,7 @@ TEST / BENCH INFRASTRUCTURE ONLY - the checker, never the thing measured or ship
 
 For every graph of a batch: max |score - float32 restatement|, max |score - float64 restatement| and the float32
 restatement's own distance from float64 (oracle/ref_numpy.gcn_forward on the reference's makestate, one graph per call
-like the reference; errors in units of max(1, |score|), see tests/conftest.check_scores); the set the reference's local
+like the reference; errors both in units of max(1, |score|), see tests/conftest.check_scores, and in absolute score units); the set the reference's local
 greedy search picks on the RESTATEMENT's priorities (ref_numpy.lgs_vectorised, pinned against the imported
 heuristics.local_greedy_search) against the given states; and SURVEY 7.3(c)'s margin count at delta = twice the
 measured error.  `full_size_configs()` names the BASELINE configurations (C2, C3, C4 at l=1 and l=20, a C5-sized batch).
@@ -37,6 +37,10 @@ def graph_report(indptr, indices, weights, layers, scores, state=None, predict="
     e32 = float((np.abs(scores.astype(np.float64) - f32) / unit).max()) if n else 0.0
     e64 = float((np.abs(scores - f64) / unit).max()) if n else 0.0
     e3264 = float((np.abs(f32.astype(np.float64) - f64) / unit).max()) if n else 0.0
+    # the same three in ABSOLUTE score units (they differ from the scaled ones only where |score| > 1: BA hubs reach 2.2)
+    a32 = float(np.abs(scores.astype(np.float64) - f32).max()) if n else 0.0
+    a64 = float(np.abs(scores - f64).max()) if n else 0.0
+    a3264 = float(np.abs(f32.astype(np.float64) - f64).max()) if n else 0.0
     pr_ref = orc.priority(f32, weights, predict)
     ref_state, _ = orc.lgs_vectorised(indptr, indices, pr_ref)
     pr_got = orc.priority(scores, weights, predict)
@@ -45,7 +49,8 @@ def graph_report(indptr, indices, weights, layers, scores, state=None, predict="
     differs = not np.array_equal(np.asarray(state) == 1, ref_state == 1)
     wabs = weights if predict == "mwis" else None
     risk = orc.margin_risk(indptr, indices, pr_got, np.asarray(state), 2.0 * e32, wabs)
-    return {"e32": e32, "e64": e64, "e3264": e3264, "set_differs": bool(differs), "risk_at_2e": int(risk)}
+    return {"e32": e32, "e64": e64, "e3264": e3264, "a32": a32, "a64": a64, "a3264": a3264, "set_differs": bool(differs),
+            "risk_at_2e": int(risk)}
 
 
 def batch_report(hb, layers, scores, state=None, predict="mwis", flavour="gdpg", graphs=None):
@@ -71,6 +76,14 @@ def summarize(reports):
             "of_those_restatement_further_from_f64": int((over & (e3264 > e64)).sum()),
             "max_err_vs_f64": float(e64.max()), "graphs_over_1e-5_vs_f64": int((e64 > 1e-5).sum()),
             "restatement_max_err_vs_f64": float(e3264.max()),
+            "graphs_over_1e-5_vs_f32_restatement_ids": [int(i) for i in np.flatnonzero(over)],
+            # absolute score units (the scaled figures above divide by max(1, |score|))
+            "abs_max_err_vs_f32_restatement": float(max(r["a32"] for r in reports)),
+            "abs_graphs_over_1e-5_vs_f32_restatement": int(sum(r["a32"] > 1e-5 for r in reports)),
+            "abs_graphs_over_1e-5_vs_f32_restatement_ids": [i for i, r in enumerate(reports) if r["a32"] > 1e-5],
+            "abs_max_err_vs_f64": float(max(r["a64"] for r in reports)),
+            "abs_graphs_over_1e-5_vs_f64": int(sum(r["a64"] > 1e-5 for r in reports)),
+            "abs_restatement_max_err_vs_f64": float(max(r["a3264"] for r in reports)),
             "sets_differing": int(sum(r["set_differs"] for r in reports)),
             "sets_differing_not_flagged_by_margin": int(sum(r["set_differs"] and r["risk_at_2e"] == 0 for r in reports)),
             "graphs_at_margin_risk_at_2x_error": int(sum(r["risk_at_2e"] > 0 for r in reports))}
@@ -109,6 +122,36 @@ def _chunk(args):
     hb = make(count, first)
     res = ctwin.solve(hb, layers)
     return batch_report(hb, layers, res["scores"][:, 0], res["state"])
+
+
+def _chunk_given(args):
+    """Worker: graphs [first, first + count) of a configuration, scores / states GIVEN (fetched from the GPU by the caller)."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    name, first, count, scores, state = args
+    _, _, model, make = full_size_configs()[name]
+    return batch_report(make(count, first), _model(model), scores, state)
+
+
+def scores_report(name, count, graph_ptr, scores, state, procs=None, chunk=64):
+    """The first ``count`` graphs of a configuration with the scores / state bytes the caller computed for that very batch
+    (``full_size_configs()[name][3](count, 0)``: the generators are seeded per graph) -> (summary dict, per-graph reports).
+    This is how the -m gpu suite holds the HIP kernels' output against the restatement directly."""
+    graph_ptr = np.asarray(graph_ptr)
+    scores, state = np.asarray(scores, np.float32).ravel(), np.asarray(state)
+    jobs = []
+    for f in range(0, count, chunk):
+        c = min(chunk, count - f)
+        n0, n1 = int(graph_ptr[f]), int(graph_ptr[f + c])
+        jobs.append((name, f, c, scores[n0:n1].copy(), state[n0:n1].copy()))
+    procs = procs or min(len(jobs), max(1, os.cpu_count() or 2), 16)
+    if procs <= 1:
+        parts = [_chunk_given(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            parts = pool.map(_chunk_given, jobs)
+    reports = [r for p in parts for r in p]
+    return summarize(reports), reports
 
 
 def twin_report(name, procs=None, chunk=125):

@@ -838,16 +838,14 @@ def test_known_answers_of_100_shipped_graphs_on_gpu(engine, dataset100, all_mode
         assert out["status"] == 0
         p = out["totals"] / z["greedy_utility"]
         want = z[key]
-        # the restatement and the kernels round differently in the last bits: a near-tie may flip a set
-        assert np.sum(~np.isclose(p, want, rtol=1e-9)) <= 2, name
-        assert abs(p.mean() - want.mean()) < 2e-3, name
+        # every one of the 100 ratios: the kernels' last-bit differences from the restatement flip no set here
+        assert np.sum(~np.isclose(p, want, rtol=1e-9)) == 0, (name, np.flatnonzero(~np.isclose(p, want, rtol=1e-9)).tolist())
         assert 0.75 < p.min() and p.max() < 1.5
 
 
 def test_test_loop_against_the_executed_reference(engine, dataset100, all_models):
     """A12 against the reference's own run of mwis_dqn_test.py (tests/golden/ref_exec.npz test_loop|*): harness.evaluate on
-    the same 100 shipped graphs with the same four checkpoints gives the reference's ratio column (float32 reorderings
-    may flip at most a couple of near-ties per model)."""
+    the same 100 shipped graphs with the same four checkpoints gives the reference's ratio column, every row of it."""
     import scipy.sparse as sp
     from distgcn_amd import harness
     from distgcn_amd.mwis_dqn_call import DQNAgent
@@ -865,8 +863,7 @@ def test_test_loop_against_the_executed_reference(engine, dataset100, all_models
         rows = harness.evaluate(agent, adjs, wts, gu)
         p = np.array([r["p"] for r in rows])
         ref = z["test_loop|%s|l%d" % (ts, nl)]
-        assert np.sum(~np.isclose(p, ref, rtol=1e-9)) <= 2, (name, int(np.sum(~np.isclose(p, ref, rtol=1e-9))))
-        assert abs(p.mean() - ref.mean()) < 2e-3
+        assert np.sum(~np.isclose(p, ref, rtol=1e-9)) == 0, (name, np.flatnonzero(~np.isclose(p, ref, rtol=1e-9)).tolist())
 
 
 def _solve(engine, db, dm):
