@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+LDS_PEAK_TBS = 256 * 128 * 2.4e9 / 1e12  # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s
 
 
 def parse(argv=None):
@@ -42,7 +43,7 @@ def parse(argv=None):
     ap.add_argument("--graphs", type=int, default=None, help="graphs per GPU (weak scaling) or in the whole job (strong); default 500 (C5: 64, or any number given here: 256 puts one search on every CU)")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--p", type=float, default=0.1)
-    ap.add_argument("--family", choices=["er", "ba"], default="er",
+    ap.add_argument("--family", choices=["er", "ba", "mc"], default="er",
                     help="er: G(nodes, p) (C2 / C3); ba: the BA test2 mix of SURVEY 8d (C4), ignores --nodes/--p")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--layers", type=int, default=20)
@@ -58,10 +59,12 @@ def parse(argv=None):
                     help="also time the step issued alternately on two HIP streams (side figure; its overlapping launches would "
                          "blur a kernel trace of the run, so it is not part of the default command)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
-    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5"], default=None,
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5", "ER500", "MC900"], default=None,
                     help="BASELINE.json configuration shortcuts: C2 = 500 ER N=100 l=1; C3 = 500 ER N=200 l=20 (the default line); "
                          "C4 = the 4 000-graph BA batch over the ranks (--layers as given, default 20); C4-share = one GPU's 500 "
-                         "graphs of it; C5 = GCN-guided rollout (b=16) on 64 ER N=500 graphs")
+                         "graphs of it; C5 = GCN-guided rollout (b=16) on 64 ER N=500 graphs; beyond the fused kernel's 512 vertices / LDS "
+                         "budget (the any-size path, csrc/general.hip + big.hip): ER500 = 256 ER N=500 p=0.1 (25 000 entries per graph), "
+                         "MC900 = 256 joint 3-channel conflict graphs of 300 flows (900 vertices, wireless_rollout_test_flood.py:98-133)")
     ap.add_argument("--parity-seconds", type=float, default=25.0,
                     help="budget of the full-size parity report against the oracle restatement (0 = skip)")
     ap.add_argument("--beam", type=int, default=16, help="C5: rollout candidates per step")
@@ -76,6 +79,12 @@ def parse(argv=None):
         args.family, args.graphs = "ba", 500
     elif args.config == "C5":
         args.family, args.graphs, args.nodes, args.p, args.layers = "er", (args.graphs or 64), 500, 0.02, 20
+    elif args.config == "ER500":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "er", (args.graphs or 256), 500, 0.1, 20
+    elif args.config == "MC900":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 900, 0.03, 20
+    if args.config in ("ER500", "MC900") and args.steps is None:
+        args.steps = 400
     if args.graphs is None:
         args.graphs = 500
     if args.steps is None:
@@ -120,8 +129,11 @@ def workload_name(args):
         if args.scaling == "strong" and args.graphs == 4000:
             return "C4"
         return "C4 (one GPU's share)" if args.graphs == 500 else "custom"
+    if args.family == "mc":
+        return "MC900 (joint 3-channel conflict graphs, beyond the fused kernel)" if args.nodes == 900 else "custom"
     key = (args.graphs, args.nodes, args.p, args.layers, args.hidden)
-    return {(500, 200, 0.1, 20, 32): "C3", (500, 100, 0.1, 1, 32): "C2"}.get(key, "custom")
+    return {(500, 200, 0.1, 20, 32): "C3", (500, 100, 0.1, 1, 32): "C2",
+            (256, 500, 0.1, 20, 32): "ER500 (25 000 entries per graph: beyond the fused kernel)"}.get(key, "custom")
 
 
 def cpu_baseline(hb, layers, budget_s):
@@ -179,6 +191,8 @@ def build_host_batch(args, rank, world):
     def gen(count, first):
         if args.family == "ba":
             return datagen.ba_test2_batch(count, first_index=first)
+        if args.family == "mc":
+            return multichannel_batch(count, args.nodes // 3, args.p, first_index=first)
         return datagen.er_batch(count, args.nodes, args.p, first_index=first)
     if args.scaling == "weak":
         return gen(args.graphs, rank * args.graphs), world * args.graphs
@@ -188,6 +202,28 @@ def build_host_batch(args, rank, world):
     # without generating (ER: drawn; BA: N and m fix the edge count), so each rank generates only its own range
     lo, hi = parallel.shard_ranges_from_sizes(graph_sizes(args), world)[rank]
     return gen(hi - lo, lo), args.graphs
+
+
+def multichannel_batch(count, nflows, p, first_index=0, n_ch=3, keep=0.8):
+    """Joint multi-channel conflict graphs as the reference's multi-channel scripts build them
+    (wireless_dqn_test_mc.py:159-161): a single-channel conflict graph (stand-in: ER(nflows, p), the topology generator
+    ``graph_util`` is absent from the reference), ``n_ch`` per-channel copies with every edge kept with probability ``keep``
+    (``multichannel_conflict_simulate``, wireless_rollout_test_flood.py:83-95) and the joint graph on ``n_ch * nflows``
+    vertices - the channels' graphs on the diagonal blocks plus a clique over every flow's copies (``:98-133``)."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen, wireless
+    from distgcn_amd.batch import HostBatch
+    ps, cs, ws = [], [], []
+    for g in range(first_index, first_index + count):
+        rng = np.random.default_rng(datagen.SEED0 + 2_000_000 + g)
+        ip, ix = datagen.er_graph(nflows, p, rng)
+        base = sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(nflows, nflows))
+        chans = wireless.multichannel_conflict_simulate(base, k=n_ch, p=keep, rng=np.random.RandomState(datagen.SEED0 % 100000 + g))
+        _, joint = wireless.multichannel_conflict_graph(chans)
+        ps.append(joint.indptr.astype(np.int64))
+        cs.append(joint.indices.astype(np.int64))
+        ws.append(rng.random(n_ch * nflows))
+    return HostBatch.from_csr_lists(ps, cs, ws)
 
 
 def graph_sizes(args):
@@ -277,7 +313,8 @@ class GpuWorkload:
 
     def kernel_times(self):
         fam_ms = {}
-        for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve"):
+        for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve", "big_forward",
+                    "general_prepare", "general_greedy"):
             ms, n = self.eng.timing_read(fam)
             if n:
                 fam_ms[fam] = (ms, n)
@@ -415,6 +452,8 @@ def roofline_objects(args, wl, fam_ms):
         ms, n = fam_ms[dom]
         avg_s = ms / n * 1e-3
         shape = ("ba%d" % args.graphs) if args.family == "ba" else "%dx%d" % (args.graphs, args.nodes)
+        if args.family == "mc":
+            shape = "mc%dx%d" % (args.graphs, args.nodes)
         tkey = ("spmm|%s|C%d" % (shape, args.hidden)) if dom == "spmm" else "%s|%s|l%d" % (dom, shape, args.layers)
         traffic = traffic_db.get(tkey, {}).get("hbm_bytes_per_launch")
         if dom in ("spmm", "layer"):
@@ -428,7 +467,7 @@ def roofline_objects(args, wl, fam_ms):
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": avg_bytes,
                         "formula": "SURVEY 8d B_spmm + 4*C*N for the fused '+Z0' read, averaged over the layers"}
-        elif dom in ("fused_forward", "fused_solve"):
+        elif dom in ("fused_forward", "fused_solve", "big_forward"):
             # one launch = every layer of every graph: SURVEY 8d counts the forward layer by layer
             # (1.658 MB per ER N=200 l=20 graph); the kernel keeps the graph in LDS, so its real HBM
             # traffic ('traffic', from PMC counters) is far BELOW this figure, not above it.
@@ -439,14 +478,27 @@ def roofline_objects(args, wl, fam_ms):
             for lyr in layers:
                 cin, cout = lyr["weights"][0].shape
                 flops += 2.0 * n_nodes * cin * 2 * cout + 2.0 * nnz_l * cout
-            roofline = {"kernel": "k_fused (%s: whole path, one launch per step)" % dom, "bound": "hbm",
+            # the resources that actually pace these kernels are on the chip (the graph never leaves it): the LDS array (one
+            # 128-byte row of Z1 per entry and hidden layer) and the fp32 MFMA pipe - printed beside the SURVEY 8d figure
+            lds_bytes = float(sum(128.0 * nnz_l for lyr in layers[1:-1] if lyr["weights"][0].shape[1] == 32))
+            kname = ("k_big (whole forward of graphs beyond the fused kernel's LDS budget, one launch per step; supports and greedy search in launches of their own)"
+                     if dom == "big_forward" else
+                     "k_shallow (one-layer model: whole path, one launch per step)" if len(layers) == 1 else
+                     "k_fused (%s: whole path, one launch per step)" % dom)
+            roofline = {"kernel": kname, "bound": "hbm",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": algo,
                         "formula": "SURVEY 8d: sum over layers of B_spmm (CSR + Z read + Y write), %d graphs" % hb.num_graphs,
                         "fp32_matrix_view": {"flops_per_launch": flops, "achieved_tflops": flops / avg_s / 1e12,
                                              "peak_tflops": F32_MATRIX_PEAK_TF,
-                                             "frac": flops / avg_s / 1e12 / F32_MATRIX_PEAK_TF}}
+                                             "frac": flops / avg_s / 1e12 / F32_MATRIX_PEAK_TF},
+                        "on_chip_view": {"binding": "LDS array + fp32 MFMA pipe (HBM sees the input once: 'traffic')",
+                                         "lds_gather_bytes_per_launch": lds_bytes,
+                                         "lds_gather_tbs": lds_bytes / avg_s / 1e12, "lds_peak_tbs": LDS_PEAK_TBS,
+                                         "lds_frac": lds_bytes / avg_s / 1e12 / LDS_PEAK_TBS,
+                                         "note": "the SURVEY 8d 'achieved' above is an equivalent bandwidth (layer-by-layer bytes / time), "
+                                                 "not bytes that crossed HBM; lds_peak = 256 CUs x 128 B/clk x 2.4 GHz"}}
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
@@ -867,6 +919,7 @@ def main(argv=None, workload_factory=None):
         per_gpu = args.graphs if args.scaling == "weak" else None
         out = {
             "metric": ("graphs/sec (GCN fwd + greedy MWIS) on ER N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
+                      else "graphs/sec (GCN fwd + greedy MWIS) on joint 3-channel conflict graphs of %d flows" % (args.nodes // 3) if args.family == "mc"
                       else "graphs/sec (GCN fwd + greedy MWIS) on the BA test2 mix",
             "value": wl.job_graphs * args.steps / dt,
             "unit": "graphs/s",
@@ -878,10 +931,11 @@ def main(argv=None, workload_factory=None):
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic %s graphs (seeded), uniform(0,1) weights; " % ("ER" if args.family == "er" else "BA") + wl.weights_note,
+            "data": "synthetic %s graphs (seeded), uniform(0,1) weights; " % {"er": "ER", "ba": "BA", "mc": "multi-channel joint conflict"}[args.family] + wl.weights_note,
             "config": {"workload": "%s: %d %s %s, l=%d c=%d GCN forward + local greedy, supports rebuilt every step"
                                    % (workload_name(args), args.graphs,
                                       ("ER graphs N=%d p=%g" % (args.nodes, args.p)) if args.family == "er"
+                                      else ("joint conflict graphs of 3 channels x %d flows (base ER p=%g, 80 %% of the edges per channel)" % (args.nodes // 3, args.p)) if args.family == "mc"
                                       else "BA test2-mix graphs (N 100..300)",
                                       "per GPU" if args.scaling == "weak" else "in the job, sharded by graph over the ranks",
                                       args.layers, args.hidden),

@@ -83,7 +83,8 @@ def multichannel_conflict_simulate(adj_i, k: int = 3, p: float = 0.8, rng=np.ran
     us, vs = us[keep_val], vs[keep_val]
     out = []
     for _ in range(int(k)):
-        draws = np.array([rng.rand() for _ in range(us.size)]) if us.size else np.zeros(0)
+        # (one vectorised draw = the same stream as one rng.rand() per edge: the legacy generator fills arrays in order)
+        draws = np.asarray(rng.rand(int(us.size))) if us.size else np.zeros(0)
         keep = ~(draws > p)
         u, v = us[keep], vs[keep]
         m = sp.csr_matrix((np.ones(2 * u.size), (np.concatenate([u, v]), np.concatenate([v, u]))), shape=(n, n))

@@ -138,3 +138,61 @@ def test_nccl_rank_without_a_device_fails_loudly():
     finally:
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
             os.environ.pop(k, None)
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus8_c4_preflight_through_torchrun():
+    """The driver's own 8-GPU command line - ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 8 --config C4`` - on eight gloo ranks with the twin as the engine: the whole
+    4 000-graph BA batch cut into eight unequal shards (strong scaling), ONE gather per step, and every field of the JSON
+    line the driver parses.  Then the same batch on ONE rank: the same sets, the same total weight."""
+    import json
+    import subprocess
+    import sys
+    from distgcn_amd import datagen, parallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    common = ["--backend", "gloo", "--steps", "2", "--warmup", "1", "--layers", "3", "--cpu-seconds", "0", "--no-spmm-probe",
+              "--no-e2e", "--config", "C4"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "_bench_gloo_driver.py"), "--gpus", "8"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = lines[0]
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["job_graphs"] == 4000
+    assert out["unit"] == "graphs/s" and out["higher_is_better"] is True and out["steps"] == 2 and out["warmup"] == 1
+    assert out["value"] == pytest.approx(4000 * 2 / (out["ms_per_step"] * 2e-3), rel=1e-6)  # whole-job aggregate
+    assert "C4" in out["config"]["workload"] and out["config"]["parallelism"] == "graph-sharded x8"
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and d["ranks_counted_by_all_reduce"] == 8
+    assert sorted(p[0] for p in d["rank_device_pairs"]) == list(range(8)) and len({tuple(p) for p in d["rank_device_pairs"]}) == 8
+    g8 = d["gathered_last_step"]
+    assert g8["graphs"] == 4000 and g8["own_slot_matches_own_result"] and g8["status_bits"] == 0
+    # the shards are unequal (balanced on sum(nnz + N), not on the graph count)
+    ranges = parallel.shard_ranges_from_sizes(__import__("bench").graph_sizes(__import__("bench").parse(["--config", "C4"])), 8)
+    assert len({hi - lo for lo, hi in ranges}) > 1 and ranges[0][0] == 0 and ranges[-1][1] == 4000
+    # one rank, same batch (strong scaling: the job does not change with the rank count)
+    r1, l1 = _run_bench_driver(["--gpus", "1", "--force-dist", "--config", "C4"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    g1 = l1[0]["dist"]["gathered_last_step"]
+    assert l1[0]["n_gpus"] == 1 and l1[0]["dist"]["world_size"] == 1
+    assert g1["graphs"] == 4000 and g1["set_members"] == g8["set_members"] and abs(g1["total_weight"] - g8["total_weight"]) < 1e-6
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus8_with_empty_shards():
+    """Eight ranks, five graphs: three ranks own nothing, still join every collective; the line reports all five graphs."""
+    from distgcn_amd import datagen
+    from oracle import ctwin
+    r, lines = _run_bench_driver(["--gpus", "8", "--graphs", "5", "--family", "ba", "--scaling", "strong"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = lines[0]
+    assert out["n_gpus"] == 8 and out["dist"]["world_size"] == 8 and out["dist"]["ranks_counted_by_all_reduce"] == 8
+    ref = ctwin.solve(datagen.ba_test2_batch(5), datagen.random_model(3, 32))
+    g = out["dist"]["gathered_last_step"]
+    assert g["graphs"] == 5 and g["set_members"] == int((ref["state"] == 1).sum())
+    assert abs(g["total_weight"] - float(ref["totals"].sum())) < 1e-9

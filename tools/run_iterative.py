@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--host", type=int, default=1)
+    ap.add_argument("--family", choices=["er", "mc"], default="er", help="mc: joint 3-channel conflict graphs of n // 3 flows (bench.multichannel_batch)")
     args = ap.parse_args()
     import torch
     from distgcn_amd import datagen
@@ -31,12 +32,18 @@ def main():
     from distgcn_amd.mwis_gdpg_call import DQNAgent
     from distgcn_amd.runtime_config import FLAGS
     eng = get_engine()
-    hb = datagen.er_batch(args.graphs, args.n, args.p)
+    if args.family == "mc":
+        import bench
+        hb = bench.multichannel_batch(args.graphs, args.n // 3, args.p)
+    else:
+        hb = datagen.er_batch(args.graphs, args.n, args.p)
     flags = FLAGS.copy(feature_size=1, hidden1=32, num_layer=args.layers, diver_num=1, max_degree=1, predict="mwis")
     agent = DQNAgent(flags, seed=3)
     dm = agent.model.device_model(eng)
     db = eng.upload(hb)
-    assert eng.solve_supported(db, dm), "outside the fused kernel"
+    path = eng.solve_path(db, dm)
+    assert path, "outside the device solvers"
+    print(json.dumps({"path": {1: "fused kernel", 2: "any-size path (general.hip + big.hip)"}[path]}), flush=True)
     greedy = {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL, "rollout": eng.GREEDY_ROLLOUT}
     for which in ("dit", "cit", "rollout"):
         for rep in range(2):
@@ -54,14 +61,15 @@ def main():
                 "ms_per_step": round(1e3 * dt / max(res["steps"], 1), 4), "mean_total": round(tot / args.graphs, 4)}
         if args.host:
             agent.device_iterative = False
-            adj, w = hb.scipy_graph(0), hb.weights[:args.n]
+            n0 = int(hb.graph_ptr[1])
+            adj, w = hb.scipy_graph(0), hb.weights[:n0]
             fn = {"dit": agent.solve_mwis_dit, "cit": agent.solve_mwis_cit,
                   "rollout": lambda a, b: agent.solve_mwis_rollout(a, b, b=args.beam)}[which]
             t0 = time.perf_counter()
             got = fn(adj, w)
             line["host_path_seconds_one_graph"] = round(time.perf_counter() - t0, 3)
             agent.device_iterative = True
-            sel = set(int(v) for v in np.flatnonzero(st[:args.n] == 1))
+            sel = set(int(v) for v in np.flatnonzero(st[:n0] == 1))
             line["host_equals_device"] = bool(sel == got[0])
         print(json.dumps(line), flush=True)
 
