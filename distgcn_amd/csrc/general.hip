@@ -41,7 +41,7 @@ size_t big_workspace(const DgcnBatch* b, const DgcnModel* m);
 int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const, float* scores,
                 void* lws, void* bws, int32_t* status, hipStream_t s);
 
-constexpr int kResBlock = 256;
+constexpr int kResBlock = 1024;  // (graphs of this path are large and batches of them small: 64 graphs x 256 threads left the chip idle)
 constexpr int kMaxBeam = 64;
 
 struct ResArgs {
@@ -355,7 +355,9 @@ __global__ __launch_bounds__(kResBlock) void k_res_central(ResArgs a) {
 }
 
 // ---- greedy_mode 2, first launch: the first `beam` undecided vertices under (priority desc, index asc) - the stable
-// argsort of -gcn_wts (mwis_gdpg_call.py:624-626) - by counting, for every undecided vertex, the ones ahead of it
+// argsort of -gcn_wts (mwis_gdpg_call.py:624-626) - by counting, for every undecided vertex, the ones ahead of it.
+// `lpv` lanes share a vertex and split the count; four independent compares in flight per lane (the first version walked
+// the graph in one dependent chain per thread with an early exit: 343 us per launch at 900 vertices).
 __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cand_lds[];
     __shared__ int s_bad;
@@ -367,45 +369,56 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
     if (threadIdx.x == 0) s_bad = 0;
     const bool in_lds = ng <= lds_nodes;
     double* pl = reinterpret_cast<double*>(cand_lds);
-    uint8_t* al = reinterpret_cast<uint8_t*>(pl + lds_nodes);
     __syncthreads();
-    if (in_lds) {
-        int bad = 0;
-        for (int v = threadIdx.x; v < ng; v += kResBlock) {
-            const double p = a.prio[n0 + v];
-            const bool alive = a.state[n0 + v] == 0;
-            pl[v] = p;
-            al[v] = alive;
-            bad |= alive && p != p;
-        }
-        if (bad) s_bad = 1;
-    } else {
-        int bad = 0;
-        for (int v = threadIdx.x; v < ng; v += kResBlock) bad |= a.state[n0 + v] == 0 && a.prio[n0 + v] != a.prio[n0 + v];
-        if (bad) s_bad = 1;
+    // a decided vertex takes part as "-inf, never ahead of anybody": its priority is replaced by a NaN-free sentinel and its
+    // liveness is folded into the compare below through the sentinel (no undecided vertex can have priority -inf AND lose
+    // to it: equal priorities are ordered by index, and a sentinel never counts)
+    int bad = 0;
+    for (int v = threadIdx.x; v < ng; v += kResBlock) {
+        const double p = a.prio[n0 + v];
+        const bool alive = a.state[n0 + v] == 0;
+        bad |= alive && p != p;
+        if (in_lds) pl[v] = alive ? p : __longlong_as_double(0x7ff8000000000001ll);  // quiet NaN: compares false both ways
     }
+    if (bad) s_bad = 1;
     __syncthreads();
     if (s_bad) {
         if (threadIdx.x == 0) atomicOr(a.status, DGCN_FAULT_NAN_PRIORITY);
         return;  // no candidates: k_res_pick leaves the graph alone
     }
     const int beam = min(a.beam, kMaxBeam);
-    for (int v = threadIdx.x; v < ng; v += kResBlock) {
-        if (in_lds ? !al[v] : a.state[n0 + v] != 0) continue;
-        const double pv = in_lds ? pl[v] : a.prio[n0 + v];
+    int lsh = 0;
+    while (lsh < 3 && (ng << (lsh + 1)) <= kResBlock) ++lsh;
+    const int lpv = 1 << lsh;
+    const int sub = threadIdx.x & (lpv - 1);
+    for (int v0 = 0; v0 < ng; v0 += kResBlock >> lsh) {  // (uniform trip count: the shuffles below need every lane)
+        const int v = v0 + ((int)threadIdx.x >> lsh);
+        const bool mine = v < ng && a.state[n0 + v] == 0;
         int cnt = 0;
-        if (in_lds) {
-            for (int w = 0; w < ng && cnt < beam; ++w) {
-                const double pw = pl[w];
-                cnt += al[w] && ((pw > pv) || (pw == pv && w < v));
-            }
-        } else {
-            for (int w = 0; w < ng && cnt < beam; ++w) {
-                const double pw = a.prio[n0 + w];
-                cnt += a.state[n0 + w] == 0 && ((pw > pv) || (pw == pv && w < v));
+        if (mine) {
+            const double pv = a.prio[n0 + v];
+            if (in_lds) {
+                int w = sub;
+                for (; w + 3 * lpv < ng; w += 4 * lpv) {
+                    const double p0 = pl[w], p1 = pl[w + lpv], p2 = pl[w + 2 * lpv], p3 = pl[w + 3 * lpv];
+                    cnt += (p0 > pv) || (p0 == pv && w < v);
+                    cnt += (p1 > pv) || (p1 == pv && w + lpv < v);
+                    cnt += (p2 > pv) || (p2 == pv && w + 2 * lpv < v);
+                    cnt += (p3 > pv) || (p3 == pv && w + 3 * lpv < v);
+                }
+                for (; w < ng; w += lpv) {
+                    const double pw = pl[w];
+                    cnt += (pw > pv) || (pw == pv && w < v);
+                }
+            } else {
+                for (int w = sub; w < ng; w += lpv) {
+                    const double pw = a.prio[n0 + w];
+                    cnt += a.state[n0 + w] == 0 && ((pw > pv) || (pw == pv && w < v));
+                }
             }
         }
-        if (cnt < beam) cid[cnt] = v;
+        for (int off = 1; off < lpv; off <<= 1) cnt += __shfl_xor(cnt, off);
+        if (mine && sub == 0 && cnt < beam) cid[cnt] = v;
     }
 }
 
@@ -632,9 +645,9 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         return check_launch("k_res_central");
     }
     {
-        // priorities + liveness bytes of one graph in LDS when they fit (9 bytes per vertex)
+        // priorities of one graph in LDS when they fit (8 bytes per vertex; a decided vertex as a NaN: never ahead of anybody)
         const int lds_nodes = b->max_nodes <= 7000 ? b->max_nodes : 0;
-        const size_t lds = (size_t)lds_nodes * 9 + 16;
+        const size_t lds = (size_t)lds_nodes * 8 + 16;
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res_cand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(DGCN_ERR_LAUNCH, "k_res_cand: cannot reserve %zu bytes of LDS", lds);
