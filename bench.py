@@ -884,11 +884,16 @@ def main(argv=None, workload_factory=None):
     if isinstance(wl, RolloutWorkload):
         ms, n = fam_ms.get("fused_residual", (0.0, 0))
         algo, launches = wl.residual_bytes() if rank == 0 else (0.0, 1)
-        avg_s = ms / max(n, 1) * 1e-3
+        # the timed milliseconds belong to the PRODUCTIVE launches (the replay's count): the host loop also issues a few
+        # launches behind the end of a search (groups of up to 32 between progress read-backs) that find nothing left and
+        # return at once - counting them would understate the launch time and overstate the rate
+        productive = max(min(n, launches * max(args.steps, 1)), 1)
+        avg_s = ms / productive * 1e-3
         ach = (algo / max(launches, 1)) / avg_s / 1e9 if avg_s > 0 else None
         roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
                     "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_search": launches,
+                    "empty_launches_per_search": n / max(args.steps, 1) - launches,
                     "algorithmic_bytes_per_launch": algo / max(launches, 1),
                     "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's launches"}
         kernel_us = {"fused_residual": {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)}}

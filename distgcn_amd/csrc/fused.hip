@@ -2401,6 +2401,11 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
             have.store(kLdsLimit, std::memory_order_relaxed);
         }
     }
+    // (the compact image build and the residual renumbering keep a vertex per thread - crs / cdg, vid = orig[threadIdx.x]:
+    // correct only while a graph has no more vertices than the workgroup has threads; fused_launch_t's block choice
+    // guarantees it today, this check keeps a future override from producing wrong rows silently)
+    if ((MASKED || COMPACT) && a.max_nodes > BLOCK)
+        return fail(DGCN_ERR_LAUNCH, "k_fused: %d vertices per graph on %d threads in a variant that keeps a vertex per thread", a.max_nodes, BLOCK);
     TimedLaunch t(family, s);
     DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
@@ -2430,6 +2435,8 @@ static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* fam
             return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
         reserved[dev & 63].store(kLdsLimit, std::memory_order_relaxed);
     }
+    if (a.max_nodes > kFusedBlock)  // (a vertex per thread in the image build and the last layer: fused_cluster_k checks it too)
+        return fail(DGCN_ERR_LAUNCH, "k_fused (cluster): %d vertices per graph on %d threads", a.max_nodes, kFusedBlock);
     TimedLaunch t(family, s);
     DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, kFusedBlock, true, COMPACT>), dim3(((B + 7) & ~7) * a.cluster), dim3(kFusedBlock), lds, s, a);
     return check_launch("k_fused (cluster)");

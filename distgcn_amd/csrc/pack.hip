@@ -440,6 +440,17 @@ extern "C" int dgcn_pack_compact_batch(const void* const* indptr_host, const voi
         unsigned hc = std::thread::hardware_concurrency();
         num_threads = (int)std::min(8u, hc ? hc : 1u);
     }
+    // caller errors are errors here; 1 stays what the header says it is ("not compactable": a graph of more than 65 535
+    // vertices or a vertex of more than 65 535 neighbours).  The layout must be THIS batch's: a stale DgcnCompactInfo with
+    // smaller offsets would let the sections overrun one another.
+    if (index_bytes != 4 && index_bytes != 8) return fail(DGCN_ERR_ARG, "dgcn_pack_compact_batch: index_bytes must be 4 or 8");
+    DgcnCompactInfo want;
+    if (compact_layout(info, &want) != 0) return 1;
+    if (want.off_graph_ptr != compact->off_graph_ptr || want.off_edge_ptr != compact->off_edge_ptr || want.off_deg != compact->off_deg ||
+        want.off_col != compact->off_col || want.off_weights != compact->off_weights || want.total_bytes != compact->total_bytes)
+        return fail(DGCN_ERR_ARG, "dgcn_pack_compact_batch: the DgcnCompactInfo does not belong to this DgcnPackInfo (dgcn_pack_compact_layout)");
+    if ((int64_t)staging_bytes < compact->total_bytes)
+        return fail(DGCN_ERR_ARG, "dgcn_pack_compact_batch: staging buffer of %zu bytes, %lld needed", staging_bytes, (long long)compact->total_bytes);
     return dgcn::pack_compact(indptr_host, indices_host, weights_host, num_nodes_host, num_graphs, index_bytes, staging_host,
                               staging_bytes, info, compact, num_threads, false);
 }

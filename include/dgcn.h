@@ -211,6 +211,12 @@ int dgcn_transform_f64acc_batch(const float* H, int32_t ldh, float h_const, int3
  * in those two places is what the remaining layers amplify.  Measured on 4 000 BA graphs with the shipped 20-layer
  * model: max |score - float64 evaluation| 1.8e-5 with float32 everywhere, 5.5e-6 with these two chains in double
  * (a NumPy float32 evaluation of the reference's formula: 1.4e-5).  DESIGN.md section 3.
+ * What this means for a caller who compares with float32 scores from elsewhere (TensorFlow's, NumPy's): on the BASELINE
+ * configurations the scores are within 1e-5 (absolute) of the float64 evaluation on every graph; they are within 1e-5 of
+ * the NumPy float32 evaluation too EXCEPT on 9 of the 4 000 BA graphs at l = 20 (up to 1.61e-5: hub-heavy N = 300, m = 2
+ * graphs, ids in tests/test_full_size_parity.py) - where seven float32 summation orders of the same formula differ from
+ * one another by up to 2.3e-5 (profiles/r04_f32_order_envelope.json): no float32 result is "the" reference there.  The
+ * selected sets are identical under every order of that envelope, on all 9 064 graph evaluations.
  *
  * scores[num_nodes * out_dim] = GCN forward over the batch.  X is the dense row-normalised
  * feature matrix [num_nodes][in_dim] or NULL for "every entry = x_const".

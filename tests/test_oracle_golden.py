@@ -133,8 +133,10 @@ def test_forward_anchors_and_closed_form(golden):
 
 
 def test_twin_forward_close_to_restatement(golden):
-    """The C twin (HIP operation order) stays within 1e-5 of the float64 restatement on every fixture graph and model
-    (conftest.check_scores: strict against float64; against the float32 restatement unless that one is the further off)."""
+    """The C twin (HIP operation order) against the restatement on every fixture graph and model (conftest.check_scores,
+    non-strict form: within max(1e-5, the float32 restatement's own distance from float64) of the float64 evaluation, and
+    within 1e-5 of the float32 restatement unless that one is the further off; the strict 1e-5-of-float64 bar is held on
+    the BASELINE configurations at full size: tests/test_full_size_parity.py, tests/test_gpu_full_size.py)."""
     from conftest import check_scores
     hb = golden.host_batch()
     lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
@@ -184,8 +186,10 @@ def _twin_supports(hb, num_supports):
 def test_twin_on_every_shipped_checkpoint(golden, all_models):
     """The C twin (kernel operation order) against the NumPy restatement on all 46 shipped models: hidden widths
     1..64, input widths 1/2/16/32, 1..20 layers, two with a bias, two with max_degree = 2 ([I, L, L.L]).
-    Bars (conftest.check_scores): within 1e-5 of the float64 restatement, strictly; within 1e-5 of the float32
-    restatement too unless that one is the further from float64 (one model: F = 32, predict = mis, scores up to 21)."""
+    Bars (conftest.check_scores, non-strict form): within max(1e-5, the float32 restatement's own distance from float64) of
+    the float64 restatement - 45 models are inside 1e-5 outright, the BA-trained 20-layer model on the ER p = 0.02 forest (out
+    of distribution) is 1.02e-5 away where the float32 restatement is 1.7e-5 away; within 1e-5 of the float32 restatement
+    too unless that one is the further from float64 (one model: F = 32, predict = mis, scores up to 21)."""
     from oracle import ctwin
     from conftest import check_scores
     assert len(all_models.names) == 46
