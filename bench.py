@@ -313,7 +313,7 @@ class GpuWorkload:
 
     def kernel_times(self):
         fam_ms = {}
-        for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve", "big_forward",
+        for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve", "big_forward", "big_solve",
                     "general_prepare", "general_greedy"):
             ms, n = self.eng.timing_read(fam)
             if n:
@@ -467,7 +467,7 @@ def roofline_objects(args, wl, fam_ms):
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": avg_bytes,
                         "formula": "SURVEY 8d B_spmm + 4*C*N for the fused '+Z0' read, averaged over the layers"}
-        elif dom in ("fused_forward", "fused_solve", "big_forward"):
+        elif dom in ("fused_forward", "fused_solve", "big_forward", "big_solve"):
             # one launch = every layer of every graph: SURVEY 8d counts the forward layer by layer
             # (1.658 MB per ER N=200 l=20 graph); the kernel keeps the graph in LDS, so its real HBM
             # traffic ('traffic', from PMC counters) is far BELOW this figure, not above it.
@@ -481,7 +481,9 @@ def roofline_objects(args, wl, fam_ms):
             # the resources that actually pace these kernels are on the chip (the graph never leaves it): the LDS array (one
             # 128-byte row of Z1 per entry and hidden layer) and the fp32 MFMA pipe - printed beside the SURVEY 8d figure
             lds_bytes = float(sum(128.0 * nnz_l for lyr in layers[1:-1] if lyr["weights"][0].shape[1] == 32))
-            kname = ("k_big (whole forward of graphs beyond the fused kernel's LDS budget, one launch per step; supports and greedy search in launches of their own)"
+            kname = ("k_big (big_solve: whole path of graphs beyond the fused kernel's LDS budget - supports, every layer, priority, greedy search - one launch per step)"
+                     if dom == "big_solve" else
+                     "k_big (whole forward of graphs beyond the fused kernel's LDS budget, one launch per step; supports and greedy search in launches of their own)"
                      if dom == "big_forward" else
                      "k_shallow (one-layer model: whole path, one launch per step)" if len(layers) == 1 else
                      "k_fused (%s: whole path, one launch per step)" % dom)

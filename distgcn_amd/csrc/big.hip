@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "lgs_rounds.h"
 
 namespace dgcn {
 
@@ -61,9 +62,21 @@ struct BigFront {          // layer index 0 on constant features + the transform
 
 struct BigArgs {
     const int32_t* graph_ptr;
-    const int32_t* lrow;   // support L: row pointers, diagonal first
+    const int32_t* lrow;   // support L: row pointers, diagonal first (null with `arow`)
     const int32_t* lcol;   // global column ids
     const float* lval;
+    // or the adjacency itself: L = I - D^-1/2 A D^-1/2 is formed while the records are written (gcn/utils.py:120-127, 258-274;
+    // supports.hip's expression: (float)(-(dinv[deg u] * dinv[deg v])), diagonal 1.0f first) - no k_supports launch, no L in HBM
+    const int32_t* arow;
+    const int32_t* acol;
+    const double* dinv;    // float64 d^-1/2 by degree
+    int32_t table_len;
+    // the local greedy search at the end of the launch (heuristics.py:77-116; lgs_rounds.h) - with `arow` only
+    int32_t do_lgs, predict_mwis, lgs_cols_lds;
+    const double* weights;
+    uint8_t* state;
+    int32_t* rounds;
+    double* totals;
     const float* Zin;      // front == 0: [num_nodes][64] Z0 | Z1 of layer index 1 (explicit input features: the caller ran
                            // layer 0 and the transform of layer 1 with the layer-by-layer kernels)
     BigFront first;        // front == 1
@@ -77,6 +90,9 @@ struct BigArgs {
     int32_t lds_cnt_off, lds_perm_off, lds_stage_off, lds_tab_off;  // byte offsets inside the dynamic LDS; the zero row sits at max_nodes * 128
     BigLayer layers[kBigMaxLayers];
 };
+
+// where the greedy search's LDS arrays start: behind the last layer's z1 array (float per vertex + the neutral slot)
+__host__ __device__ __forceinline__ unsigned big_lgs_base(int max_nodes) { return (4u * (unsigned)(max_nodes + 1) + 15u) & ~15u; }
 
 __device__ __forceinline__ int big_key(int row) { return (row >> 1) & 3; }
 __device__ __forceinline__ unsigned big_word(int u) { return ((unsigned)u << 7) | ((unsigned)big_key(u) << 4); }
@@ -116,7 +132,13 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
-    if (ng <= 0) return;
+    if (ng <= 0) {
+        if (a.do_lgs && threadIdx.x == 0) {  // an empty graph: no rounds, total 0 (heuristics.py's loops do not run)
+            if (a.rounds) a.rounds[g] = 0;
+            if (a.totals) a.totals[g] = 0.0;
+        }
+        return;
+    }
     float* bufB = reinterpret_cast<float*>(big_lds);  // LDS offset 0: a gather address is the record's word ^ (chunk << 4)
     const unsigned zrow = (unsigned)a.max_nodes * 128u;
     unsigned short* cnt = reinterpret_cast<unsigned short*>(big_lds + a.lds_cnt_off);  // [max_nodes] entries per row (clamped: only orders rows and bounds walks)
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     if (threadIdx.x < 32) reinterpret_cast<float*>(big_lds + zrow)[threadIdx.x] = 0.f;
     __syncthreads();
     for (int v = threadIdx.x; v < ng; v += kBigBlock) {
-        const unsigned c = (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
+        const unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
         cnt[v] = (unsigned short)min(c, 65535u);
         atomicAdd(&hist[min((int)c, 575)], 1);
     }
@@ -174,6 +196,17 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         tbase[lane] = (unsigned)(incl - tl) * 64u;
         if (!fits && lane == 0) fault |= DGCN_FAULT_DEGREE_RANGE;
     }
+    // (adjacency input) every vertex's d^-1/2 once, in the staging tiles' space (free until the first layer's epilogue): the
+    // records below then need no global lookups beyond the column ids themselves
+    double* dvl = reinterpret_cast<double*>(big_lds + a.lds_stage_off);
+    if (a.arow) {
+        for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+            const int d = (int)cnt[v] - 1;
+            double x = 0.0;
+            if (d < a.table_len) x = a.dinv[d]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+            dvl[v] = x;
+        }
+    }
     __syncthreads();
     const int s16 = lane >> 2, kq4 = lane & 3;  // aggregation: row slot of the tile, quarter of the row
     // every wave writes the records of its own tiles (read back by the same lanes: no barrier)
@@ -183,20 +216,46 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         const int slot = t * 16 + s16;
         const bool has = slot < ng;
         const int v = has ? (int)perm[slot] : 0;
-        const int start = has ? a.lrow[n0 + v] : 0;
-        const int c = has ? a.lrow[n0 + v + 1] - start : 0;
+        const int start = has ? (a.arow ? a.arow[n0 + v] : a.lrow[n0 + v]) : 0;
+        const int c = has ? (a.arow ? a.arow[n0 + v + 1] - start + 1 : a.lrow[n0 + v + 1] - start) : 0;
+        const double dv = (a.arow && has) ? dvl[v] : 0.0;
         uint2* out = rec + base + lane;
-        for (int tt = 0; tt < trips; ++tt) {
-            const int e = 4 * tt + kq4;
-            uint2 r = make_uint2(0x80000000u, zrow);  // {-0.0f, zero row}: fmaf(-0.0f, +0.0f, acc) == acc for every acc
-            if (e < c) {
-                const int u = a.lcol[start + e] - n0;
-                if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
-                else r = make_uint2(__float_as_uint(a.lval[start + e]), big_word(u));
+        const uint2 nothing = make_uint2(0x80000000u, zrow);  // {-0.0f, zero row}: fmaf(-0.0f, +0.0f, acc) == acc for every acc
+        for (int t0 = 0; t0 < trips; t0 += 4) {  // four trips' loads in flight (the walk is a chain of global round trips otherwise)
+            int uu[4];
+            float vv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * (t0 + i) + kq4;
+                uu[i] = -1;
+                vv[i] = 0.f;
+                if (t0 + i < trips && e < c) {
+                    if (a.arow) { if (e > 0) uu[i] = a.acol[start + e - 1] - n0; }
+                    else { uu[i] = a.lcol[start + e] - n0; vv[i] = a.lval[start + e]; }
+                }
             }
-            out[tt * 64] = r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * (t0 + i) + kq4;
+                if (t0 + i >= trips) break;
+                uint2 r = nothing;
+                if (e < c) {
+                    if (a.arow && e == 0) r = make_uint2(__float_as_uint(1.0f), big_word(v));  // (I - A_hat)[v][v], zero-diagonal adjacency
+                    else {
+                        const int u = uu[i];
+                        if (u < 0 || u >= ng) fault |= DGCN_FAULT_BAD_COLUMN;
+                        else if (a.arow) {
+                            if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                            // reference order: (A_vu * dinv[u]) * dinv[v] in float64, negated by "eye - A_hat", then the float32 feed cast
+                            r = make_uint2(__float_as_uint((float)(-(dvl[u] * dv))), big_word(u));
+                        } else r = make_uint2(__float_as_uint(vv[i]), big_word(u));
+                    }
+                }
+                out[(t0 + i) * 64] = r;
+            }
         }
     }
+    __syncthreads();  // (the d^-1/2 array shares the staging tiles' space)
     // (the records are read by the lanes that wrote them, after at least one workgroup barrier below)
 
     // ---- layers
@@ -499,7 +558,89 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
             float o = zz0[k] + accs;
             if (a.bias_last) o += a.bias_last[0];
             o = big_act(o, a.act_last);
-            if (has && kq4 == 0 && trips > 0) a.scores[n0 + (int)perm[slot]] = o;
+            if (has && kq4 == 0 && trips > 0) {
+                const int v = (int)perm[slot];
+                a.scores[n0 + v] = o;
+                if (a.do_lgs) {  // the priority (mwis_dqn_call.py:232: float32 x float64 -> float64), behind z1's array in LDS
+                    double p = (double)o;
+                    if (a.predict_mwis && a.weights) p *= a.weights[n0 + v];
+                    reinterpret_cast<double*>(big_lds + big_lgs_base(a.max_nodes))[v] = p;
+                }
+            }
+        }
+    }
+    if (a.do_lgs) {
+        // -------- the local greedy search (heuristics.py:77-116), as k_lgs runs it: priorities, state bytes, row bounds and the
+        // graph's 16-bit local column ids in LDS (everything the forward pass kept there is dead after the next barrier)
+        double* pr = reinterpret_cast<double*>(big_lds + big_lgs_base(a.max_nodes));
+        double* red = pr + a.max_nodes;
+        unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 1024);
+        int* rol = reinterpret_cast<int*>(acc64 + 4);
+        uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
+        uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
+        uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
+        __syncthreads();  // every score of the graph is computed, every walk over z1 done
+        const int e0 = a.arow[n0], e1 = a.arow[n0 + ng];
+        int bad = 0;
+        for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+            const double p = pr[v];
+            bad |= p != p;
+            st[v] = 0;
+            nw[v] = 0;
+        }
+        for (int v = threadIdx.x; v <= ng; v += kBigBlock) rol[v] = a.arow[n0 + v];
+        for (int base = e0 + (int)threadIdx.x; base < e1; base += kBigBlock * 4) {  // 4 loads in flight per thread
+            int c4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c4[i] = (base + i * kBigBlock < e1) ? a.acol[base + i * kBigBlock] : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + i * kBigBlock < e1) cl[base + i * kBigBlock - e0] = (uint16_t)(c4[i] - n0);
+        }
+        // (no __syncthreads_or: ockl's workgroup reductions bring static LDS with them, and bufB must stay at LDS offset 0)
+        if (threadIdx.x == 0) acc64[3] = 0;
+        __syncthreads();
+        if (bad) acc64[3] = 1;
+        __syncthreads();
+        if (acc64[3] != 0) {  // the reference would spin forever on a NaN priority: report instead
+            if (threadIdx.x == 0) {
+                atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+                if (a.rounds) a.rounds[g] = -1;
+                if (a.totals) a.totals[g] = 0.0;
+            }
+            for (int v = threadIdx.x; v < ng; v += kBigBlock) a.state[n0 + v] = 0;
+            return;
+        }
+        LgsArgs la = {};
+        la.row_ptr = a.arow;
+        la.col_idx = a.acol;
+        la.rounds = a.rounds;
+        if (ng <= 256) lgs_rounds<4, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        else if (ng <= 512) lgs_rounds<2, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        else lgs_rounds<1, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        {
+            // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots)
+            double part = 0.0;
+            for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+                const uint8_t s1 = st[v];
+                if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
+                a.state[n0 + v] = s1;
+            }
+            red[threadIdx.x] = part;
+        }
+        if (a.totals) {
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                double acc = red[threadIdx.x];
+                for (int k2 = 256; k2 < kBigBlock; k2 += 256) acc += red[threadIdx.x + k2];
+                red[threadIdx.x] = acc;
+            }
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) a.totals[g] = red[0];
         }
     }
 #undef DGCN_BSTAGE_TO_AGG
@@ -628,6 +769,77 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
         if ((rc = check_launch("k_big"))) return rc;
     }
     return DGCN_OK;
+}
+
+// bytes of LDS the search at the end of the launch needs (k_lgs's arrays behind z1's), or 0 when a graph's columns do not fit
+static size_t big_lgs_lds(int max_nodes, int max_graph_edges) {
+    const size_t pad = (size_t)((max_nodes + 15) & ~15);
+    const size_t need = big_lgs_base(max_nodes) + (size_t)max_nodes * 8 + 1024 * 8 + 32 + (size_t)((max_nodes + 1 + 3) & ~3) * 4 + 2 * pad +
+                        (size_t)std::max(max_graph_edges, 0) * 2 + 16;
+    return need <= 160 * 1024 ? need : 0;
+}
+
+// 1 = dgcn_solve_batch's whole path in ONE launch: adjacency in, set out (constant input features, k_big's shapes, the graphs'
+// column ids fit the LDS next to the search's state)
+int big_solve_takes(const DgcnBatch* b, const DgcnModel* m, const float* X) {
+    if (const char* e = getenv("DGCN_BIG_SOLVE")) if (atoi(e) == 0) return 0;
+    return !X && big_takes(b, m) && m->layers_host[0].in_dim <= 64 && big_lgs_lds((std::max(b->max_nodes, 16) + 15) & ~15, b->max_graph_edges) != 0;
+}
+
+static void big_fill_model(BigArgs& a, const DgcnModel* m, float x_const) {
+    const int Lc = m->num_layers;
+    const DgcnLayer& L0 = m->layers_host[0];
+    const DgcnLayer& L1 = m->layers_host[1];
+    const DgcnLayer& LL = m->layers_host[Lc - 1];
+    a.first.W0 = L0.weights; a.first.bias0 = L0.bias; a.first.W1 = L1.weights; a.first.x_const = x_const;
+    a.first.cin = L0.in_dim; a.first.act0 = L0.act;
+    a.Wlast = LL.weights; a.bias_last = LL.bias; a.act_last = LL.act;
+    a.num_hidden = Lc - 2;
+    for (int l = 1; l <= Lc - 2; ++l) {
+        const DgcnLayer& L = m->layers_host[l];
+        a.layers[l - 1].bias = L.bias;
+        a.layers[l - 1].act = L.act;
+        a.layers[l - 1].Wnext = l < Lc - 2 ? m->layers_host[l + 1].weights : nullptr;
+    }
+}
+
+static int big_launch(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
+    if (lds > 64 * 1024) {
+        static std::atomic<int> reserved[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "k_big: cannot reserve %zu bytes of LDS", lds);
+            reserved[dev & 63].store(1, std::memory_order_relaxed);
+        }
+    }
+    TimedLaunch t(family, s);
+    DGCN_LAUNCH(t, k_big, dim3((unsigned)B), dim3(kBigBlock), lds, s, a);
+    return check_launch("k_big");
+}
+
+// A1-A10 in one launch for graphs beyond fused.hip's LDS budget: support construction while the records are written, every
+// layer, priority, local greedy search.  `scores` must be given (dgcn_solve_batch passes scratch when the caller wants none).
+int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+              int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
+              hipStream_t s) {
+    BigArgs a = {};
+    a.graph_ptr = b->graph_ptr;
+    a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
+    a.rec = reinterpret_cast<uint2*>((reinterpret_cast<uintptr_t>(bws) + 255) & ~(uintptr_t)255);
+    a.status = status;
+    a.rec_cap = big_rec_cap(b);
+    a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
+    a.front = 1;
+    a.scores = scores;
+    a.do_lgs = 1; a.predict_mwis = predict_mwis; a.lgs_cols_lds = 1;
+    a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
+    big_fill_model(a, m, x_const);
+    size_t lds = big_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
+    lds = std::max(lds, big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    return big_launch(a, b->num_graphs, lds, "big_solve", s);
 }
 
 }  // namespace dgcn

@@ -40,6 +40,10 @@ int big_takes(const DgcnBatch* b, const DgcnModel* m);
 size_t big_workspace(const DgcnBatch* b, const DgcnModel* m);
 int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const, float* scores,
                 void* lws, void* bws, int32_t* status, hipStream_t s);
+int big_solve_takes(const DgcnBatch* b, const DgcnModel* m, const float* X);
+int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+              int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
+              hipStream_t s);
 
 constexpr int kResBlock = 1024;  // (graphs of this path are large and batches of them small: 64 graphs x 256 threads left the chip idle)
 constexpr int kMaxBeam = 64;
@@ -548,6 +552,9 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     char* bws = big ? w.take<char>(big_workspace(b, m)) : nullptr;
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
+    // constant input features on k_big's shapes: the whole path - supports, every layer, priority, greedy search - in ONE launch
+    if (big && big_solve_takes(b, m, X))
+        return big_solve(b, m, dinv_table, table_len, x_const, weights, predict_mwis, sc, state, rounds, totals, status, bws, s);
     int rc = dgcn_supports_batch(b, dinv_table, table_len, lrow, lcol, lval, status, s);
     if (rc) return rc;
     DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, lrow, lcol, lval};

@@ -1,0 +1,175 @@
+// The local greedy search's device-side core, shared by lgs.hip (k_lgs) and big.hip (k_big runs the search at the end of its
+// launch): heuristics.py:77-116, synchronous rounds under the order (priority desc, index asc).  See lgs.hip for the mapping.
+#pragma once
+#include "common.h"
+
+namespace dgcn {
+
+struct LgsArgs {
+    const int32_t* graph_ptr;
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const double* prio;
+    const float* scores;
+    const double* weights;
+    int max_rounds;
+    uint8_t* state;
+    int32_t* rounds;
+    int64_t* stats;
+    int32_t* overhead;
+    const double* sum_weights;
+    double* totals;
+    int32_t* status;
+    int max_nodes;   // LDS carve-up
+    int cols_cap;    // 16-bit column slots in LDS (0 = read col_idx from global memory)
+    // masked / multi-instance form (dgcn_lgs_masked_batch): instance k works on its own
+    // [num_nodes] slice of state/init_state/overhead (and prio when prio_stride != 0) and its own
+    // [num_graphs] slice of rounds/totals/stats, all over the SAME block-diagonal adjacency.
+    const uint8_t* init_state;  // non-zero = vertex does not take part (kept as given in the output)
+    int num_graphs, num_nodes;
+    long prio_stride;
+    const int32_t* active;      // [num_graphs] or null: 0 = leave this graph alone (rounds 0, total 0, state untouched) -
+                                // the "nothing left / no positive weight left" graphs of a residual step (general.hip)
+};
+
+template <bool COLS_LDS>
+__device__ __forceinline__ int nbr_at(const uint16_t* cl, const int32_t* cg, int j, int e0, int n0) {
+    if (COLS_LDS) return cl[j - e0];
+    return cg[j] - n0;
+}
+
+// One residual neighbour test: liveness byte, then the float64 priority compare of the total order
+// (priority desc, index asc).  (A variant on precomputed 16-bit ranks, as in the fused kernel, was
+// measured slower here: the O(N^2) ranking costs more than the cheaper tests save.)
+__device__ __forceinline__ void nbr_test(int u, int v, double pv, const uint8_t* st, const double* pr, bool& lost,
+                                         int& resid) {
+    if (st[u] == 0) {
+        const double pu = pr[u];
+        lost |= (pu > pv) || (pu == pv && u < v);
+        ++resid;
+    }
+}
+
+// FLAG_OR: the "anybody still in?" vote through acc64[3] instead of __syncthreads_count - that one (ockl's workgroup reduction)
+// brings a static LDS allocation with it, and k_big addresses its dynamic LDS from offset 0
+template <int LPV, bool STATS, bool COLS_LDS, int BLOCK, bool FLAG_OR = false>
+__device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int ng, int e0, double* pr, uint8_t* st,
+                                           uint8_t* nw, const uint16_t* cl, unsigned long long* acc64, const int* ro) {
+    constexpr int kVerts = BLOCK / LPV;
+    const int lane = threadIdx.x & 63;
+    const int slot = threadIdx.x / LPV, sub = threadIdx.x % LPV;
+    const int gshift = lane & ~(LPV - 1);
+    const unsigned long long gmask = (LPV == 64) ? ~0ull : ((1ull << LPV) - 1ull);
+    const int passes = (ng + kVerts - 1) / kVerts;
+    unsigned long long p2p = 0, bst = 0;
+    int rounds = 0;
+    int remaining = ng;
+    if (a.init_state) {  // masked start: count the vertices that actually take part
+        if (threadIdx.x == 0) acc64[2] = 0;
+        __syncthreads();
+        int c = 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) c += st[v] == 0;
+        if (c) atomicAdd(&acc64[2], (unsigned long long)c);
+        __syncthreads();
+        remaining = (int)acc64[2];
+        __syncthreads();
+    }
+    while (remaining > 0 && (a.max_rounds <= 0 || rounds < a.max_rounds)) {
+        if (STATS && threadIdx.x == 0) bst += (unsigned long long)remaining;
+        // ---------------- phase A: who wins this round
+        for (int p = 0; p < passes; ++p) {
+            const int v = p * kVerts + slot;
+            const bool live = v < ng && st[v] == 0;
+            bool lost = false;
+            int resid = 0;
+            if (live) {
+                const double pv = pr[v];
+                const int rs = ro[v], re = ro[v + 1];
+                int j = rs + sub;
+                for (; j + 3 * LPV < re; j += 4 * LPV) {  // four independent neighbour chains in flight
+                    const int u0 = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                    const int u1 = nbr_at<COLS_LDS>(cl, a.col_idx, j + LPV, e0, n0);
+                    const int u2 = nbr_at<COLS_LDS>(cl, a.col_idx, j + 2 * LPV, e0, n0);
+                    const int u3 = nbr_at<COLS_LDS>(cl, a.col_idx, j + 3 * LPV, e0, n0);
+                    nbr_test(u0, v, pv, st, pr, lost, resid);
+                    nbr_test(u1, v, pv, st, pr, lost, resid);
+                    nbr_test(u2, v, pv, st, pr, lost, resid);
+                    nbr_test(u3, v, pv, st, pr, lost, resid);
+                }
+                for (; j < re; j += LPV)
+                    nbr_test(nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0), v, pv, st, pr, lost, resid);
+            }
+            if (LPV > 1) {
+                const unsigned long long m = __ballot(lost);
+                lost = ((m >> gshift) & gmask) != 0ull;
+            }
+            if (STATS) {
+#pragma unroll
+                for (int off = 1; off < LPV; off <<= 1) resid += __shfl_xor(resid, off);
+            }
+            if (live && sub == 0) {
+                nw[v] = lost ? 0 : 1;
+                if (STATS) {
+                    p2p += (unsigned long long)resid;
+                    if (a.overhead) a.overhead[n0 + v] += resid + ((!lost && resid > 0) ? 1 : 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (FLAG_OR && threadIdx.x == 0) acc64[3] = 0;  // (every thread has read last round's vote: it decided to enter this round)
+        // ---------------- phase B: winners join, their remaining neighbours are excluded
+        for (int p = 0; p < passes; ++p) {
+            const int v = p * kVerts + slot;
+            if (v < ng && st[v] == 0 && nw[v]) {
+                const int rs = ro[v], re = ro[v + 1];
+                for (int j = rs + sub; j < re; j += LPV) {
+                    const int u = nbr_at<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                    if (st[u] == 0) st[u] = 2;  // same value from every writer: benign
+                }
+            }
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
+            if (st[v] == 0) {
+                if (nw[v]) st[v] = 1; else ++mine;
+            }
+            nw[v] = 0;
+        }
+        if constexpr (FLAG_OR) {
+            if (mine > 0) acc64[3] = 1;  // (same value from every writer)
+            __syncthreads();
+            remaining = acc64[3] != 0 ? 1 : 0;
+        } else {
+            remaining = __syncthreads_count(mine > 0) ? 1 : 0;
+        }
+        if (remaining) {
+            // exact count only matters for bst (stats); otherwise "some remain" is enough
+            if (STATS) {
+                if (threadIdx.x == 0) acc64[2] = 0;
+                __syncthreads();
+                if (mine) atomicAdd(&acc64[2], (unsigned long long)mine);
+                __syncthreads();
+                remaining = (int)acc64[2];
+            }
+        }
+        ++rounds;
+    }
+    if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+    if (STATS) {
+        if (threadIdx.x == 0) { acc64[0] = 0; acc64[1] = 0; }
+        __syncthreads();
+        if (p2p) atomicAdd(&acc64[0], p2p);
+        int members = 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) members += st[v] == 1;
+        if (members) atomicAdd(&acc64[1], (unsigned long long)members);
+        __syncthreads();
+        if (threadIdx.x == 0 && a.stats) {
+            a.stats[2 * g + 0] = (int64_t)acc64[0];
+            a.stats[2 * g + 1] = (int64_t)(bst + acc64[1]);  // bst += len(mwis) (heuristics.py:208)
+        }
+    }
+}
+
+
+}  // namespace dgcn

@@ -45,7 +45,7 @@ def pmc(kind, counter, match):
 tpath = os.path.join(DST, "hbm_traffic.json")
 traffic = json.load(open(tpath)) if os.path.isfile(tpath) else {}
 notes = []
-for kind, match, key in (("er500", "k_big", "big_forward|256x500|l20"), ("mc900", "k_big", "big_forward|mc256x900|l20")):
+for kind, match, key in (("er500", "k_big", "big_solve|256x500|l20"), ("mc900", "k_big", "big_solve|mc256x900|l20")):
     fe, wr = pmc(kind, "FETCH_SIZE", match), pmc(kind, "WRITE_SIZE", match)
     if fe is None or wr is None:
         continue
