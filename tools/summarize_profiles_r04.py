@@ -27,8 +27,13 @@ def keep(name):
                 open(os.path.join(DST, "%s_%s%s" % (TAG, name, tail)), "w").write(lines[-1])
 
 
-for name in ("bench_default", "bench_er500", "bench_mc900", "bench_c2", "bench_c4_l1", "bench_c4_l20", "bench_c5"):
+NAMES = ("bench_default", "bench_er500", "bench_mc900", "bench_c2", "bench_c4_l1", "bench_c4_l20", "bench_c5", "bench_c5_256",
+         "bench_c3_anysize", "bench_layered", "iterative_mc900")
+for name in NAMES:
     keep(name)
+for f in ("iterative_mc900.txt", "iterative_er500.txt", "iterative_c5.txt"):
+    if os.path.isfile(os.path.join(SRC, f)):
+        open(os.path.join(DST, "%s_%s" % (TAG, f)), "w").write(open(os.path.join(SRC, f)).read())
 
 
 def pmc(kind, counter, match):
@@ -59,7 +64,7 @@ for kind, match, key in (("er500", "k_big", "big_solve|256x500|l20"), ("mc900", 
 json.dump(traffic, open(tpath, "w"), indent=1)
 open(os.path.join(DST, "%s_hbm_traffic.txt" % TAG), "w").write("\n".join(notes) + "\n")
 print("\n".join(notes))
-for name in ("bench_default", "bench_er500", "bench_mc900", "bench_c2", "bench_c4_l1", "bench_c4_l20", "bench_c5"):
+for name in NAMES:
     p = os.path.join(DST, "%s_%s.json" % (TAG, name))
     if os.path.isfile(p):
         d = json.loads(open(p).read())
