@@ -36,8 +36,7 @@
 
 namespace dgcn {
 
-constexpr int kBigBlock = 1024;
-constexpr int kBigWaves = kBigBlock / 64;
+constexpr int kBigBlock = 1024;     // one graph per CU: graphs above 512 vertices; 512 threads (two graphs per CU) below
 constexpr int kBigMaxNodes = 976;   // Z1 (128 B per vertex) + a 2 KB staging tile per wave + the row tables in 160 KB; 61 tiles
 constexpr int kBigTilesPerWave = 4;  // 64 tiles over 16 waves: what a wave keeps in registers
 constexpr int kBigMaxLayers = 64;
@@ -128,7 +127,9 @@ __device__ __forceinline__ void big_load_bfrag(const float* W, float (&b)[8][4],
         for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
 }
 
-__global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_big(BigArgs a) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_big(BigArgs a) {
+    constexpr int kWavesB = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
@@ -152,15 +153,15 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     int fault = 0;
 
     // ---- P0: row lengths, row order (counting sort, descending), Z1 of the first aggregation into LDS
-    for (int i = threadIdx.x; i < 576; i += kBigBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
     if (threadIdx.x < 32) reinterpret_cast<float*>(big_lds + zrow)[threadIdx.x] = 0.f;
     __syncthreads();
-    for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
         const unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
         cnt[v] = (unsigned short)min(c, 65535u);
         atomicAdd(&hist[min((int)c, 575)], 1);
     }
-    for (int idx = threadIdx.x; idx < (a.front ? 0 : ng * 8); idx += kBigBlock) {
+    for (int idx = threadIdx.x; idx < (a.front ? 0 : ng * 8); idx += BLOCK) {
         const int v = idx >> 3, c = idx & 7;
         const float4 z = *reinterpret_cast<const float4*>(a.Zin + (size_t)(n0 + v) * 64 + kBH + 4 * c);
         *reinterpret_cast<float4*>(bufB + v * kBH + ((c ^ big_key(v)) << 2)) = z;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     __syncthreads();
     if (threadIdx.x < 576) hist[threadIdx.x] = my_off;
     __syncthreads();
-    for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
         const int pos = atomicAdd(&hist[min((int)cnt[v], 575)], 1);
         perm[pos] = (unsigned short)v;  // (order among equal counts: whatever the atomics took - it decides which rows share a pass, never a sum)
     }
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     // records below then need no global lookups beyond the column ids themselves
     double* dvl = reinterpret_cast<double*>(big_lds + a.lds_stage_off);
     if (a.arow) {
-        for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int d = (int)cnt[v] - 1;
             double x = 0.0;
             if (d < a.table_len) x = a.dinv[d]; else fault |= DGCN_FAULT_DEGREE_RANGE;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     __syncthreads();
     const int s16 = lane >> 2, kq4 = lane & 3;  // aggregation: row slot of the tile, quarter of the row
     // every wave writes the records of its own tiles (read back by the same lanes: no barrier)
-    for (int t = wave; t < tiles; t += kBigWaves) {
+    for (int t = wave; t < tiles; t += kWavesB) {
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);
         const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);
         const int slot = t * 16 + s16;
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
 #define DGCN_BQBF(x, e) __int_as_float(DGCN_BQB(__float_as_int(x), e))
     // the tile of slot k of this wave: t, its trips and records, the wave's next tile's records
 #define DGCN_BTILE_HEAD                                                                                                  \
-        const int t = wave + kBigWaves * k;                                                                            \
-        const int tn = t + kBigWaves;                                                                                  \
+        const int t = wave + kWavesB * k;                                                                            \
+        const int tn = t + kWavesB;                                                                                  \
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);                                                   \
         const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);                                 \
         const bool have_next = k + 1 < kBigTilesPerWave && tn < tiles;                                                 \
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         DGCN_BFIRST_GROUP
 #pragma unroll
         for (int k = 0; k < kBigTilesPerWave; ++k) {
-            if (wave + kBigWaves * k < tiles) {  // (wave-uniform)
+            if (wave + kWavesB * k < tiles) {  // (wave-uniform)
                 DGCN_BTILE_HEAD
                 const int crow = has ? (int)cnt[perm[slot]] : 0;
                 double accd[8];
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         big_load_bfrag(F.W1, bfrag, true);
 #pragma unroll
         for (int k = 0; k < kBigTilesPerWave; ++k) {
-            const int t = wave + kBigWaves * k;
+            const int t = wave + kWavesB * k;
             if (t < tiles) {
                 float4 zo[4];
 #pragma unroll
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         // Z0 of the first aggregation: from the caller's Z (row-major, Z0 | Z1), in the aggregation's layout
 #pragma unroll
         for (int k = 0; k < kBigTilesPerWave; ++k) {
-            const int slot = (wave + kBigWaves * k) * 16 + s16;
+            const int slot = (wave + kWavesB * k) * 16 + s16;
             if (slot < ng) {
                 const float* zr = a.Zin + (size_t)(n0 + (int)perm[slot]) * 64;
                 const float4 yA = *reinterpret_cast<const float4*>(zr + 4 * cfirst), yB = *reinterpret_cast<const float4*>(zr + 4 * csecond);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         DGCN_BFIRST_GROUP
 #pragma unroll
         for (int k = 0; k < kBigTilesPerWave; ++k) {
-            if (wave + kBigWaves * k < tiles) {  // (wave-uniform)
+            if (wave + kWavesB * k < tiles) {  // (wave-uniform)
                 DGCN_BTILE_HEAD
                 float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
 #define DGCN_BTRIP(R, TT)                                                                                                \
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         // so that a lane ends with four consecutive features of one vertex; Z1 -> bufB, Z0 -> registers (aggregation layout)
 #pragma unroll
         for (int k = 0; k < kBigTilesPerWave; ++k) {
-            const int t = wave + kBigWaves * k;
+            const int t = wave + kWavesB * k;
             if (t < tiles) {
                 bf32x4 acc[4];
 #pragma unroll
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     float* zl = bufB;
 #pragma unroll
     for (int k = 0; k < kBigTilesPerWave; ++k) {
-        const int slot = (wave + kBigWaves * k) * 16 + s16;
+        const int slot = (wave + kWavesB * k) * 16 + s16;
         if (slot < ng && kq4 == 0) zl[perm[slot]] = zz1[k];
     }
     if (threadIdx.x == 0) zl[a.max_nodes] = 0.f;  // the neutral record's neighbour
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
     DGCN_BFIRST_GROUP
 #pragma unroll
     for (int k = 0; k < kBigTilesPerWave; ++k) {
-        if (wave + kBigWaves * k < tiles) {
+        if (wave + kWavesB * k < tiles) {
             DGCN_BTILE_HEAD
             float accs = 0.f;
 #define DGCN_BTRIP_TAIL(R, TT)                                                                                           \
@@ -582,20 +583,20 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
         __syncthreads();  // every score of the graph is computed, every walk over z1 done
         const int e0 = a.arow[n0], e1 = a.arow[n0 + ng];
         int bad = 0;
-        for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const double p = pr[v];
             bad |= p != p;
             st[v] = 0;
             nw[v] = 0;
         }
-        for (int v = threadIdx.x; v <= ng; v += kBigBlock) rol[v] = a.arow[n0 + v];
-        for (int base = e0 + (int)threadIdx.x; base < e1; base += kBigBlock * 4) {  // 4 loads in flight per thread
+        for (int v = threadIdx.x; v <= ng; v += BLOCK) rol[v] = a.arow[n0 + v];
+        for (int base = e0 + (int)threadIdx.x; base < e1; base += BLOCK * 4) {  // 4 loads in flight per thread
             int c4[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) c4[i] = (base + i * kBigBlock < e1) ? a.acol[base + i * kBigBlock] : 0;
+            for (int i = 0; i < 4; ++i) c4[i] = (base + i * BLOCK < e1) ? a.acol[base + i * BLOCK] : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (base + i * kBigBlock < e1) cl[base + i * kBigBlock - e0] = (uint16_t)(c4[i] - n0);
+                if (base + i * BLOCK < e1) cl[base + i * BLOCK - e0] = (uint16_t)(c4[i] - n0);
         }
         // (no __syncthreads_or: ockl's workgroup reductions bring static LDS with them, and bufB must stay at LDS offset 0)
         if (threadIdx.x == 0) acc64[3] = 0;
@@ -608,20 +609,20 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
                 if (a.rounds) a.rounds[g] = -1;
                 if (a.totals) a.totals[g] = 0.0;
             }
-            for (int v = threadIdx.x; v < ng; v += kBigBlock) a.state[n0 + v] = 0;
+            for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = 0;
             return;
         }
         LgsArgs la = {};
         la.row_ptr = a.arow;
         la.col_idx = a.acol;
         la.rounds = a.rounds;
-        if (ng <= 256) lgs_rounds<4, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
-        else if (ng <= 512) lgs_rounds<2, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
-        else lgs_rounds<1, false, true, kBigBlock, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        if (4 * ng <= BLOCK) lgs_rounds<4, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        else if (2 * ng <= BLOCK) lgs_rounds<2, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        else lgs_rounds<1, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
         {
             // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots)
             double part = 0.0;
-            for (int v = threadIdx.x; v < ng; v += kBigBlock) {
+            for (int v = threadIdx.x; v < ng; v += BLOCK) {
                 const uint8_t s1 = st[v];
                 if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
                 a.state[n0 + v] = s1;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(kBigBlock) __attribute__((amdgpu_waves_per_eu(4))) 
             __syncthreads();
             if (threadIdx.x < 256) {
                 double acc = red[threadIdx.x];
-                for (int k2 = 256; k2 < kBigBlock; k2 += 256) acc += red[threadIdx.x + k2];
+                for (int k2 = 256; k2 < BLOCK; k2 += 256) acc += red[threadIdx.x + k2];
                 red[threadIdx.x] = acc;
             }
             __syncthreads();
@@ -665,15 +666,27 @@ int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, 
 
 static size_t b256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// threads per workgroup: a wave keeps at most kBigTilesPerWave tiles in registers, so 512 threads reach 512 vertices - and two
+// such workgroups share a CU (the recipe of fused.hip's C3 launch: one's barriers and round trips under the other's work);
+// larger graphs get the CU to themselves.  DGCN_BIG_BLOCK=512|1024 overrides (tuning / tests).
+static int big_block(int max_nodes) {
+    int block = max_nodes <= 16 * kBigTilesPerWave * 8 ? 512 : 1024;
+    if (const char* e = getenv("DGCN_BIG_BLOCK")) {
+        const int want = atoi(e);
+        if (want == 1024 || (want == 512 && max_nodes <= 16 * kBigTilesPerWave * 8)) block = want;
+    }
+    return block;
+}
+
 static int big_rec_cap(const DgcnBatch* b) {
     // fused.hip's bound for block-major records of rows in descending order: entries + 20 N + 192 (+ one cache line)
     return ((b->max_graph_edges + b->max_nodes + 2 + 16 + 15) & ~15) + ((20 * b->max_nodes + 448 + 15) & ~15);
 }
 
-static size_t big_lds_bytes(int max_nodes, int* cnt_off, int* perm_off, int* stage_off, int* tab_off) {
+static size_t big_lds_bytes(int max_nodes, int block, int* cnt_off, int* perm_off, int* stage_off, int* tab_off) {
     size_t off = (size_t)max_nodes * 128 + 128;  // Z1 + the zero row
     *stage_off = (int)off;
-    off += (size_t)kBigWaves * 2048;            // a 16 x 32 float tile per wave (P0: the count histogram)
+    off += (size_t)std::max(block / 64 * 2048, 8192);  // a 16 x 32 float tile per wave (P0: the count histogram, the d^-1/2 array)
     *cnt_off = (int)off;
     off += ((size_t)max_nodes * 2 + 15) & ~(size_t)15;
     *perm_off = (int)off;
@@ -706,6 +719,9 @@ size_t big_workspace(const DgcnBatch* b, const DgcnModel* m) {
     const size_t B = (size_t)std::max(b->num_graphs, 1);
     return 256 + b256(B * (size_t)big_rec_cap(b) * 8);
 }
+
+static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s);
+static int big_block(int max_nodes);
 
 // The forward pass in one launch (constant input features: X == NULL), or - explicit features - layer 0 and the transform
 // of layer 1 by the layer-by-layer kernels exactly as layered_forward runs them, then everything else in one launch.
@@ -751,24 +767,13 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
         a.layers[l - 1].act = L.act;
         a.layers[l - 1].Wnext = l < Lc - 2 ? m->layers_host[l + 1].weights : nullptr;
     }
-    const size_t lds = big_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
-    if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
-    if (lds > 64 * 1024) {
-        static std::atomic<int> reserved[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return fail(DGCN_ERR_LAUNCH, "k_big: cannot reserve %zu bytes of LDS", lds);
-            reserved[dev & 63].store(1, std::memory_order_relaxed);
-        }
+    int block = big_block(a.max_nodes);
+    size_t lds = big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
+    if (block == 512 && lds > 80 * 1024 && !getenv("DGCN_BIG_BLOCK")) {
+        block = 1024;
+        lds = big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
     }
-    {
-        TimedLaunch t("big_forward", s);
-        DGCN_LAUNCH(t, k_big, dim3((unsigned)b->num_graphs), dim3(kBigBlock), lds, s, a);
-        if ((rc = check_launch("k_big"))) return rc;
-    }
-    return DGCN_OK;
+    return big_launch(a, b->num_graphs, lds, block, "big_forward", s);
 }
 
 // bytes of LDS the search at the end of the launch needs (k_lgs's arrays behind z1's), or 0 when a graph's columns do not fit
@@ -803,21 +808,26 @@ static void big_fill_model(BigArgs& a, const DgcnModel* m, float x_const) {
     }
 }
 
-static int big_launch(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
-    if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
+template <int BLOCK>
+static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<int> reserved[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_big: cannot reserve %zu bytes of LDS", lds);
             reserved[dev & 63].store(1, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, k_big, dim3((unsigned)B), dim3(kBigBlock), lds, s, a);
+    DGCN_LAUNCH(t, (k_big<BLOCK>), dim3((unsigned)B), dim3(BLOCK), lds, s, a);
     return check_launch("k_big");
+}
+
+static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s) {
+    if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
+    return block == 512 ? big_launch_b<512>(a, B, lds, family, s) : big_launch_b<1024>(a, B, lds, family, s);
 }
 
 // A1-A10 in one launch for graphs beyond fused.hip's LDS budget: support construction while the records are written, every
@@ -837,9 +847,15 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     a.do_lgs = 1; a.predict_mwis = predict_mwis; a.lgs_cols_lds = 1;
     a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
     big_fill_model(a, m, x_const);
-    size_t lds = big_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
-    lds = std::max(lds, big_lgs_lds(a.max_nodes, b->max_graph_edges));
-    return big_launch(a, b->num_graphs, lds, "big_solve", s);
+    int block = big_block(a.max_nodes);
+    size_t lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                          big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    if (block == 512 && lds > 80 * 1024 && !getenv("DGCN_BIG_BLOCK")) {  // no second workgroup on the CU anyway: all 16 waves for this graph
+        block = 1024;
+        lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                       big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    }
+    return big_launch(a, b->num_graphs, lds, block, "big_solve", s);
 }
 
 }  // namespace dgcn
