@@ -92,3 +92,81 @@ def test_random_calls_through_the_host_solver_match_the_twin(engine):
         assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), (call, layers_n)
     for _, hs in solvers.values():
         hs.close()
+
+
+def _star(n, rng):
+    """A hub with n - 1 leaves plus a few random edges between leaves: one row as long as the graph has vertices."""
+    import scipy.sparse as sp
+    rows, cols = [0] * (n - 1), list(range(1, n))
+    for _ in range(n // 3):
+        u, v = int(rng.integers(1, n)), int(rng.integers(1, n))
+        if u != v:
+            rows.append(u); cols.append(v)
+    a = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    a = ((a + a.T) > 0).astype(np.float64).tocsr()
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def test_random_shapes_down_the_any_size_path_match_the_twin(engine):
+    """dgcn_solve_batch forced down the any-size path (csrc/general.hip, big.hip) on random shapes: k_big with 512 and 1 024
+    threads (tile boundaries at 15 / 16 / 17 vertices, empty and one-vertex graphs, isolated vertices, hubs as long as their
+    graph, graphs up to 976 vertices), explicit input features (the layer-by-layer front), wide and shallow models (the
+    layer-by-layer kernels), graphs above 976 vertices - against the CPU twin, bit for bit."""
+    from distgcn_amd import _lib, datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    lib = _lib.load()
+    initial = int(lib.dgcn_get_general())
+    cases = int(os.environ.get("DGCN_FUZZ_CASES", "16"))
+    rng = np.random.default_rng(4040)
+    try:
+        lib.dgcn_set_general(1)
+        for case in range(cases):
+            layers_n = int(rng.choice([1, 2, 3, 4, 7, 20]))
+            hidden = int(rng.choice([32, 32, 32, 16, 48]))
+            fsize = int(rng.choice([1, 1, 2]))
+            layers = datagen.random_model(layers_n, hidden, feature_size=fsize, bias=bool(rng.integers(2)), seed=300 + case)
+            ps, cs, ws = [], [], []
+            big = int(rng.choice([0, 0, 600, 976, 977, 1300]))
+            for _ in range(int(rng.integers(1, 24))):
+                n = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 64, 129, 255, 256, 257, 333, 512]))
+                if n == 0:
+                    ps.append(np.zeros(1, np.int32)); cs.append(np.zeros(0, np.int32)); ws.append(np.zeros(0))
+                    continue
+                if n >= 15 and rng.random() < 0.2:
+                    ip, ix = _star(n, rng)
+                    ps.append(ip); cs.append(ix); ws.append(rng.random(n))
+                    continue
+                g = datagen.er_batch(1, n, min(0.9, float(rng.choice([2.0, 8.0, 30.0])) / max(n, 2)), first_index=int(rng.integers(1 << 20)))
+                ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
+            if big:
+                g = datagen.er_batch(1, big, 6.0 / big, first_index=7000 + case)
+                ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
+            hb = HostBatch.from_csr_lists(ps, cs, ws)
+            if hb.num_nodes == 0:
+                continue
+            model = DeviceModel(layers, engine.device)
+            db = engine.upload(hb)
+            assert engine.solve_path(db, model) == 2
+            X = None
+            if rng.random() < 0.3:  # explicit features: layer 0 and the transform of layer 1 by the layer-by-layer kernels
+                import torch
+                X = torch.from_numpy(rng.random((hb.num_nodes, fsize)).astype(np.float32)).to(engine.device)
+            out = engine.solve_buffers(db, True)
+            engine.solve_fused(db, model, out=out, want_scores=True, X=X)
+            got = engine.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
+            assert got["status"] == 0, (case, got["status"])
+            want = ctwin.solve(hb, layers) if X is None else None
+            if X is not None:
+                lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+                sc = ctwin.forward(lap, layers, hb.num_nodes, X=X.cpu().numpy())
+                r = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, sc[:, 0].astype(np.float64) * hb.weights, sum_weights=hb.weights)
+                want = {"scores": sc, "state": r["state"], "rounds": r["rounds"], "totals": r["totals"]}
+            tag = (case, layers_n, hidden, fsize, X is not None, hb.num_graphs, hb.max_nodes)
+            assert np.array_equal(got["scores"].ravel().view(np.uint32), np.asarray(want["scores"], np.float32).ravel().view(np.uint32)), tag
+            assert np.array_equal(got["state"], want["state"]) and np.array_equal(got["rounds"], want["rounds"]), tag
+            assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), tag
+    finally:
+        lib.dgcn_set_general(initial)
