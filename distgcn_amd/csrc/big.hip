@@ -38,7 +38,7 @@ namespace dgcn {
 
 constexpr int kBigBlock = 1024;     // one graph per CU: graphs above 512 vertices; 512 threads (two graphs per CU) below
 constexpr int kBigMaxNodes = 976;   // Z1 (128 B per vertex) + a 2 KB staging tile per wave + the row tables in 160 KB; 61 tiles
-constexpr int kBigTilesPerWave = 4;  // 64 tiles over 16 waves: what a wave keeps in registers
+constexpr int kBigTilesPerWave = 4;  // at most: 64 tiles over 16 waves (k_big<BLOCK, TILES>: 2 where half of that is enough)
 constexpr int kBigMaxLayers = 64;
 constexpr int kBH = 32;
 
@@ -127,9 +127,12 @@ __device__ __forceinline__ void big_load_bfrag(const float* W, float (&b)[8][4],
         for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
 }
 
-template <int BLOCK>
+// TILES: sixteen-row tiles a wave keeps in registers (4: up to 64 BLOCK / 64 tiles; 2: half of that, and the freed registers hold
+// a second group of records in flight: the walk asks for its records TWO groups of four trips ahead)
+template <int BLOCK, int TILES>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_big(BigArgs a) {
     constexpr int kWavesB = BLOCK / 64;
+    constexpr int DEPTH = TILES == 2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
@@ -272,41 +275,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const int mr = lane & 15, mq = lane >> 4;  // transform: row of the tile, k quarter
     float* stg = reinterpret_cast<float*>(big_lds + a.lds_stage_off) + wave * 512;  // [16 rows][32], 16-byte chunks XOR-swizzled by row & 7
     float bfrag[8][4];
-    float pz[kBigTilesPerWave][8];
+    float pz[TILES][8];
     const unsigned voff = (unsigned)lane * 8u;
-    BigRec4 A = {};
+    BigRec4 A = {}, Bq = {}, Cq = {};  // the group being walked, the next one(s) in flight
+    int pf_k = 0, pf_j = 0;
+    (void)Cq;
 #define DGCN_BQB(x, e) __builtin_amdgcn_update_dpp(0, (int)(x), (e) * 0x55, 0xf, 0xf, true)
 #define DGCN_BQBF(x, e) __int_as_float(DGCN_BQB(__float_as_int(x), e))
     // the tile of slot k of this wave: t, its trips and records, the wave's next tile's records
 #define DGCN_BTILE_HEAD                                                                                                  \
-        const int t = wave + kWavesB * k;                                                                            \
-        const int tn = t + kWavesB;                                                                                  \
+        const int t = wave + kWavesB * k;                                                                              \
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);                                                   \
-        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);                                 \
-        const bool have_next = k + 1 < kBigTilesPerWave && tn < tiles;                                                 \
-        const unsigned base_n = have_next ? (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[tn]) : 0u;            \
         const int slot = t * 16 + s16;                                                                                 \
         const bool has = slot < ng;                                                                                    \
-        const char* bp = reinterpret_cast<const char*>(rec + base) + voff;                                             \
         (void)has;
-    // walks the tile's records; every trip needs a record from global memory (L2 / MALL: 500 .. 2 000 cycles), so they are
-    // requested a GROUP of four trips ahead - the next group of this tile, or the first group of the wave's next tile
+    // The records of a wave's tiles are one stream of GROUPS (four trips each, tile after tile); every trip needs a record
+    // from global memory (L2 / MALL: 500 .. 2 000 cycles), so the stream is requested DEPTH groups ahead of the walk - a
+    // cursor (pf_k, pf_j) names the next group to ask for, whichever tile it belongs to.  (With one group in flight per wave
+    // a CU has 32 KB of records under way: 3.3 TB/s chip-wide at MALL latency - what ER(500, 0.1) measured; TILES = 2 frees
+    // the registers for a second one.)
+#define DGCN_BPREFETCH(X)                                                                                                \
+        {                                                                                                              \
+            const int pt_ = wave + kWavesB * pf_k;                                                                     \
+            if (pf_k < TILES && pt_ < tiles) { /* (wave-uniform) */                                                    \
+                const int ptr_ = __builtin_amdgcn_readfirstlane(ttrips[pt_]);                                          \
+                const unsigned pb_ = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[pt_]);                        \
+                big_load_group(X, reinterpret_cast<const char*>(rec + pb_) + (size_t)pf_j * 2048 + voff); /* (its last trips may lie past the tile: never walked) */ \
+                pf_j += 1;                                                                                             \
+                if (pf_j * 4 >= ptr_) { pf_j = 0; pf_k += 1; }                                                         \
+            }                                                                                                          \
+        }
 #define DGCN_BWALK(TRIP)                                                                                                 \
         for (int g0 = 0; g0 < trips; g0 += 4) { /* (trips is wave-uniform: scalar branches) */                         \
-            BigRec4 Bn = A;                                                                                            \
-            if (g0 + 4 < trips) big_load_group(Bn, bp + (size_t)(g0 + 4) * 512); /* (its last trips may lie past the tile: never walked) */ \
-            else if (have_next) big_load_group(Bn, reinterpret_cast<const char*>(rec + base_n) + voff);                \
+            if constexpr (DEPTH == 2) { DGCN_BPREFETCH(Cq) } else { DGCN_BPREFETCH(Bq) }                               \
             TRIP(A.r0, g0)                                                                                             \
             if (g0 + 1 < trips) TRIP(A.r1, g0 + 1)                                                                     \
             if (g0 + 2 < trips) TRIP(A.r2, g0 + 2)                                                                     \
             if (g0 + 3 < trips) TRIP(A.r3, g0 + 3)                                                                     \
-            A = Bn;                                                                                                    \
+            A = Bq;                                                                                                    \
+            if constexpr (DEPTH == 2) Bq = Cq;                                                                         \
         }
 #define DGCN_BFIRST_GROUP                                                                                                \
-        if (wave < tiles) {                                                                                            \
-            const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[wave]);                         \
-            big_load_group(A, reinterpret_cast<const char*>(rec + base0) + voff);                                      \
-        }
+        pf_k = 0;                                                                                                      \
+        pf_j = 0;                                                                                                      \
+        DGCN_BPREFETCH(A)                                                                                              \
+        if constexpr (DEPTH == 2) { DGCN_BPREFETCH(Bq) }
     // aggregation layout (row s16, chunks cfirst / csecond: oA, oB) -> the MFMA's operand layout (lane 16 q + r: H[r][4 s + q])
 #define DGCN_BSTAGE_TO_OPERAND(OA, OB)                                                                                   \
         *reinterpret_cast<float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2)) = OA;                                \
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < kBigTilesPerWave; ++k)
+    for (int k = 0; k < TILES; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pz[k][j] = 0.f;
 
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         }
         DGCN_BFIRST_GROUP
 #pragma unroll
-        for (int k = 0; k < kBigTilesPerWave; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             if (wave + kWavesB * k < tiles) {  // (wave-uniform)
                 DGCN_BTILE_HEAD
                 const int crow = has ? (int)cnt[perm[slot]] : 0;
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         // its output register i of lane (q, r) holds row 4 i + q: the weight fragments are loaded accordingly, fused.hip)
         big_load_bfrag(F.W1, bfrag, true);
 #pragma unroll
-        for (int k = 0; k < kBigTilesPerWave; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             const int t = wave + kWavesB * k;
             if (t < tiles) {
                 float4 zo[4];
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     } else {
         // Z0 of the first aggregation: from the caller's Z (row-major, Z0 | Z1), in the aggregation's layout
 #pragma unroll
-        for (int k = 0; k < kBigTilesPerWave; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             const int slot = (wave + kWavesB * k) * 16 + s16;
             if (slot < ng) {
                 const float* zr = a.Zin + (size_t)(n0 + (int)perm[slot]) * 64;
@@ -429,16 +442,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             }
         }
     }
-    float zz0[kBigTilesPerWave], zz1[kBigTilesPerWave];  // the last layer's (width 1) z0 / z1 of this lane's row
+    float zz0[TILES], zz1[TILES];  // the last layer's (width 1) z0 / z1 of this lane's row
 #pragma unroll
-    for (int k = 0; k < kBigTilesPerWave; ++k) zz0[k] = zz1[k] = 0.f;
+    for (int k = 0; k < TILES; ++k) zz0[k] = zz1[k] = 0.f;
     for (int i = 0; i < a.num_hidden; ++i) {
         const BigLayer& L = a.layers[i];
         const bool last = i == a.num_hidden - 1;
         // -------- aggregation: H' = act(Z0 + L.Z1 + b), 4 lanes x 2 float4 per row, 16 rows per pass
         DGCN_BFIRST_GROUP
 #pragma unroll
-        for (int k = 0; k < kBigTilesPerWave; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             if (wave + kWavesB * k < tiles) {  // (wave-uniform)
                 DGCN_BTILE_HEAD
                 float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA;
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         // -------- transform of the next layer: Z0 | Z1 = H'.[W0 | W1], v_mfma_f32_16x16x4_f32, operands swapped (D^T = W^T.H^T)
         // so that a lane ends with four consecutive features of one vertex; Z1 -> bufB, Z0 -> registers (aggregation layout)
 #pragma unroll
-        for (int k = 0; k < kBigTilesPerWave; ++k) {
+        for (int k = 0; k < TILES; ++k) {
             const int t = wave + kWavesB * k;
             if (t < tiles) {
                 bf32x4 acc[4];
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     __syncthreads();  // every gather of the last hidden aggregation has read Z1
     float* zl = bufB;
 #pragma unroll
-    for (int k = 0; k < kBigTilesPerWave; ++k) {
+    for (int k = 0; k < TILES; ++k) {
         const int slot = (wave + kWavesB * k) * 16 + s16;
         if (slot < ng && kq4 == 0) zl[perm[slot]] = zz1[k];
     }
@@ -540,7 +553,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     __syncthreads();
     DGCN_BFIRST_GROUP
 #pragma unroll
-    for (int k = 0; k < kBigTilesPerWave; ++k) {
+    for (int k = 0; k < TILES; ++k) {
         if (wave + kWavesB * k < tiles) {
             DGCN_BTILE_HEAD
             float accs = 0.f;
@@ -647,6 +660,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #undef DGCN_BSTAGE_TO_AGG
 #undef DGCN_BSTAGE_TO_OPERAND
 #undef DGCN_BFIRST_GROUP
+#undef DGCN_BPREFETCH
 #undef DGCN_BWALK
 #undef DGCN_BTILE_HEAD
 #undef DGCN_BQBF
@@ -808,26 +822,29 @@ static void big_fill_model(BigArgs& a, const DgcnModel* m, float x_const) {
     }
 }
 
-template <int BLOCK>
+template <int BLOCK, int TILES>
 static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<int> reserved[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big<BLOCK, TILES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_big: cannot reserve %zu bytes of LDS", lds);
             reserved[dev & 63].store(1, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_big<BLOCK>), dim3((unsigned)B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_big<BLOCK, TILES>), dim3((unsigned)B), dim3(BLOCK), lds, s, a);
     return check_launch("k_big");
 }
 
 static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s) {
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
-    return block == 512 ? big_launch_b<512>(a, B, lds, family, s) : big_launch_b<1024>(a, B, lds, family, s);
+    // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
+    const bool two = a.max_nodes <= 16 * 2 * (block / 64) && !(getenv("DGCN_BIG_TILES") && atoi(getenv("DGCN_BIG_TILES")) == 4);
+    if (block == 512) return two ? big_launch_b<512, 2>(a, B, lds, family, s) : big_launch_b<512, 4>(a, B, lds, family, s);
+    return two ? big_launch_b<1024, 2>(a, B, lds, family, s) : big_launch_b<1024, 4>(a, B, lds, family, s);
 }
 
 // A1-A10 in one launch for graphs beyond fused.hip's LDS budget: support construction while the records are written, every
