@@ -534,12 +534,18 @@ def spmm_probe(args, wl, traffic_db):
         Yt = torch.empty(h.num_nodes, C, device=dev)
         return (h, d, lap, Zt, Yt)
 
+    plain = [False]  # True: K4 alone (gcn/layers.py:206: Y = S.Z, no Z0 / bias / activation) - exactly SURVEY 8d's B_spmm
+
     def launch(st):
         h, d, lap, Zt, Yt = st
-        eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=d.graph_ptr, num_graphs=h.num_graphs,
-                 max_nodes=h.max_nodes, Y0=Zt, ldy0=2 * C, act="leaky_relu", out=Yt)
+        if plain[0]:
+            eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=d.graph_ptr, num_graphs=h.num_graphs, max_nodes=h.max_nodes, out=Yt)
+        else:
+            eng.spmm(lap, Zt[:, C:], C, ldz=2 * C, graph_ptr=d.graph_ptr, num_graphs=h.num_graphs,
+                     max_nodes=h.max_nodes, Y0=Zt, ldy0=2 * C, act="leaky_relu", out=Yt)
 
-    def timed(sets, reps):
+    def timed(sets, reps, plain_spmm=False):
+        plain[0] = plain_spmm
         for st in sets:
             launch(st)
         torch.cuda.synchronize()
@@ -578,6 +584,15 @@ def spmm_probe(args, wl, traffic_db):
         bigh = datagen.er_batch(8 * args.graphs, args.nodes, args.p, first_index=3_000_000)
         big = make_set(bigh, eng.upload(bigh))
         avg3 = timed([big], 6)
+        avg3p = timed([big], 6, plain_spmm=True)
+        avg2p = timed(sets, 4, plain_spmm=True)
+        # K4 ALONE (no '+ Z0', bias, activation): the kernel and the byte count of SURVEY 8d's B_spmm, nothing else in the launch
+        line["plain_spmm"] = {
+            "kernel": "k_spmm_lds C=%d, Y = S.Z only (gcn/layers.py:206)" % C, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "one_launch_%d_graphs" % bigh.num_graphs: {"avg_launch_us": avg3p * 1e6, "achieved": bytes_of(bigh, False) / avg3p / 1e9,
+                                                      "frac": bytes_of(bigh, False) / avg3p / 1e9 / HBM_PEAK_GBS},
+            "rotating_%d_graph_launches" % args.graphs: {"avg_launch_us": avg2p * 1e6, "achieved": nbp_avg / avg2p / 1e9,
+                                                        "frac": nbp_avg / avg2p / 1e9 / HBM_PEAK_GBS}}
         line["out_of_cache_one_launch"] = {
             "working_set": "one launch over %d graphs: %.0f MB algorithmic per launch (> 256 MiB Infinity Cache)"
                            % (bigh.num_graphs, bytes_of(bigh, True) / 1e6),

@@ -680,15 +680,25 @@ int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, 
 
 static size_t b256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// tuning / A-B switches of this file, read from the environment ONCE per process (never per launch: getenv next to the
+// packer's worker threads is a data race in glibc): DGCN_BIG=0 (no k_big: layer by layer), DGCN_BIG_SOLVE=0 (supports and
+// greedy search in launches of their own), DGCN_BIG_BLOCK=512|1024, DGCN_BIG_TILES=4
+static int env_once(const char* name) {  // the value, or -1 when the variable is not set
+    const char* e = getenv(name);
+    return e ? atoi(e) : -1;
+}
+static int big_env_enabled() { static const int v = env_once("DGCN_BIG"); return v; }
+static int big_env_solve() { static const int v = env_once("DGCN_BIG_SOLVE"); return v; }
+static int big_env_block() { static const int v = env_once("DGCN_BIG_BLOCK"); return v; }
+static int big_env_tiles() { static const int v = env_once("DGCN_BIG_TILES"); return v; }
+
 // threads per workgroup: a wave keeps at most kBigTilesPerWave tiles in registers, so 512 threads reach 512 vertices - and two
 // such workgroups share a CU (the recipe of fused.hip's C3 launch: one's barriers and round trips under the other's work);
 // larger graphs get the CU to themselves.  DGCN_BIG_BLOCK=512|1024 overrides (tuning / tests).
 static int big_block(int max_nodes) {
     int block = max_nodes <= 16 * kBigTilesPerWave * 8 ? 512 : 1024;
-    if (const char* e = getenv("DGCN_BIG_BLOCK")) {
-        const int want = atoi(e);
-        if (want == 1024 || (want == 512 && max_nodes <= 16 * kBigTilesPerWave * 8)) block = want;
-    }
+    const int want = big_env_block();
+    if (want == 1024 || (want == 512 && max_nodes <= 16 * kBigTilesPerWave * 8)) block = want;
     return block;
 }
 
@@ -712,7 +722,7 @@ static size_t big_lds_bytes(int max_nodes, int block, int* cnt_off, int* perm_of
 
 // 1 = a deep [I, L] stack F -> 32 -> .. -> 32 -> 1 on graphs of at most 976 vertices: the shape k_big takes
 int big_takes(const DgcnBatch* b, const DgcnModel* m) {
-    if (const char* e = getenv("DGCN_BIG")) if (atoi(e) == 0) return 0;
+    if (big_env_enabled() == 0) return 0;
     if (!b || !m || !m->layers_host || m->num_supports != 2 || m->num_layers < 3 || m->num_layers - 2 > kBigMaxLayers) return 0;
     if (b->max_nodes <= 0 || b->max_nodes > kBigMaxNodes) return 0;
     const int Lc = m->num_layers;
@@ -783,7 +793,7 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
     }
     int block = big_block(a.max_nodes);
     size_t lds = big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
-    if (block == 512 && lds > 80 * 1024 && !getenv("DGCN_BIG_BLOCK")) {
+    if (block == 512 && lds > 80 * 1024 && big_env_block() < 0) {
         block = 1024;
         lds = big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off);
     }
@@ -801,7 +811,7 @@ static size_t big_lgs_lds(int max_nodes, int max_graph_edges) {
 // 1 = dgcn_solve_batch's whole path in ONE launch: adjacency in, set out (constant input features, k_big's shapes, the graphs'
 // column ids fit the LDS next to the search's state)
 int big_solve_takes(const DgcnBatch* b, const DgcnModel* m, const float* X) {
-    if (const char* e = getenv("DGCN_BIG_SOLVE")) if (atoi(e) == 0) return 0;
+    if (big_env_solve() == 0) return 0;
     return !X && big_takes(b, m) && m->layers_host[0].in_dim <= 64 && big_lgs_lds((std::max(b->max_nodes, 16) + 15) & ~15, b->max_graph_edges) != 0;
 }
 
@@ -842,7 +852,7 @@ static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipSt
 static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s) {
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
     // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
-    const bool two = a.max_nodes <= 16 * 2 * (block / 64) && !(getenv("DGCN_BIG_TILES") && atoi(getenv("DGCN_BIG_TILES")) == 4);
+    const bool two = a.max_nodes <= 16 * 2 * (block / 64) && big_env_tiles() != 4;
     if (block == 512) return two ? big_launch_b<512, 2>(a, B, lds, family, s) : big_launch_b<512, 4>(a, B, lds, family, s);
     return two ? big_launch_b<1024, 2>(a, B, lds, family, s) : big_launch_b<1024, 4>(a, B, lds, family, s);
 }
@@ -867,7 +877,7 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     int block = big_block(a.max_nodes);
     size_t lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
                           big_lgs_lds(a.max_nodes, b->max_graph_edges));
-    if (block == 512 && lds > 80 * 1024 && !getenv("DGCN_BIG_BLOCK")) {  // no second workgroup on the CU anyway: all 16 waves for this graph
+    if (block == 512 && lds > 80 * 1024 && big_env_block() < 0) {  // no second workgroup on the CU anyway: all 16 waves for this graph
         block = 1024;
         lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
                        big_lgs_lds(a.max_nodes, b->max_graph_edges));
