@@ -39,6 +39,7 @@
 #include <random>
 
 #include "common.h"
+#include "tile_ops.h"
 #include <type_traits>
 
 namespace dgcn {
@@ -47,9 +48,6 @@ constexpr int kMaxFusedLayers = 64;
 constexpr int kFusedBlock = 512;      // threads per workgroup when two or more graphs share a CU
 constexpr int kFusedBlockBig = 1024;  // ... when one graph's image takes more than half the LDS (it has the CU to itself)
 constexpr int kFusedMaxNodes = 512;
-constexpr int kHid = 32;  // hidden width of the LDS image
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct FusedLayer {
     const float* W;     // [cin][2*cout]
@@ -93,6 +91,8 @@ struct FusedArgs {
     int32_t beam;          // greedy_mode 2: number of candidates
     int32_t options;       // DGCN_RESIDUAL_* bits
     int32_t* progress;     // += 1 per graph that decided at least one vertex in this launch
+    unsigned long long* tail_word;  // residual-graph variant, or null: atomicMax(tail_tag | undecided vertices of an active graph) -
+    unsigned long long tail_tag;    // what tail.hip reads to see whether EVERY graph of the batch is small enough for it
     const int32_t* order;  // null, or the graph of workgroup i (largest graphs first: k_graph_rank)
     const int32_t* cedge;          // compact batch (common.h CompactHook), or null: first entry of every graph,
     const unsigned short* cdeg;    // entries per row,
@@ -127,21 +127,6 @@ struct FusedArgs {
 #define STAMP(a, g, i, t0) do { } while (0)
 #endif
 
-__device__ __forceinline__ int swz(int row, int col) {  // float index of H[row][col] in a swizzled buffer
-    return row * kHid + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));
-}
-// (Tried and dropped: rows of bufA / bufB in a permuted slot order - slot p = feature 4 * (p % 8) + p / 8 - that makes the
-// eight features 4s + kq of an MFMA lane two ds_read_b128 instead of eight ds_read_b32.  The reads got 2 us cheaper per
-// launch, but every wave then fetches its weight fragments with a stride of four columns and the doubled L1 traffic of
-// that cost 30 us.)
-
-// bufB swizzle key of a row (xor-ed into the chunk index, inside the 64-byte half)
-__device__ __forceinline__ int keyB(int row) { return (row >> 1) & 3; }
-__device__ __forceinline__ unsigned short enc_word(int u) { return (unsigned short)((u << 7) | (keyB(u) << 4)); }
-__device__ __forceinline__ int swzB(int row, int col) {
-    return row * kHid + ((((col >> 2) ^ keyB(row)) << 2) | (col & 3));
-}
-
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
 __device__ __forceinline__ void set_prio(int p) {  // s_setprio takes an immediate
     if (p <= 0) __builtin_amdgcn_s_setprio(0);
@@ -171,117 +156,6 @@ __device__ __forceinline__ void first_layer_transform(const FusedArgs& a, const 
             }
         }
     }
-}
-
-// ---- hidden layer 32 -> (32 | 32): fp32 MFMA 16x16x4, one 16-row tile per wave at a time.
-// A: lane (r = l & 15, kq = l >> 4) holds H[row0 + r][4s + kq]; B: W[4s + kq][ct*16 + r];
-// C/D: col = l & 15, row = 4 * (l >> 4) + reg.  Z0 overwrites the tile's own rows of bufA.
-// The B fragments of a layer are fetched one layer ahead (load_bfrag) so that their global-memory
-// latency hides under the previous layer's gather phase.
-// `f64map`: fragments for hidden_transform_f64 - the f64 MFMA returns rows 4 * reg + (lane >> 4) where the f32 one
-// returns 4 * (lane >> 4) + reg, so lane r feeds column 4 * (r & 3) + (r >> 2) of the tile and the accumulator again
-// holds four CONSECUTIVE features per lane.
-__device__ __forceinline__ void load_bfrag(const float* W, float (&b)[8][4], int skip = 0, bool f64map = false) {
-    const int lane = threadIdx.x & 63;
-#ifdef DGCN_DIAG
-    if (skip) {  // experiment: no weight fetch
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) b[s][ct] = 0.01f * (float)(s + ct);
-        return;
-    }
-#endif
-    (void)skip;
-    const int r0 = lane & 15, kq = lane >> 4;
-    const int r = f64map ? 4 * (r0 & 3) + (r0 >> 2) : r0;
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
-}
-
-// (Tried and dropped: sending the 1..8 rows a vertex count leaves over - ER N = 200: 12 full tiles + 8 rows, which puts a
-// 4th tile on one SIMD - through the VALU of the last wave instead of a 13th MFMA tile (lane = output column, 32-term
-// fmaf chain per row).  Same bits, but 252 us instead of 219 us per C3 launch: the wave's 32 column weights spill at
-// the 128-VGPR budget and its serial rows become the phase's critical path.)
-template <int BLOCK>
-__device__ __forceinline__ void hidden_transform(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, kq = lane >> 4;
-    constexpr int kWaves = BLOCK / 64;
-    const int tiles = (ng + 15) >> 4;
-    for (int t = wave; t < tiles; t += kWaves) {
-        const int row = t * 16 + r;
-        float av[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
-        f32x4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // Operands swapped (D^T = W^T . H^T): the accumulator then holds, per lane, 4 CONSECUTIVE
-        // features (4*kq + reg of column tile ct) of ONE vertex (row0 + r) = one 16-byte chunk,
-        // stored with a single ds_write_b128.  Each element is still the k-ordered fmaf chain.
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc[ct], 0, 0, 0);
-        if (row < ng) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int chunk = (ct & 1) * 4 + kq;
-                const float4 o = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
-                if (ct < 2) *reinterpret_cast<float4*>(bufA + row * kHid + ((chunk ^ (row & 7)) << 2)) = o;
-                else *reinterpret_cast<float4*>(bufB + row * kHid + ((chunk ^ keyB(row)) << 2)) = o;
-            }
-        }
-    }
-}
-
-// The same product with every chain carried in double and rounded once (layer index 1): v_mfma_f64_16x16x4_f64, which
-// on gfx950 is exactly fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, c)))) per element (tools/micro/mfma_f64.hip: 0 of
-// 5.1 M outputs differ from the CPU's chain, cancellation included).  Fragments from load_bfrag(.., f64map = true).
-// Column tiles in pairs: 16 accumulator registers live at a time.
-using f64x4 = __attribute__((ext_vector_type(4))) double;
-template <int BLOCK>
-__device__ __forceinline__ void hidden_transform_f64(const float (&b)[8][4], int ng, float* bufA, float* bufB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, kq = lane >> 4;
-    constexpr int kWaves = BLOCK / 64;
-    const int tiles = (ng + 15) >> 4;
-    for (int t = wave; t < tiles; t += kWaves) {
-        const int row = t * 16 + r;
-        float av[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) av[s] = bufA[row * kHid + (((s ^ (row & 7)) << 2) | kq)];
-#pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                // (opaque copies: otherwise the 32 conversions of b are hoisted out of the tile loop and their 64 registers
-                // push the row-block state of the aggregation into scratch memory)
-                float b0 = b[s][2 * cp], b1 = b[s][2 * cp + 1], a0 = av[s];
-                asm volatile("" : "+v"(b0), "+v"(b1), "+v"(a0));
-                const double ad = (double)a0;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b0, ad, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b1, ad, acc1, 0, 0, 0);
-            }
-            if (row < ng) {
-                const float4 o0 = make_float4((float)acc0[0], (float)acc0[1], (float)acc0[2], (float)acc0[3]);
-                const float4 o1 = make_float4((float)acc1[0], (float)acc1[1], (float)acc1[2], (float)acc1[3]);
-                float* dst = cp == 0 ? bufA : bufB;
-                const int key = cp == 0 ? (row & 7) : keyB(row);
-                *reinterpret_cast<float4*>(dst + row * kHid + ((kq ^ key) << 2)) = o0;
-                *reinterpret_cast<float4*>(dst + row * kHid + (((4 + kq) ^ key) << 2)) = o1;
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ float4 fma4(float a, float4 z, float4 acc) {
-    acc.x = fmaf(a, z.x, acc.x); acc.y = fmaf(a, z.y, acc.y); acc.z = fmaf(a, z.z, acc.z); acc.w = fmaf(a, z.w, acc.w);
-    return acc;
 }
 
 // Z1 row chunk at ABSOLUTE LDS byte address `addr` (bufB starts at LDS offset 0).
@@ -1220,6 +1094,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         }
         __syncthreads();
         const int ng_full = ng;
+        if (a.tail_word && threadIdx.x == 0) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)na);
         ng = na;
         vid = tv0 < na ? (int)orig[tv0] : 0;
         was_alive = tv0 < na;  // from here on: "thread tv0 stands for a vertex of the image"
@@ -2513,7 +2388,16 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
 int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
                      float x_const, int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t greedy_mode,
                      int32_t max_rounds, int32_t beam, int32_t options, float* scores, uint8_t* state, int32_t* rounds,
-                     double* totals, int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s);
+                     double* totals, int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s,
+                     unsigned long long* tail_word, unsigned long long tail_tag);
+
+// tail.hip: the rest of a graph's search in one launch once at most 64 of its vertices are undecided
+int tail_takes(const DgcnModel* m, const float* X, int32_t options);
+int tail_finish(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const,
+                int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds,
+                int32_t beam, int32_t options, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress,
+                int32_t* status, hipStream_t s, const unsigned long long* tail_word, unsigned long long tail_tag);
+constexpr size_t kTailWordBytes = 512;  // what dgcn_solve_workspace adds behind a path's own scratch: the tail's word, 256-byte aligned
 
 }  // namespace dgcn
 
@@ -2536,10 +2420,15 @@ extern "C" int dgcn_solve_path(const DgcnBatch* b, const DgcnModel* m) {
     return general_takes(b, m) ? 2 : 0;
 }
 
-extern "C" size_t dgcn_solve_workspace(const DgcnBatch* b, const DgcnModel* m) {
-    if (!b || !m) return 0;
+// a path's own scratch; the residual entry point keeps one more word behind it (DGCN_RESIDUAL_FINISH_SMALL)
+static size_t solve_scratch(const DgcnBatch* b, const DgcnModel* m) {
     if (m->layers_host && dgcn_solve_path(b, m) == 2) return general_workspace(b, m);
     return fused_scratch(b, m, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
+}
+
+extern "C" size_t dgcn_solve_workspace(const DgcnBatch* b, const DgcnModel* m) {
+    if (!b || !m) return 0;
+    return solve_scratch(b, m) + kTailWordBytes;
 }
 
 extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len,
@@ -2614,10 +2503,33 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     if (feature_mode == 1 && (!weights || X))
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: feature_mode 1 derives X from the weights");
     if (b->num_graphs <= 0) return DGCN_OK;
+    // DGCN_RESIDUAL_FINISH_SMALL: after this call's step, graphs with at most 64 undecided vertices run the REST of their
+    // search inside one more launch (tail.hip); graphs it does not take go on step by step, call by call
+    // The tail pays only when it is the LAST thing a search launches (its one launch runs ~40 steps of every graph side by side;
+    // started while other graphs still step call by call it would hold the stream up every time a graph joins it): the step
+    // kernels report the largest number of undecided vertices among the active graphs - atomicMax into a word behind the
+    // path's scratch, tagged with this call's number so that nothing has to be cleared - and k_tail leaves at once while
+    // that is above 64.
+    bool finish = (options & DGCN_RESIDUAL_FINISH_SMALL) && tail_takes(m, X, options);
+    const size_t scratch = solve_scratch(b, m);
+    unsigned long long* tail_word = nullptr;
+    unsigned long long tail_tag = 0;
+    if (finish && workspace && workspace_bytes >= scratch + kTailWordBytes) {
+        static std::atomic<unsigned long long> calls{1};
+        tail_word = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(workspace) + scratch + 255) & ~(uintptr_t)255);
+        tail_tag = calls.fetch_add(1, std::memory_order_relaxed) << 32;
+    } else {
+        finish = false;
+    }
+    auto tail = [&](int rc) {
+        if (rc != DGCN_OK || !finish) return rc;
+        return tail_finish(b, m, dinv_table, table_len, x_const, feature_mode, weights, predict_mwis, greedy_mode, max_rounds, beam,
+                           options, scores, state, rounds, totals, progress, status, (hipStream_t)stream, tail_word, tail_tag);
+    };
     if (dgcn_solve_path(b, m) != 1)
-        return general_residual(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, greedy_mode, max_rounds,
-                                beam, options, scores, state, rounds, totals, progress, status, workspace, workspace_bytes,
-                                (hipStream_t)stream);
+        return tail(general_residual(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, greedy_mode, max_rounds,
+                                     beam, options, scores, state, rounds, totals, progress, status, workspace, workspace_bytes,
+                                     (hipStream_t)stream, tail_word, tail_tag));
     FusedArgs args = {};
     args.row_ptr = b->row_ptr;
     args.col_idx = b->col_idx;
@@ -2642,11 +2554,13 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     args.totals = totals;
     args.progress = progress;
     args.status = status;
+    args.tail_word = tail_word;
+    args.tail_tag = tail_tag;
     size_t lds = 0;
     bool gvals = false;
     // (with given scores no layer runs: nothing for a second workgroup to do)
     int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream,
                            (options & DGCN_RESIDUAL_SCORES_GIVEN) != 0);
     if (rc) return rc;
-    return fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals);
+    return tail(fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals));
 }

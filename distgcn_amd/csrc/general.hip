@@ -84,6 +84,8 @@ struct ResArgs {
     double* totals;
     int32_t* status;
     int32_t* progress;
+    unsigned long long* tail_word;  // or null: atomicMax(tail_tag | undecided vertices of an active graph), read by tail.hip
+    unsigned long long tail_tag;
 };
 
 // exclusive scan of two ints over the workgroup; returns the block totals through ta / tb.  `sh` = 2 * (BLOCK / 64) + 2 ints.
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kResBlock) void k_res_count(ResArgs a) {
         a.active[g] = 1;
         a.wmax[g] = mx;
         if (a.progress) atomicAdd(a.progress, 1);
+        if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)cnt);
     }
     if (fault) atomicOr(a.status, fault);
 }
@@ -567,7 +570,8 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
 int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
                      float x_const, int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t greedy_mode,
                      int32_t max_rounds, int32_t beam, int32_t options, float* scores, uint8_t* state, int32_t* rounds,
-                     double* totals, int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                     double* totals, int32_t* progress, int32_t* status, void* workspace, size_t workspace_bytes, hipStream_t s,
+                     unsigned long long* tail_word, unsigned long long tail_tag) {
     if (!general_takes(b, m))
         return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_residual_batch: model / graph shape outside both the fused kernel and the layer-by-layer path");
     const size_t n = (size_t)b->num_nodes, e = (size_t)b->num_edges, B = (size_t)b->num_graphs;
@@ -608,6 +612,7 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         a.inst_totals = inst_totals;
     }
     a.rounds = rounds; a.totals = totals; a.status = status; a.progress = progress;
+    a.tail_word = tail_word; a.tail_tag = tail_tag;
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_residual_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);

@@ -426,17 +426,20 @@ class Engine:
                 "scores": None if scores is None else scores[:n], "stats": None, "overhead": None}
 
     GREEDY_ROUNDS, GREEDY_CENTRAL, GREEDY_ROLLOUT = 0, 1, 2
-    SCORES_GIVEN, COMPLETE_BY_PRIORITY = 1, 2  # DGCN_RESIDUAL_* option bits
+    SCORES_GIVEN, COMPLETE_BY_PRIORITY, FINISH_SMALL = 1, 2, 4  # DGCN_RESIDUAL_* option bits
 
     def solve_residual(self, b: DeviceBatch, model: DeviceModel, state, predict: str = "mwis", greedy: int = 0,
                        max_rounds: int = 0, beam: int = 16, X=None, x_const=None, weight_features: bool = False,
                        want_scores: bool = False, max_steps: Optional[int] = None, out=None, options: int = 0,
-                       scores=None):
+                       scores=None, finish_small: Optional[bool] = None):
         """Iterative solvers on the device (dgcn_solve_residual_batch): repeat one launch per step on the
         residual graphs until no graph makes progress.  ``state`` (uint8 [num_nodes], 0 = undecided) is
         updated in place.  greedy = GREEDY_ROUNDS with max_rounds=1 is solve_mwis_dit, GREEDY_CENTRAL is
         solve_mwis_cit, GREEDY_ROLLOUT is solve_mwis_rollout (mwis_gdpg_call.py:278-318, 343-384, 596-659)
-        for every graph of the batch at once.  -> {"state", "steps", "status", "scores" (last step)}"""
+        for every graph of the batch at once.  -> {"state", "steps", "status", "scores" (last step)}
+        ``finish_small`` (default: on for a search run to its end, off when ``max_steps`` asks for single steps): a graph
+        with at most 64 undecided vertices runs the rest of its search inside the call that finds it so
+        (DGCN_RESIDUAL_FINISH_SMALL, csrc/tail.hip); same final states, fewer calls - ``steps`` counts calls."""
         t = self.torch
         n, B = b.host.num_nodes, b.host.num_graphs
         if x_const is None:
@@ -448,6 +451,8 @@ class Engine:
             if scores is None:
                 raise ValueError("options & SCORES_GIVEN needs scores")
             out = dict(out, scores=scores)
+        if finish_small is None:
+            finish_small = max_steps is None
         p = lambda x: x.data_ptr() if x is not None else None
         need = int(self.lib.dgcn_solve_workspace(C.byref(b.c), C.byref(model.c)))
         ws = self._workspace(need)
@@ -457,17 +462,22 @@ class Engine:
         # step that decides nothing leaves the state as it is, so every later step of the group decides nothing either
         # (and costs next to nothing: a graph with nothing left returns at once) - one host round trip per group, not per step.
         group = 4
+        issued = 0
         done = n == 0
         while not done and steps < limit:
             k = min(group, limit - steps)
             progress = t.zeros(k, dtype=t.int32, device=self.device)
             for i in range(k):
+                # (the tail's launch leaves at once while a graph of the batch is still large: asked for with every second
+                # call, it costs a search ~3 us per step and starts at most one step late)
+                opts = options | (self.FINISH_SMALL if finish_small and ((issued + i) & 1) else 0)
                 _lib.check(self.lib.dgcn_solve_residual_batch(
                     C.byref(b.c), C.byref(model.c), tab.data_ptr(), int(tab.numel()), p(X), x_const,
                     1 if weight_features else 0, p(b.weights), 1 if predict == "mwis" else 0, int(greedy),
-                    int(max_rounds), int(beam), int(options), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
+                    int(max_rounds), int(beam), int(opts), p(out["scores"]), state.data_ptr(), p(out["rounds"]), p(out["totals"]),
                     progress.data_ptr() + 4 * i, out["status"].data_ptr(), ws.data_ptr(), need, self._stream()),
                     "dgcn_solve_residual_batch")
+            issued += k
             if max_steps == 1:  # a caller that asks for exactly one step does not need to know whether it decided anything
                 steps = 1
                 break

@@ -350,6 +350,14 @@ int dgcn_solve_batch(const DgcnBatch* batch, const DgcnModel* model, const doubl
                                               caller): no forward pass here - solve_mwis_rollout00 / rollout0 */
 #define DGCN_RESIDUAL_COMPLETE_BY_PRIORITY 2 /* rollout completions ordered by priority instead of weight
                                               (greedy_search(adj_ro, gw_ro)): solve_mwis_rollout0 / rollout1 */
+#define DGCN_RESIDUAL_FINISH_SMALL 4         /* after this call's step, a graph with at most 64 undecided vertices runs ALL its
+                                              remaining steps inside the same call (csrc/tail.hip: one more launch, the
+                                              residual graph held on the chip); graphs with more go on step by step, call
+                                              by call.  Final states as without the bit; rounds[g] / totals[g] then are the
+                                              sums over every step the call ran for graph g (rounds: + 1 per step of the
+                                              tail), scores of a graph finished this way read 0 (as after the last step).
+                                              Taken for [I, L] stacks F -> 32 -> ... -> 32 -> 1 of >= 3 layers with X == NULL
+                                              and without DGCN_RESIDUAL_SCORES_GIVEN; ignored otherwise */
 int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, const double* dinv_table,
                               int32_t table_len, const float* X, float x_const, int32_t feature_mode,
                               const double* weights, int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds,

@@ -162,7 +162,7 @@ def test_residual_steps_equal_the_fused_kernel(engine, golden, general_switch, w
         general_switch(path)
         s0 = torch.from_numpy(init.copy()).to(engine.device)
         res = engine.solve_residual(db, dm, s0, predict=predict, greedy=greedy, max_rounds=max_rounds, beam=6,
-                                    weight_features=predict != "mwis", options=options,
+                                    weight_features=predict != "mwis", options=options, finish_small=False,
                                     scores=None if full_scores is None else full_scores.clone())
         assert res["steps"] == steps - 1 and np.array_equal(s0.cpu().numpy(), st), (which, path, res["steps"], steps)
 
