@@ -385,8 +385,12 @@ class RolloutWorkload:
         self.eng.timing(on)
 
     def kernel_times(self):
-        ms, n = self.eng.timing_read("fused_residual")
-        return {"fused_residual": (ms, n)} if n else {}
+        out = {}
+        for fam in ("fused_residual", "tail_finish"):
+            ms, n = self.eng.timing_read(fam)
+            if n:
+                out[fam] = (ms, n)
+        return out
 
     def residual_bytes(self):
         """SURVEY 8d's layer-by-layer bytes of every launch of one search, from the residual graphs' actual sizes:
@@ -395,7 +399,7 @@ class RolloutWorkload:
         rows = np.repeat(np.arange(hb.num_nodes), np.diff(hb.row_ptr))
         gid = np.repeat(np.arange(hb.num_graphs), np.diff(hb.graph_ptr))
         state = t.zeros(hb.num_nodes, dtype=t.uint8, device=self.dev)
-        total, launches = 0.0, 0
+        per_step, launches = [], 0
         while True:
             alive = state.cpu().numpy() == 0
             if not alive.any():
@@ -404,14 +408,13 @@ class RolloutWorkload:
             nnz_res = int((alive[rows] & alive[hb.col_idx]).sum())
             graphs_res = int(np.unique(gid[alive]).size)
             csr = (nnz_res + n_res) * 8 + (n_res + graphs_res) * 4
-            for lyr in self.layers:
-                total += csr + 2 * 4 * lyr["weights"][0].shape[1] * n_res
+            per_step.append(sum(csr + 2 * 4 * lyr["weights"][0].shape[1] * n_res for lyr in self.layers))
             eng.solve_residual(self.db, self.model, state, greedy=eng.GREEDY_ROLLOUT, max_rounds=1, beam=self.args.beam,
                                out=self.out, max_steps=1)
             launches += 1
             if launches > hb.max_nodes + 2:
                 break
-        return total, launches
+        return per_step, launches
 
 
 def c5_cpu_baseline(wl, budget_s):
@@ -905,20 +908,30 @@ def main(argv=None, workload_factory=None):
     fam_ms = wl.kernel_times()
     if isinstance(wl, RolloutWorkload):
         ms, n = fam_ms.get("fused_residual", (0.0, 0))
-        algo, launches = wl.residual_bytes() if rank == 0 else (0.0, 1)
-        # the timed milliseconds belong to the PRODUCTIVE launches (the replay's count): the host loop also issues a few
-        # launches behind the end of a search (groups of up to 32 between progress read-backs) that find nothing left and
-        # return at once - counting them would understate the launch time and overstate the rate
-        productive = max(min(n, launches * max(args.steps, 1)), 1)
+        per_step, search_steps = wl.residual_bytes() if rank == 0 else ([0.0], 1)
+        # A search of `search_steps` solver steps (the untimed replay's count) is `calls` calls of dgcn_solve_residual_batch:
+        # one step each, and - once every graph has at most 64 undecided vertices - the rest inside ONE launch of the tail
+        # kernel (csrc/tail.hip).  The timed milliseconds of k_fused belong to its PRODUCTIVE launches: the host loop also
+        # issues a few behind the end of a search (groups of up to 32 between progress read-backs) that find nothing left and
+        # return at once - counting them would understate the launch time and overstate the rate.
+        calls = max(min(wl.launches, search_steps), 1)
+        productive = max(min(n, calls * max(args.steps, 1)), 1)
         avg_s = ms / productive * 1e-3
-        ach = (algo / max(launches, 1)) / avg_s / 1e9 if avg_s > 0 else None
+        algo = float(sum(per_step[:calls]))
+        ach = (algo / calls) / avg_s / 1e9 if avg_s > 0 else None
+        tms, tn = fam_ms.get("tail_finish", (0.0, 0))
         roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_search": launches,
-                    "empty_launches_per_search": n / max(args.steps, 1) - launches,
-                    "algorithmic_bytes_per_launch": algo / max(launches, 1),
-                    "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's launches"}
-        kernel_us = {"fused_residual": {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)}}
+                    "traffic": None, "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
+                    "empty_launches_per_search": n / max(args.steps, 1) - calls,
+                    "algorithmic_bytes_per_launch": algo / calls,
+                    "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's k_fused launches",
+                    "tail": {"kernel": "k_tail (the last steps of every graph in one launch, from <= 64 undecided vertices on)",
+                             "steps_inside": search_steps - calls, "ms_per_search": tms / max(args.steps, 1),
+                             "launches_per_search": tn / max(args.steps, 1),
+                             "algorithmic_bytes": float(sum(per_step[calls:]))}}
+        kernel_us = {"fused_residual": {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)},
+                     "tail_finish": {"ms_per_step": tms / max(args.steps, 1), "launches_per_step": tn / max(args.steps, 1)}}
         traffic_db = {}
     else:
         roofline, kernel_us, traffic_db = roofline_objects(args, wl, fam_ms)
@@ -983,7 +996,7 @@ def main(argv=None, workload_factory=None):
         if world == 1 and args.cpu_seconds > 0 and isinstance(wl, RolloutWorkload):
             out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on ER N=%d p=%g" % (args.beam, args.nodes, args.p)
             out["config"]["workload"] = ("C5: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per step of the search, "
-                                         "~%d launches per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
+                                         "~%d calls per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
             out["cpu_baseline"] = c5_cpu_baseline(wl, args.cpu_seconds)
         elif world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(hb, wl.layers, args.cpu_seconds)
