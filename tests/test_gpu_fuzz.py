@@ -170,3 +170,63 @@ def test_random_shapes_down_the_any_size_path_match_the_twin(engine):
             assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), tag
     finally:
         lib.dgcn_set_general(initial)
+
+
+def test_random_searches_with_and_without_the_tail(engine):
+    """Iterative solvers on random batches (ragged sizes round the tail's 64-vertex limit, empty / one-vertex / edgeless graphs,
+    stars, zero and missing weights, random starts), random model depth / bias / beam / solver variant, on the fused residual
+    kernel and forced down the any-size path: the search with DGCN_RESIDUAL_FINISH_SMALL must leave the state bytes of the
+    step-by-step search."""
+    import torch
+    from distgcn_amd import _lib, datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    lib = _lib.load()
+    initial = int(lib.dgcn_get_general())
+    cases = int(os.environ.get("DGCN_FUZZ_CASES", "16"))
+    rng = np.random.default_rng(6464)
+    try:
+        for case in range(cases):
+            layers = datagen.random_model(int(rng.choice([3, 4, 6, 20])), 32, feature_size=int(rng.choice([1, 1, 3])),
+                                          bias=bool(rng.integers(2)), seed=500 + case)
+            ps, cs, ws = [], [], []
+            for _ in range(int(rng.integers(1, 10))):
+                n = int(rng.choice([0, 1, 2, 16, 40, 63, 64, 65, 66, 100, 130, 200]))
+                if n == 0:
+                    ps.append(np.zeros(1, np.int32)); cs.append(np.zeros(0, np.int32)); ws.append(np.zeros(0))
+                    continue
+                if n >= 16 and rng.random() < 0.2:
+                    ip, ix = _star(n, rng)
+                    ps.append(ip); cs.append(ix); ws.append(rng.random(n))
+                    continue
+                g = datagen.er_batch(1, n, min(0.9, float(rng.choice([0.0, 2.0, 6.0, 20.0])) / max(n, 2)), first_index=int(rng.integers(1 << 20)))
+                w = g.weights.copy()
+                if rng.random() < 0.3:
+                    w[rng.random(n) < 0.3] = 0.0
+                ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(w)
+            hb = HostBatch.from_csr_lists(ps, cs, ws)
+            if hb.num_nodes == 0:
+                continue
+            model = DeviceModel(layers, engine.device)
+            db = engine.upload(hb)
+            greedy, max_rounds = [(engine.GREEDY_ROUNDS, 1), (engine.GREEDY_ROUNDS, 0), (engine.GREEDY_ROUNDS, 2), (engine.GREEDY_CENTRAL, 1),
+                                  (engine.GREEDY_ROLLOUT, 1)][int(rng.integers(5))]
+            options = engine.COMPLETE_BY_PRIORITY if rng.random() < 0.3 else 0
+            predict = "mwis" if rng.random() < 0.7 else "mis"
+            beam = int(rng.choice([1, 3, 16, 64]))
+            init = np.where(rng.random(hb.num_nodes) < float(rng.choice([0.0, 0.2, 0.6])), rng.integers(1, 3, hb.num_nodes), 0).astype(np.uint8)
+            got = {}
+            for path in (-1, 1):
+                lib.dgcn_set_general(path)
+                for finish in (False, True):
+                    s0 = torch.from_numpy(init.copy()).to(engine.device)
+                    res = engine.solve_residual(db, model, s0, predict=predict, greedy=greedy, max_rounds=max_rounds, beam=beam,
+                                                weight_features=predict != "mwis", options=options, finish_small=finish)
+                    engine.check_status(res["status"])
+                    got[(path, finish)] = s0.cpu().numpy().copy()
+            ref = got[(-1, False)]
+            for key, st in got.items():
+                assert np.array_equal(st, ref), (case, key, len(layers), hb.num_graphs, hb.max_nodes, greedy, max_rounds, options, predict, beam,
+                                                 int((st != ref).sum()))
+    finally:
+        lib.dgcn_set_general(initial)
