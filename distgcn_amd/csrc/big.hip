@@ -589,28 +589,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         double* pr = reinterpret_cast<double*>(big_lds + big_lgs_base(a.max_nodes));
         double* red = pr + a.max_nodes;
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 1024);
-        int* rol = reinterpret_cast<int*>(acc64 + 4);
-        uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
-        uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
-        uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
+        // The search on bit masks (a workgroup has a thread per vertex here: ng <= BLOCK).  A live vertex wins a round iff no
+        // live neighbour is AHEAD of it in the order (priority desc, index asc); and whoever wins is ahead of all its live
+        // neighbours, so a vertex is excluded iff one of the vertices ahead of it won.  Both tests need one mask per vertex
+        // only - its neighbours that are ahead of it, a bit per vertex of the graph - built with ONE walk over the adjacency;
+        // a round is then two AND-OR sweeps over ceil(ng / 64) words against the live / winners words of the graph and two
+        // barriers, whatever the degrees.  Same synchronous rounds, hence the same sets and round counts, as lgs_rounds.h
+        // (ER(500, 0.1): 45 -> 9 us of the launch; the walk per round over 16-bit columns in LDS was what the phase cost).
+        unsigned long long* liveA = acc64 + 4;   // [16] live vertices, a word per wave (ping)
+        unsigned long long* liveB = liveA + 16;  // [16] (pong)
+        unsigned long long* wonm = liveB + 16;   // [16] this round's winners
+        uint8_t* st = reinterpret_cast<uint8_t*>(wonm + 16);
+        unsigned long long* am = reinterpret_cast<unsigned long long*>(st + ((a.max_nodes + 15) & ~15));  // [ng][W64] ahead masks
         __syncthreads();  // every score of the graph is computed, every walk over z1 done
-        const int e0 = a.arow[n0], e1 = a.arow[n0 + ng];
+        const int W64 = (ng + 63) >> 6;
+        const int tv = threadIdx.x;
         int bad = 0;
-        for (int v = threadIdx.x; v < ng; v += BLOCK) {
-            const double p = pr[v];
-            bad |= p != p;
-            st[v] = 0;
-            nw[v] = 0;
+        if (tv < ng) {
+            const double p = pr[tv];
+            bad = p != p;
+            st[tv] = 0;
         }
-        for (int v = threadIdx.x; v <= ng; v += BLOCK) rol[v] = a.arow[n0 + v];
-        for (int base = e0 + (int)threadIdx.x; base < e1; base += BLOCK * 4) {  // 4 loads in flight per thread
-            int c4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c4[i] = (base + i * BLOCK < e1) ? a.acol[base + i * BLOCK] : 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (base + i * BLOCK < e1) cl[base + i * BLOCK - e0] = (uint16_t)(c4[i] - n0);
-        }
+        for (int i = threadIdx.x; i < ng * W64; i += BLOCK) am[i] = 0ull;
         // (no __syncthreads_or: ockl's workgroup reductions bring static LDS with them, and bufB must stay at LDS offset 0)
         if (threadIdx.x == 0) acc64[3] = 0;
         __syncthreads();
@@ -625,13 +625,79 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = 0;
             return;
         }
-        LgsArgs la = {};
-        la.row_ptr = a.arow;
-        la.col_idx = a.acol;
-        la.rounds = a.rounds;
-        if (4 * ng <= BLOCK) lgs_rounds<4, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
-        else if (2 * ng <= BLOCK) lgs_rounds<2, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
-        else lgs_rounds<1, false, true, BLOCK, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+        {
+            // the walk: as many lanes per vertex as the workgroup affords (<= 8), sixteen neighbours in flight per lane
+            int lsh = 0;
+            while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
+            const int lpv = 1 << lsh;
+            const int v = (int)threadIdx.x >> lsh, sub = (int)threadIdx.x & (lpv - 1);
+            if (v < ng) {
+                const double pv = pr[v];
+                const int rs = a.arow[n0 + v], re = a.arow[n0 + v + 1];
+                unsigned* row = reinterpret_cast<unsigned*>(am + (size_t)v * W64);
+                constexpr int kFly = 16;  // column loads in flight per lane (L2 round trips are what this walk costs: 25 entries a lane at ER(500, 0.1))
+                for (int j = rs + sub; j < re; j += kFly * lpv) {
+                    int u4[kFly];
+#pragma unroll
+                    for (int i = 0; i < kFly; ++i) u4[i] = (j + i * lpv < re) ? a.acol[j + i * lpv] - n0 : -1;
+#pragma unroll
+                    for (int i = 0; i < kFly; ++i) {
+                        const int u = u4[i];
+                        if ((unsigned)u < (unsigned)ng) {  // (columns outside the graph: reported by the image build)
+                            const double pu = pr[u];
+                            if ((pu > pv) || (pu == pv && u < v)) atomicOr(row + (u >> 5), 1u << (u & 31));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        unsigned long long aw[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) aw[w] = (tv < ng && w < W64) ? am[(size_t)tv * W64 + w] : 0ull;
+        bool my = tv < ng;
+        {
+            const unsigned long long m0 = __ballot(my);
+            if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) liveA[threadIdx.x >> 6] = m0;
+        }
+        int rounds = 0;
+        unsigned long long* lcur = liveA;
+        unsigned long long* lnext = liveB;
+        for (;;) {
+            __syncthreads();  // this round's live words are written
+            unsigned long long any = 0ull, t = 0ull;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                if (w < W64) {
+                    const unsigned long long lw = lcur[w];
+                    any |= lw;
+                    t |= aw[w] & lw;
+                }
+            }
+            if (any == 0ull) break;
+            ++rounds;
+            const bool won = my && t == 0ull;
+            {
+                const unsigned long long wm = __ballot(won);
+                if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) wonm[threadIdx.x >> 6] = wm;
+            }
+            __syncthreads();
+            unsigned long long k2 = 0ull;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+                if (w < W64) k2 |= aw[w] & wonm[w];
+            const bool killed = my && !won && k2 != 0ull;
+            if (won) st[tv] = 1;
+            else if (killed) st[tv] = 2;
+            my = my && !won && !killed;
+            {
+                const unsigned long long m1 = __ballot(my);
+                if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) lnext[threadIdx.x >> 6] = m1;
+            }
+            unsigned long long* sw = lcur; lcur = lnext; lnext = sw;
+        }
+        if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+        __syncthreads();  // every state byte is written
         {
             // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots)
             double part = 0.0;
@@ -802,9 +868,10 @@ int big_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, cons
 
 // bytes of LDS the search at the end of the launch needs (k_lgs's arrays behind z1's), or 0 when a graph's columns do not fit
 static size_t big_lgs_lds(int max_nodes, int max_graph_edges) {
+    (void)max_graph_edges;  // (the search works on a mask per vertex - a bit per vertex of the graph -, not on the column lists)
     const size_t pad = (size_t)((max_nodes + 15) & ~15);
-    const size_t need = big_lgs_base(max_nodes) + (size_t)max_nodes * 8 + 1024 * 8 + 32 + (size_t)((max_nodes + 1 + 3) & ~3) * 4 + 2 * pad +
-                        (size_t)std::max(max_graph_edges, 0) * 2 + 16;
+    const size_t w64 = (size_t)(max_nodes + 63) / 64;
+    const size_t need = big_lgs_base(max_nodes) + (size_t)max_nodes * 8 + 1024 * 8 + (4 + 3 * 16) * 8 + pad + (size_t)max_nodes * w64 * 8 + 16;
     return need <= 160 * 1024 ? need : 0;
 }
 

@@ -167,12 +167,13 @@ def test_residual_steps_equal_the_fused_kernel(engine, golden, general_switch, w
         assert res["steps"] == steps - 1 and np.array_equal(s0.cpu().numpy(), st), (which, path, res["steps"], steps)
 
 
-BIG = [(600, 0.01), (500, 0.1), (900, 0.02), (1500, 0.004)]
+BIG = [(600, 0.01), (500, 0.1), (900, 0.02), (1500, 0.004), (700, 0.15), (976, 0.05)]
 
 
 @pytest.mark.parametrize("n,p", BIG)
 def test_big_graphs_plain_solve_vs_twin(engine, n, p):
-    """Graphs the fused kernel cannot hold: ER(500, 0.1) (25 000 entries), 600, 900 and 1 500 vertices - one call of
+    """Graphs the fused kernel cannot hold: ER(500, 0.1) (25 000 entries), 600, 900 and 1 500 vertices, dense graphs whose
+    column lists alone exceed the LDS (ER(700, 0.15): 73 000 entries; k_big's largest, 976 vertices at 47 000) - one call of
     dgcn_solve_batch, scores / sets / rounds equal to the twin bit for bit, through the agent API and the host solver."""
     from distgcn_amd import datagen
     from distgcn_amd.engine import DeviceModel
