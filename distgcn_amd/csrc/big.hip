@@ -589,13 +589,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         double* pr = reinterpret_cast<double*>(big_lds + big_lgs_base(a.max_nodes));
         double* red = pr + a.max_nodes;
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 1024);
-        // The search on bit masks (a workgroup has a thread per vertex here: ng <= BLOCK).  A live vertex wins a round iff no
-        // live neighbour is AHEAD of it in the order (priority desc, index asc); and whoever wins is ahead of all its live
-        // neighbours, so a vertex is excluded iff one of the vertices ahead of it won.  Both tests need one mask per vertex
-        // only - its neighbours that are ahead of it, a bit per vertex of the graph - built with ONE walk over the adjacency;
-        // a round is then two AND-OR sweeps over ceil(ng / 64) words against the live / winners words of the graph and two
-        // barriers, whatever the degrees.  Same synchronous rounds, hence the same sets and round counts, as lgs_rounds.h
-        // (ER(500, 0.1): 45 -> 9 us of the launch; the walk per round over 16-bit columns in LDS was what the phase cost).
+        // The search on bit masks (lgs_rounds.h: lgs_mask_build / lgs_mask_rounds; a workgroup has a thread per vertex here,
+        // ng <= BLOCK): ER(500, 0.1) 412 -> 397 us per launch against the rounds that walked 16-bit column lists in LDS.
         unsigned long long* liveA = acc64 + 4;   // [16] live vertices, a word per wave (ping)
         unsigned long long* liveB = liveA + 16;  // [16] (pong)
         unsigned long long* wonm = liveB + 16;   // [16] this round's winners
@@ -610,7 +605,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             bad = p != p;
             st[tv] = 0;
         }
-        for (int i = threadIdx.x; i < ng * W64; i += BLOCK) am[i] = 0ull;
         // (no __syncthreads_or: ockl's workgroup reductions bring static LDS with them, and bufB must stay at LDS offset 0)
         if (threadIdx.x == 0) acc64[3] = 0;
         __syncthreads();
@@ -625,79 +619,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = 0;
             return;
         }
-        {
-            // the walk: as many lanes per vertex as the workgroup affords (<= 8), sixteen neighbours in flight per lane
-            int lsh = 0;
-            while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
-            const int lpv = 1 << lsh;
-            const int v = (int)threadIdx.x >> lsh, sub = (int)threadIdx.x & (lpv - 1);
-            if (v < ng) {
-                const double pv = pr[v];
-                const int rs = a.arow[n0 + v], re = a.arow[n0 + v + 1];
-                unsigned* row = reinterpret_cast<unsigned*>(am + (size_t)v * W64);
-                constexpr int kFly = 16;  // column loads in flight per lane (L2 round trips are what this walk costs: 25 entries a lane at ER(500, 0.1))
-                for (int j = rs + sub; j < re; j += kFly * lpv) {
-                    int u4[kFly];
-#pragma unroll
-                    for (int i = 0; i < kFly; ++i) u4[i] = (j + i * lpv < re) ? a.acol[j + i * lpv] - n0 : -1;
-#pragma unroll
-                    for (int i = 0; i < kFly; ++i) {
-                        const int u = u4[i];
-                        if ((unsigned)u < (unsigned)ng) {  // (columns outside the graph: reported by the image build)
-                            const double pu = pr[u];
-                            if ((pu > pv) || (pu == pv && u < v)) atomicOr(row + (u >> 5), 1u << (u & 31));
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        unsigned long long aw[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) aw[w] = (tv < ng && w < W64) ? am[(size_t)tv * W64 + w] : 0ull;
-        bool my = tv < ng;
-        {
-            const unsigned long long m0 = __ballot(my);
-            if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) liveA[threadIdx.x >> 6] = m0;
-        }
-        int rounds = 0;
-        unsigned long long* lcur = liveA;
-        unsigned long long* lnext = liveB;
-        for (;;) {
-            __syncthreads();  // this round's live words are written
-            unsigned long long any = 0ull, t = 0ull;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                if (w < W64) {
-                    const unsigned long long lw = lcur[w];
-                    any |= lw;
-                    t |= aw[w] & lw;
-                }
-            }
-            if (any == 0ull) break;
-            ++rounds;
-            const bool won = my && t == 0ull;
-            {
-                const unsigned long long wm = __ballot(won);
-                if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) wonm[threadIdx.x >> 6] = wm;
-            }
-            __syncthreads();
-            unsigned long long k2 = 0ull;
-#pragma unroll
-            for (int w = 0; w < 16; ++w)
-                if (w < W64) k2 |= aw[w] & wonm[w];
-            const bool killed = my && !won && k2 != 0ull;
-            if (won) st[tv] = 1;
-            else if (killed) st[tv] = 2;
-            my = my && !won && !killed;
-            {
-                const unsigned long long m1 = __ballot(my);
-                if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) < 16) lnext[threadIdx.x >> 6] = m1;
-            }
-            unsigned long long* sw = lcur; lcur = lnext; lnext = sw;
-        }
+        lgs_mask_build<BLOCK>(a.arow, a.acol, n0, ng, pr, am, W64);
+        const int rounds = lgs_mask_rounds<BLOCK>(tv, tv < ng, am, W64, liveA, liveB, wonm, st, 0);
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
-        __syncthreads();  // every state byte is written
         {
             // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots)
             double part = 0.0;

@@ -171,5 +171,102 @@ __device__ __forceinline__ void lgs_rounds(const LgsArgs& a, int g, int n0, int 
     }
 }
 
+// ---- the same search on bit masks (graphs with a thread per vertex: ng <= BLOCK <= 1024) --------------------------------
+// A live vertex wins a round iff no live neighbour is AHEAD of it in the order (priority desc, index asc); and whoever wins
+// is ahead of all its live neighbours, so a vertex is excluded iff one of the vertices ahead of it won.  Both tests need one
+// mask per vertex only - the neighbours ahead of it, a bit per vertex of the graph - built with ONE walk over the adjacency
+// (lgs_mask_build); a round is two AND-OR sweeps over ceil(ng / 64) words against the graph's live / winners words and two
+// barriers, whatever the degrees (lgs_mask_rounds).  Same synchronous rounds - same sets, same round counts - as lgs_rounds.
+constexpr int kLgsMaskWords = 16;  // 1 024 vertices
+
+// am[ng][W64] (zeroed here) <- the neighbours ahead of each vertex.  pr: priorities in LDS.  Barriers inside; the masks are
+// complete when it returns.
+template <int BLOCK>
+__device__ __forceinline__ void lgs_mask_build(const int32_t* row_ptr, const int32_t* col_idx, int n0, int ng, const double* pr,
+                                               unsigned long long* am, int W64) {
+    for (int i = threadIdx.x; i < ng * W64; i += BLOCK) am[i] = 0ull;
+    __syncthreads();
+    // as many lanes per vertex as the workgroup affords (<= 8), sixteen neighbours in flight per lane (L2 round trips are
+    // what this walk costs)
+    int lsh = 0;
+    while (lsh < 3 && (ng << (lsh + 1)) <= BLOCK) ++lsh;
+    const int lpv = 1 << lsh;
+    const int v = (int)threadIdx.x >> lsh, sub = (int)threadIdx.x & (lpv - 1);
+    if (v < ng) {
+        const double pv = pr[v];
+        const int rs = row_ptr[n0 + v], re = row_ptr[n0 + v + 1];
+        unsigned* row = reinterpret_cast<unsigned*>(am + (size_t)v * W64);
+        constexpr int kFly = 16;
+        for (int j = rs + sub; j < re; j += kFly * lpv) {
+            int uu[kFly];
+#pragma unroll
+            for (int i = 0; i < kFly; ++i) uu[i] = (j + i * lpv < re) ? col_idx[j + i * lpv] - n0 : -1;
+#pragma unroll
+            for (int i = 0; i < kFly; ++i) {
+                const int u = uu[i];
+                if ((unsigned)u < (unsigned)ng) {  // (columns outside the graph are reported where the batch is validated)
+                    const double pu = pr[u];
+                    if ((pu > pv) || (pu == pv && u < v)) atomicOr(row + (u >> 5), 1u << (u & 31));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The rounds.  Thread tv stands for vertex tv; `my`: it takes part (tv < ng and not masked out); st[tv] is set to 1 / 2 when
+// it joins / is excluded.  live / wonm: [kLgsMaskWords] words each (a word per wave).  Returns the number of rounds; every
+// state byte is visible to the workgroup when it returns.
+template <int BLOCK>
+__device__ __forceinline__ int lgs_mask_rounds(int tv, bool my, const unsigned long long* am, int W64, unsigned long long* liveA,
+                                               unsigned long long* liveB, unsigned long long* wonm, uint8_t* st, int max_rounds) {
+    unsigned long long aw[kLgsMaskWords];
+#pragma unroll
+    for (int w = 0; w < kLgsMaskWords; ++w) aw[w] = (my && w < W64) ? am[(size_t)tv * W64 + w] : 0ull;
+    const int wave = threadIdx.x >> 6;
+    const bool lead = (threadIdx.x & 63) == 0 && wave < kLgsMaskWords;
+    {
+        const unsigned long long m0 = __ballot(my);
+        if (lead) liveA[wave] = m0;
+    }
+    int rounds = 0;
+    unsigned long long* lcur = liveA;
+    unsigned long long* lnext = liveB;
+    for (;;) {
+        __syncthreads();  // this round's live words are written
+        unsigned long long any = 0ull, t = 0ull;
+#pragma unroll
+        for (int w = 0; w < kLgsMaskWords; ++w) {
+            if (w < W64) {
+                const unsigned long long lw = lcur[w];
+                any |= lw;
+                t |= aw[w] & lw;
+            }
+        }
+        if (any == 0ull || (max_rounds > 0 && rounds >= max_rounds)) break;
+        ++rounds;
+        const bool won = my && t == 0ull;
+        {
+            const unsigned long long wm = __ballot(won);
+            if (lead) wonm[wave] = wm;
+        }
+        __syncthreads();
+        unsigned long long k2 = 0ull;
+#pragma unroll
+        for (int w = 0; w < kLgsMaskWords; ++w)
+            if (w < W64) k2 |= aw[w] & wonm[w];
+        const bool killed = my && !won && k2 != 0ull;
+        if (won) st[tv] = 1;
+        else if (killed) st[tv] = 2;
+        my = my && !won && !killed;
+        {
+            const unsigned long long m1 = __ballot(my);
+            if (lead) lnext[wave] = m1;
+        }
+        unsigned long long* sw = lcur; lcur = lnext; lnext = sw;
+    }
+    __syncthreads();  // every state byte is written
+    return rounds;
+}
 
 }  // namespace dgcn
