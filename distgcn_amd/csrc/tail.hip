@@ -115,11 +115,6 @@ __device__ __forceinline__ void tail_row(const float* cvr, const uint8_t* cur, i
     yB = make_float4(apply_act(oB.x, act), apply_act(oB.y, act), apply_act(oB.z, act), apply_act(oB.w, act));
 }
 
-// Workgroup barrier for data handed over through the LDS only: waits for this wave's LDS operations, NOT for its outstanding
-// global loads (__syncthreads() carries a workgroup-scope fence that drains vmcnt too - the weight fragments requested a
-// layer ahead would be waited for at the very next barrier, ~1.2 us of L2 latency per layer: tools/tail_probe.py).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 #ifdef DGCN_DIAG
 #define TAIL_DIAG(a, bit) (((a).diag >> (bit)) & 1)
 #else
@@ -344,7 +339,7 @@ __global__ __launch_bounds__(kTailBlock) void k_tail(TailArgs a) {
                 if (TAIL_DIAG(a, 1)) {}
                 else if (l == 1) hidden_transform_f64<kTailBlock>(bfrag, kTailMax, bufA, zb);
                 else hidden_transform<kTailBlock>(bfrag, kTailMax, bufA, zb);
-                lds_barrier();
+                __syncthreads();  // (on gfx950 a workgroup barrier waits for the wave's LDS operations only: the fragments requested above stay in flight)
             }
             if (mine && !TAIL_DIAG(a, 0)) {
                 const int c = rc;
