@@ -116,15 +116,25 @@ struct FusedArgs {
 #ifdef DGCN_DIAG
 #define DIAG_ON(a, bit) (((a).diag >> (bit)) & 1)
 // phase clock of workgroup g, slot i: accumulated (not overwritten) so per-layer phases sum up
+// (kept in registers - the clock is a scalar - and written out once by STAMP_FLUSH: a global read-modify-write per phase,
+// as in round 3, put a global round trip into every phase it measured)
 #define STAMP(a, g, i, t0)                                                                    \
     do {                                                                                      \
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
-        if ((a).stamps && stamp_wg && threadIdx.x == 0) (a).stamps[(size_t)(g) * 64 + (i)] += _t - (t0); \
+        stamp_acc[i] += _t - (t0);                                                            \
         (t0) = _t;                                                                            \
+    } while (0)
+#define STAMP_FLUSH(a, g)                                                                     \
+    do {                                                                                      \
+        if ((a).stamps && stamp_wg && threadIdx.x == 0) {                                     \
+            _Pragma("unroll") for (int _i = 0; _i < 12; ++_i) (a).stamps[(size_t)(g) * 64 + _i] += stamp_acc[_i]; \
+            (a).stamps[(size_t)(g) * 64 + 15] = __builtin_amdgcn_s_memrealtime(); /* (slot 14: the same clock at the start) */ \
+        }                                                                                     \
     } while (0)
 #else
 #define DIAG_ON(a, bit) 0
 #define STAMP(a, g, i, t0) do { } while (0)
+#define STAMP_FLUSH(a, g) do { } while (0)
 #endif
 
 // ---- first layer (input from global X or a constant): one thread per vertex, outputs in chunks of 16
@@ -1012,6 +1022,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     unsigned long long tclk = 0;
 #ifdef DGCN_DIAG
     tclk = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #endif
     (void)tclk;
 #ifdef DGCN_DIAG
@@ -1093,6 +1104,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             orig[c] = (unsigned short)tv0;
         }
         __syncthreads();
+        STAMP(a, g, 0, tclk);  // residual P0: states, weights, "anything left", renumbering
         const int ng_full = ng;
         if (a.tail_word && threadIdx.x == 0) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)na);
         ng = na;
@@ -1159,6 +1171,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             vals[start] = 1.0f;
         }
         __syncthreads();
+        STAMP(a, g, 1, tclk);  // residual P0: row bounds, first columns, surviving neighbours, row slots, d^-1/2
         hist_to_offsets(hist);
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
@@ -1356,6 +1369,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     const int voff = vid - (int)threadIdx.x;  // 0 unless the residual-graph variant renumbered the vertices
     if (scores_given && (int)threadIdx.x < ng) score = a.scores[n0 + vid];
     float bfrag[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bfrag[i][c] = 0.f;
+    const bool wave_has_tile = (int)(threadIdx.x >> 6) < ((ng + 15) >> 4);  // hidden_transform: tile t on wave t % (BLOCK / 64)
     const int P = a.wide_passes > 1 ? a.wide_passes : 1;  // first-layer column blocks (1 = the ordinary case)
     int l_first = 0;
     if (P > 1 && !scores_given) {
@@ -1410,7 +1428,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
         }
         STAMP(a, g, 4, tclk);
-        if (a.layers[1].cout == kHid) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3), true);  // layer index 1: the f64 MFMA's lane map
+        // (a wave without a tile - residual graphs late in a search: a handful of tiles on sixteen waves - fetches nothing: every
+        // wave pulls the same 8 KB through the L1, 128 KB per layer for a lone 1 024-thread workgroup = ~0.85 us of a layer
+        // that computes for ~0.9 us; `tools/stamp_residual.py`)
+        if (a.layers[1].cout == kHid && (CLUSTER || wave_has_tile)) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3), true);  // layer index 1: the f64 MFMA's lane map
         __syncthreads();
         l_first = 1;
     }
@@ -1481,7 +1502,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             // their 32 registers are not live during the gather phase
             // (both branches define bfrag: otherwise its 32 registers count as live through the gather of every layer)
             if constexpr (!CLUSTER) {
-                if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
+                if (P == 1 && l + 1 < a.num_layers && a.layers[l + 1].cout == kHid && wave_has_tile) load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
                 else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
@@ -1686,6 +1707,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             __syncthreads();
             int nc = 0;
             while (nc < a.beam && nc < 64 && cid[nc] >= 0) ++nc;  // fewer remaining vertices than candidates: the list ends early
+            STAMP(a, g, 10, tclk);  // residual step: priorities, ranks, candidates
             // The completions - for each candidate: the residual graph minus its closed neighbourhood, searched greedily by
             // weight (or by priority), total weight of what joins - run CONCURRENTLY, one wave per candidate, each on its own
             // rank array in LDS (bufA / bufB are free here) and without a single workgroup barrier.  A wave walks its instance's
@@ -1771,6 +1793,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (threadIdx.x == 0) a.totals[g] = tot;
         }
         if (fault) atomicOr(a.status, fault);
+        STAMP(a, g, 11, tclk);  // residual step: rounds / completions + pick, state, totals
+        STAMP_FLUSH(a, g);
     } else {
     double* pr = reinterpret_cast<double*>(bufB);
     double* red = pr + a.max_nodes;  // [BLOCK] slots; bufB has 128 B per row and max_nodes >= 64 rows
@@ -1915,6 +1939,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     if (fault) atomicOr(a.status, fault);
     signal_done(a);
     STAMP(a, g, 11, tclk);  // totals, output
+    STAMP_FLUSH(a, g);
     }
 }
 

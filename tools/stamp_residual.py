@@ -30,10 +30,16 @@ eng.solve_residual(db, dm, state, greedy=greedy, max_rounds=1, beam=16, max_step
 torch.cuda.synchronize()
 os.environ.pop("DGCN_FUSED_STAMPS")
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0
-names = ["P0a states, renumbering, counts", "P0b entries", "P0c order, records", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
-         "hidden A (sum)", "barrier after A (sum)", "last layer", "ranks + greedy step (+ completions)", "tail"]
+names = ["P0 states, anything left, renumbering", "P0 row bounds, columns, counts, slots", "P0 entries, row order, records", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
+         "hidden A (sum)", "barrier after A (sum)", "last layer", "priorities, ranks, candidates", "rounds / completions, pick, output"]
 print("%s step after %d steps: %d graphs of %d vertices, %.0f left on average (min %d, max %d)" % (which, before, graphs, n, left.mean(), left.min(), left.max()))
 print("phase clocks of wave 0, hundred cycles: mean over graphs / max")
 for i, nm in enumerate(names):
     print("%-40s %8.2f %8.2f" % (nm, s[:, i].mean(), s[:, i].max()))
 print("%-40s %8.2f" % ("sum of means", s[:, :12].mean(axis=0).sum()))
+raw = st.cpu().numpy().reshape(-1, 64)
+wall_us = (raw[:, 15] - raw[:, 14]) / 100.0  # s_memrealtime: 100 MHz
+ok = wall_us > 0
+if ok.any():
+    cyc = raw[ok, :12].sum(axis=1)
+    print("workgroup wall time (100 MHz clock): mean %.1f us, max %.1f us; phase clocks tick at %.2f GHz" % (wall_us[ok].mean(), wall_us[ok].max(), (cyc / wall_us[ok]).mean() / 1e3))
