@@ -16,7 +16,7 @@ st = torch.zeros(hb.num_graphs * 64, dtype=torch.int64, device="cuda")
 os.environ["DGCN_FUSED_STAMPS"] = str(st.data_ptr())
 eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
 os.environ.pop("DGCN_FUSED_STAMPS")
-s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0  # s_memtime ticks at 100 MHz -> us
+s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 2400.0  # s_memtime ticks at the shader clock (2.4 GHz under load: tools/stamp_residual.py) -> us
 names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
          "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]
 print("phase clocks of wave 0, microseconds: mean over graphs / max")
