@@ -85,6 +85,8 @@ struct BigArgs {
     int32_t front, act_last;
     uint2* rec;            // [num_graphs][rec_cap]
     int32_t* status;
+    int32_t num_graphs_diag;     // DGCN_DIAG builds only: graphs of the launch (the per-wave table sits behind the per-graph one)
+    unsigned long long* stamps;  // DGCN_DIAG builds only (tools/stamp_big.py): [num_graphs][16] phase clocks of wave 0 (s_memtime), kept in registers and written once
     int32_t rec_cap, max_nodes, num_hidden;
     int32_t lds_cnt_off, lds_perm_off, lds_stage_off, lds_tab_off;  // byte offsets inside the dynamic LDS; the zero row sits at max_nodes * 128
     BigLayer layers[kBigMaxLayers];
@@ -127,6 +129,25 @@ __device__ __forceinline__ void big_load_bfrag(const float* W, float (&b)[8][4],
         for (int ct = 0; ct < 4; ++ct) b[s][ct] = W[(4 * s + kq) * 64 + ct * 16 + r];
 }
 
+#ifdef DGCN_DIAG
+#define BIG_STAMP(i)                                                   \
+    do {                                                               \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();    \
+        big_acc[i] += _t - big_t0;                                     \
+        big_t0 = _t;                                                   \
+    } while (0)
+#define BIG_STAMP_FLUSH()                                                                                              \
+    do {                                                                                                               \
+        if (a.stamps && threadIdx.x == 0) {                                                                            \
+            _Pragma("unroll") for (int _i = 0; _i < 12; ++_i) a.stamps[(size_t)g * 16 + _i] = big_acc[_i];           \
+            a.stamps[(size_t)g * 16 + 13] = __builtin_amdgcn_s_memrealtime();                                          \
+        }                                                                                                              \
+    } while (0)
+#else
+#define BIG_STAMP(i) do { } while (0)
+#define BIG_STAMP_FLUSH() do { } while (0)
+#endif
+
 // TILES: sixteen-row tiles a wave keeps in registers (4: up to 64 BLOCK / 64 tiles; 2: half of that, and the freed registers hold
 // a second group of records in flight: the walk asks for its records TWO groups of four trips ahead)
 template <int BLOCK, int TILES>
@@ -154,6 +175,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const int tiles = (ng + 15) >> 4;
     uint2* rec = a.rec + (size_t)g * a.rec_cap;
     int fault = 0;
+#ifdef DGCN_DIAG
+    unsigned long long big_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long big_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)g * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- P0: row lengths, row order (counting sort, descending), Z1 of the first aggregation into LDS
     for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
@@ -212,6 +238,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         }
     }
     __syncthreads();
+    BIG_STAMP(0);  // row lengths, row order, tiles, d^-1/2
     const int s16 = lane >> 2, kq4 = lane & 3;  // aggregation: row slot of the tile, quarter of the row
     // every wave writes the records of its own tiles (read back by the same lanes: no barrier)
     for (int t = wave; t < tiles; t += kWavesB) {
@@ -260,6 +287,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         }
     }
     __syncthreads();  // (the d^-1/2 array shares the staging tiles' space)
+    BIG_STAMP(1);  // records
     // (the records are read by the lanes that wrote them, after at least one workgroup barrier below)
 
     // ---- layers
@@ -445,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     float zz0[TILES], zz1[TILES];  // the last layer's (width 1) z0 / z1 of this lane's row
 #pragma unroll
     for (int k = 0; k < TILES; ++k) zz0[k] = zz1[k] = 0.f;
+    BIG_STAMP(2);  // layer 0 and the transform of layer 1 (or Z of layer 1 read from global memory)
     for (int i = 0; i < a.num_hidden; ++i) {
         const BigLayer& L = a.layers[i];
         const bool last = i == a.num_hidden - 1;
@@ -508,10 +537,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 }
             }
         }
+        BIG_STAMP(3);  // aggregations (sum over the hidden layers)
+#ifdef DGCN_DIAG
+        if (a.stamps && lane == 0) a.stamps[(size_t)a.num_graphs_diag * 16 + (size_t)g * 16 + wave] = big_acc[3];  // every wave's own sum, behind the phase table
+#endif
         if (last) break;
         // the next layer's weight fragments: requested here, they land while this wave waits at the barrier
         big_load_bfrag(L.Wnext, bfrag, false);
+        BIG_STAMP(4);  // issuing the weight loads
         __syncthreads();  // every gather of this layer has read Z1
+        BIG_STAMP(5);  // barrier behind the aggregation
         // -------- transform of the next layer: Z0 | Z1 = H'.[W0 | W1], v_mfma_f32_16x16x4_f32, operands swapped (D^T = W^T.H^T)
         // so that a lane ends with four consecutive features of one vertex; Z1 -> bufB, Z0 -> registers (aggregation layout)
 #pragma unroll
@@ -538,7 +573,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 DGCN_BSTAGE_TO_AGG(o0, o1)
             }
         }
+        BIG_STAMP(6);  // transforms (sum)
         __syncthreads();  // Z1 of the next layer is complete
+        BIG_STAMP(7);  // barrier behind the transform
     }
     // -------- the last layer's aggregation at width 1: score = act(z0 + sum_j val_j z1[u_j] + b), an fmaf chain in storage
     // order like every other; z1 of the whole graph as a float array over bufB (the record's word >> 7 is the neighbour)
@@ -583,6 +620,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             }
         }
     }
+    BIG_STAMP(8);  // last layer: width-1 walk, scores, priorities
     if (a.do_lgs) {
         // -------- the local greedy search (heuristics.py:77-116), as k_lgs runs it: priorities, state bytes, row bounds and the
         // graph's 16-bit local column ids in LDS (everything the forward pass kept there is dead after the next barrier)
@@ -647,6 +685,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             if (threadIdx.x == 0) a.totals[g] = red[0];
         }
     }
+    BIG_STAMP(9);  // the search, state, totals
+    BIG_STAMP_FLUSH();
 #undef DGCN_BSTAGE_TO_AGG
 #undef DGCN_BSTAGE_TO_OPERAND
 #undef DGCN_BFIRST_GROUP
@@ -842,6 +882,10 @@ static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipSt
 
 static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s) {
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
+#ifdef DGCN_DIAG
+    a.stamps = getenv("DGCN_BIG_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_BIG_STAMPS"), nullptr, 0) : nullptr;
+    a.num_graphs_diag = B;
+#endif
     // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
     const bool two = a.max_nodes <= 16 * 2 * (block / 64) && big_env_tiles() != 4;
     if (block == 512) return two ? big_launch_b<512, 2>(a, B, lds, family, s) : big_launch_b<512, 4>(a, B, lds, family, s);
