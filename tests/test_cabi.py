@@ -81,3 +81,16 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dgcn.h")
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_python_option_bits_equal_the_header():
+    """The DGCN_RESIDUAL_* option bits and DGCN_FAULT_* status bits the Python layer passes / decodes are the header's."""
+    import re
+    from distgcn_amd import engine
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dgcn.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(DGCN_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\b", text)}
+    assert defs["DGCN_RESIDUAL_SCORES_GIVEN"] == engine.Engine.SCORES_GIVEN
+    assert defs["DGCN_RESIDUAL_COMPLETE_BY_PRIORITY"] == engine.Engine.COMPLETE_BY_PRIORITY
+    assert defs["DGCN_RESIDUAL_FINISH_SMALL"] == engine.Engine.FINISH_SMALL
+    bits = [defs[k] for k in ("DGCN_RESIDUAL_SCORES_GIVEN", "DGCN_RESIDUAL_COMPLETE_BY_PRIORITY", "DGCN_RESIDUAL_FINISH_SMALL")]
+    assert len(set(bits)) == 3 and all(b & (b - 1) == 0 for b in bits)  # distinct single bits
