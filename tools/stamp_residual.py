@@ -16,6 +16,10 @@ which = sys.argv[4] if len(sys.argv) > 4 else "rollout"
 eng = get_engine()
 hb = datagen.er_batch(graphs, n, 0.02)
 agent = DQNAgent(FLAGS.copy(feature_size=1, hidden1=32, num_layer=20, diver_num=1, max_degree=1, predict="mwis"), seed=3)
+if os.environ.get("STAMP_NOBIAS") == "1":  # the bench's C5 model (IS4SAT weights) has no biases
+    for lyr in agent.model.layers:
+        lyr["bias"] = None
+    agent.model._device_model = None
 dm = agent.model.device_model(eng)
 db = eng.upload(hb)
 greedy = eng.GREEDY_ROLLOUT if which == "rollout" else eng.GREEDY_CENTRAL
