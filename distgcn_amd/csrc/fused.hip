@@ -529,8 +529,11 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
     (void)st;
     (void)rinfo_lds;
 #ifdef DGCN_DIAG
-#define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) st[i] += _t - bt; bt = _t; } while (0)
+// (accumulated in registers, written once at the end of the call: a global read-modify-write per stamp put a round trip into
+// every phase it measured)
+#define BSTAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); bacc[i] += _t - bt; bt = _t; } while (0)
     unsigned long long bt = 0;
+    unsigned long long bacc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
@@ -674,11 +677,18 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         *ownB = oB;
         BSTAMP(3);
 #ifdef DGCN_DIAG
-        if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) { st[4] += 1; st[5] += (unsigned long long)trips; }
+        bacc[4] += 1;
+        bacc[5] += (unsigned long long)trips;
 #endif
     };
     one_block(std::integral_constant<int, 0>{});
     one_block(std::integral_constant<int, 1>{});
+#ifdef DGCN_DIAG
+    if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st[i] += bacc[i];
+    }
+#endif
 #undef BSTAMP
 }
 

@@ -47,3 +47,8 @@ ok = wall_us > 0
 if ok.any():
     cyc = raw[ok, :12].sum(axis=1)
     print("workgroup wall time (100 MHz clock): mean %.1f us, max %.1f us; phase clocks tick at %.2f GHz" % (wall_us[ok].mean(), wall_us[ok].max(), (cyc / wall_us[ok]).mean() / 1e3))
+blk = raw[:, 48:54].astype(np.float64)
+if blk[:, 4].sum() > 0:
+    nb, ntr = blk[:, 4].mean(), blk[:, 5].mean()
+    print("wave 0's hidden aggregations, per graph: %.1f row blocks, %.1f trips; cycles per block: prologue %.0f, tails %.0f, epilogue %.0f; per trip %.0f"
+          % (nb, ntr, blk[:, 0].mean() / nb, blk[:, 2].mean() / nb, blk[:, 3].mean() / nb, blk[:, 1].mean() / max(ntr, 1)))
