@@ -509,11 +509,36 @@ def roofline_objects(args, wl, fam_ms):
                                          "lds_frac": lds_bytes / avg_s / 1e12 / LDS_PEAK_TBS,
                                          "note": "the SURVEY 8d 'achieved' above is an equivalent bandwidth (layer-by-layer bytes / time), "
                                                  "not bytes that crossed HBM; lds_peak = 256 CUs x 128 B/clk x 2.4 GHz"}}
+            pmc = fused_pmc_reference(args, dom)
+            if pmc:
+                roofline["on_chip_view"]["pmc_reference"] = pmc
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
     kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
     return roofline, kernel_us, traffic_db
+
+
+def fused_pmc_reference(args, dom):
+    """SQ counters of the C3 launch from an earlier PMC pass of the same kernel (profiles/r03_fused_pmc.txt: per-launch sums
+    over the chip), as fractions: how long the LDS was active, how much of that was bank conflicts, how busy the MFMA pipes
+    were.  Only for the configuration the pass was taken on; not measured in this run."""
+    path = os.path.join(ROOT, "profiles", "r03_fused_pmc.txt")
+    if not dom.startswith("k_fused") or args.family != "er" or (args.nodes, args.graphs, args.layers) != (200, 500, 20) or not os.path.isfile(path):
+        return None
+    c = {}
+    for line in open(path):
+        parts = line.split()
+        if len(parts) == 2 and parts[0].startswith("SQ_") and parts[1].isdigit():
+            c[parts[0]] = int(parts[1])
+    need = ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA")
+    if any(k not in c for k in need):
+        return None
+    return {"source": "profiles/r03_fused_pmc.txt (rocprofv3 --pmc passes of this kernel on this configuration, round 3; not measured in this run)",
+            "lds_active_frac_of_cu_busy_cycles": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"],
+            "lds_bank_conflict_frac_of_lds_active": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
+            "mfma_busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]),
+            "mfma_instructions_per_launch": c["SQ_INSTS_MFMA"]}
 
 
 def spmm_probe(args, wl, traffic_db):
