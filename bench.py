@@ -524,7 +524,7 @@ def fused_pmc_reference(args, dom):
     over the chip), as fractions: how long the LDS was active, how much of that was bank conflicts, how busy the MFMA pipes
     were.  Only for the configuration the pass was taken on; not measured in this run."""
     path = os.path.join(ROOT, "profiles", "r03_fused_pmc.txt")
-    if not dom.startswith("k_fused") or args.family != "er" or (args.nodes, args.graphs, args.layers) != (200, 500, 20) or not os.path.isfile(path):
+    if dom != "fused_solve" or args.family != "er" or (args.nodes, args.graphs, args.layers) != (200, 500, 20) or not os.path.isfile(path):
         return None
     c = {}
     for line in open(path):
