@@ -41,6 +41,7 @@ constexpr int kBigMaxNodes = 976;   // Z1 (128 B per vertex) + a 2 KB staging ti
 constexpr int kBigTilesPerWave = 4;  // at most: 64 tiles over 16 waves (k_big<BLOCK, TILES>: 2 where half of that is enough)
 constexpr int kBigMaxLayers = 64;
 constexpr int kBH = 32;
+constexpr int kBigBins = 1024;    // one bin per entry count of a row in the row-order counting sort (4 KB of the staging tiles' space)
 
 using bf32x4 = __attribute__((ext_vector_type(4))) float;
 using bf64x4 = __attribute__((ext_vector_type(4))) double;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     const unsigned zrow = (unsigned)a.max_nodes * 128u;
     unsigned short* cnt = reinterpret_cast<unsigned short*>(big_lds + a.lds_cnt_off);  // [max_nodes] entries per row (clamped: only orders rows and bounds walks)
     unsigned short* perm = reinterpret_cast<unsigned short*>(big_lds + a.lds_perm_off);  // [max_nodes] rows by descending entry count
-    int* hist = reinterpret_cast<int*>(big_lds + a.lds_stage_off);                    // [576] (P0 only: the staging tiles' space)
+    int* hist = reinterpret_cast<int*>(big_lds + a.lds_stage_off);                    // [kBigBins] (P0 only: the staging tiles' space)
     int* ttrips = reinterpret_cast<int*>(big_lds + a.lds_tab_off);                    // [64] trips per tile
     unsigned* tbase = reinterpret_cast<unsigned*>(ttrips + 64);                        // [64] first record of a tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,13 +183,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #endif
 
     // ---- P0: row lengths, row order (counting sort, descending), Z1 of the first aggregation into LDS
-    for (int i = threadIdx.x; i < 576; i += BLOCK) hist[i] = 0;
+    // One bin per possible entry count (a row of a 976-vertex graph has at most 977 entries; a caller's matrix with repeated
+    // columns may exceed that: such rows share the last bin, and a tile's trips are the maximum over its sixteen rows, so no
+    // row is ever cut short whatever order the bins give).
+    for (int i = threadIdx.x; i < kBigBins; i += BLOCK) hist[i] = 0;
     if (threadIdx.x < 32) reinterpret_cast<float*>(big_lds + zrow)[threadIdx.x] = 0.f;
     __syncthreads();
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
         const unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
         cnt[v] = (unsigned short)min(c, 65535u);
-        atomicAdd(&hist[min((int)c, 575)], 1);
+        atomicAdd(&hist[min((int)c, kBigBins - 1)], 1);
     }
     for (int idx = threadIdx.x; idx < (a.front ? 0 : ng * 8); idx += BLOCK) {
         const int v = idx >> 3, c = idx & 7;
@@ -196,22 +200,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         *reinterpret_cast<float4*>(bufB + v * kBH + ((c ^ big_key(v)) << 2)) = z;
     }
     __syncthreads();
-    // start offset of count class c in the descending order = rows with a larger count (576 bins: one pass, once per graph)
-    int my_off = 0;
-    if (threadIdx.x < 576) {
-        for (int c = (int)threadIdx.x + 1; c < 576; ++c) my_off += hist[c];
+    // start offset of count class c in the descending order = rows with a larger count: a suffix scan over the bins, PER
+    // consecutive bins per thread (shuffle scan inside a wave, the waves' totals through the tile table's space)
+    {
+        constexpr int PER = kBigBins / BLOCK;
+        static_assert(PER >= 1 && PER * BLOCK == kBigBins, "k_big: the bins are dealt evenly");
+        int h[PER], own = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { h[j] = hist[threadIdx.x * PER + j]; own += h[j]; }
+        int suf = own;  // inclusive suffix sum over the lanes of the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(suf, off);
+            if (lane + off < 64) suf += t;
+        }
+        if (lane == 0) ttrips[wave] = suf;
+        __syncthreads();
+        int above = suf - own;
+        for (int w = wave + 1; w < kWavesB; ++w) above += ttrips[w];
+        __syncthreads();  // (the tile table's space is written again below)
+#pragma unroll
+        for (int j = PER - 1; j >= 0; --j) { hist[threadIdx.x * PER + j] = above; above += h[j]; }
     }
     __syncthreads();
-    if (threadIdx.x < 576) hist[threadIdx.x] = my_off;
-    __syncthreads();
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
-        const int pos = atomicAdd(&hist[min((int)cnt[v], 575)], 1);
+        const int pos = atomicAdd(&hist[min((int)cnt[v], kBigBins - 1)], 1);
         perm[pos] = (unsigned short)v;  // (order among equal counts: whatever the atomics took - it decides which rows share a pass, never a sum)
     }
     __syncthreads();
-    // trips of every tile (its first row is its longest) and where its records start: one wave, one scan
+    // trips of every tile (its longest row's) and where its records start: one wave, one scan
     if (wave == 0) {
-        const int tl = lane < tiles ? max(1, (int)((cnt[perm[lane * 16]] + 3) >> 2)) : 0;
+        int longest = 0;
+        if (lane < tiles) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int sl = lane * 16 + j;
+                if (sl < ng) longest = max(longest, (int)cnt[perm[sl]]);
+            }
+        }
+        const int tl = lane < tiles ? max(1, (longest + 3) >> 2) : 0;
         int incl = tl;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {

@@ -270,7 +270,8 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     // every pass instead of a quarter of the graph per pass (ER(500, 0.1), 256 graphs: 118 us with 256 threads; the search is a chain
     // of LDS round trips, more waves hide more of them).  Same decisions, same totals (the reduction tree is fixed).
     static const int blk_env = [] { const char* e = getenv("DGCN_LGS_BLOCK"); return e ? atoi(e) : -1; }();  // (read once per process)
-    const bool wide = blk_env >= 0 ? blk_env == 1024 : (b->max_nodes > 384 && !want_stats);
+    // (the 1 024-thread kernels are built without the statistics: a caller that wants them never gets the wide launch)
+    const bool wide = !want_stats && (blk_env >= 0 ? blk_env == 1024 : b->max_nodes > 384);
     if (wide && lpv_env <= 0) lpv = b->max_nodes <= 256 ? 4 : (b->max_nodes <= 512 ? 2 : 1);
     if (wide) {
         if (lpv == 1) return launch_lgs<1, false, 1024>(a, b->num_graphs * num_instances, lds, s);

@@ -530,6 +530,7 @@ int tail_takes(const DgcnModel* m, const float* X, int32_t options) {
         if (l == 0 && (Ly.in_dim < 1 || Ly.in_dim > 64)) return 0;
         if (l > 0 && Ly.in_dim != kHid) return 0;
         if (Ly.out_dim != (l == L - 1 ? 1 : kHid)) return 0;
+        if (Ly.bias && (reinterpret_cast<uintptr_t>(Ly.bias) & 15)) return 0;  // (k_tail reads a hidden layer's bias as float4, like k_big)
     }
     return 1;
 }

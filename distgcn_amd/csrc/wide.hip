@@ -1,0 +1,442 @@
+// One-layer models (F -> 1) on graphs of ANY size the any-size path takes (<= 9 600 vertices), adjacency in, set out, ONE launch:
+// what the reference's multi-channel launchers actually run - `--num_layer=1 --num_channels=3` on the joint conflict graph of
+// K * nflows vertices (bash/twc_major_wireless_mc_test.sh:3,6,9, bash/test_wireless_gcn_rollout.sh:6-8,
+// wireless_dqn_test_mc.py:161, 244-289) - and every residual step of solve_mwis_dit / _cit / the rollouts on such a model
+// (mwis_gdpg_call.py:278-318, 343-384, 596-659).  shallow.hip serves the same models up to 512 vertices with the graph's
+// entry list in LDS; beyond that these shapes used to run as k_supports -> layer-by-layer forward -> k_lgs (three to five
+// launches), a residual step as seven to nine.
+//
+// For one layer the score is a closed form in the (residual) degrees: with L = I - D^-1/2 A D^-1/2,
+//     score_v = act( z0_v + [ 1.z1_v + sum_u (float)(-(d_u^-1/2 d_v^-1/2)) z1_u ] + b ),   z = x.[w0 | w1]
+// - no 32-wide image, no records, no MFMA: d^-1/2 per vertex in LDS, one chain per vertex.  Arithmetic exactly as shallow.hip /
+// the twin (oracle/dgcn_oracle.c: orc_spmm_f64 - layer index 0 carries its row chain in double): the transform is a float32
+// fmaf chain over the input features, the row sum ONE fma chain in double over [diagonal, the row's (undecided) neighbours in
+// CSR order], score = act((float)((double)z0 + acc [+ (double)b])), priority (double)score * weight (mwis_dqn_call.py:232).
+//
+// One 1 024-thread workgroup per graph, vertex v = thread + 1 024 p.  LDS is k_lgs's carve-up (lgs.hip) - float64 priorities,
+// row offsets, state bytes, the graph's columns as 16-bit local ids when they fit - with two of its arrays doing double duty
+// before the search starts: the priorities' space holds d^-1/2 (float64) while the chains run, the row offsets' space holds
+// z1 per vertex (explicit / weight-derived features) or else the float32 scores on their way to becoming priorities.
+//   residual = 0  dgcn_solve_batch: every vertex takes part (heuristics.py:77-116 on gcn_wts)
+//   residual = 1  one step of dgcn_solve_residual_batch: `state` is the running state (0 = undecided); degrees, chains and the
+//                 greedy step see the undecided vertices only - the re-sliced graph of mwis_gdpg_call.py:284-285 without
+//                 re-slicing it: a chain that skips decided neighbours IS the chain over the re-sliced row (same order);
+//                 a graph with nothing left or no positive weight left is left alone (np.sum(wts_nn) <= 0 -> break, :286)
+//   mode 0 local greedy rounds (max_rounds; lgs_rounds.h), 1 the best-priority vertex joins (solve_mwis_cit), 2 scores and
+//   priorities only (the rollout's candidate / completion launches of general.hip follow)
+// Bound: latency (dependent LDS round trips of the rounds); HBM sees the adjacency once or twice (columns that do not fit the
+// LDS are re-read from L2 by every sweep), `nnz * 4 + N * 20` bytes in, `N + 16` out per graph - shallow.hip's figure.
+#include <algorithm>
+#include <atomic>
+
+#include "common.h"
+#include "lgs_rounds.h"
+
+namespace dgcn {
+
+constexpr int kWideBlock = 1024;
+constexpr int kWideMaxNodes = 9600;  // the search's LDS state (lgs.hip)
+
+struct WideArgs {
+    const int32_t* graph_ptr;
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const double* dinv;        // float64 d^-1/2 by degree
+    int32_t table_len;
+    const float* X;            // [num_nodes][cin] or null
+    float x_const;
+    int32_t cin, feature_mode; // feature_mode 1: x = weight / (largest undecided weight + 1e-9) (mwis_gdpg_call.py:88)
+    const float* W;            // [cin][2]
+    const float* bias;         // [1] or null
+    int32_t act;
+    const double* weights;     // or null
+    int32_t predict_mwis, residual, scores_given, mode, max_rounds;
+    float* sc;                 // [num_nodes] scores, original numbering: out (in with scores_given); never null
+    uint8_t* state;
+    int32_t* rounds;
+    double* totals;
+    int32_t* status;
+    int32_t* progress;
+    double* prio;              // mode 2: [num_nodes] out
+    int32_t* active;           // mode 2: [num_graphs] out
+    unsigned long long* tail_word;
+    unsigned long long tail_tag;
+    int32_t max_nodes, cols_cap;
+};
+
+__host__ __device__ __forceinline__ size_t wide_pad16(int x) { return (size_t)((x + 15) & ~15); }
+
+static size_t wide_lds_bytes(int max_nodes, int cols_cap) {
+    const size_t ro = (size_t)((max_nodes + 1 + 3) & ~3) * 4;
+    return (size_t)max_nodes * 8 + 1024 * 8 + 4 * 8 + ro + 2 * wide_pad16(max_nodes + 1) + (size_t)cols_cap * 2;
+}
+
+// the column of entry j of the graph (local id; anything >= ng is not a vertex of the graph)
+template <bool COLS_LDS>
+__device__ __forceinline__ int wide_col(const uint16_t* cl, const int32_t* cg, int j, int e0, int n0) {
+    if (COLS_LDS) return (int)cl[j - e0];
+    return cg[j] - n0;
+}
+
+template <bool COLS_LDS>
+__device__ __forceinline__ void wide_scores(const WideArgs& a, int n0, int ng, int e0, const uint8_t* st, const uint16_t* cl, double* dinv,
+                                            float* z1, float* stash, double wmax, int& fault) {
+    const bool need_z1 = z1 != nullptr;
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    // ---- (residual) degrees -> d^-1/2 per vertex; z1 per vertex where the features differ from vertex to vertex
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        if (st[v] != 0) continue;
+        const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+        int deg = re - rs;
+        if (a.residual) {
+            deg = 0;
+#pragma unroll 4
+            for (int j = rs; j < re; ++j) {
+                const int u = wide_col<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; continue; }
+                deg += st[u] == 0;
+            }
+        }
+        double dv = 0.0;
+        if (deg < a.table_len) dv = a.dinv[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+        dinv[v] = dv;
+        if (need_z1) {
+            float q1 = 0.f;
+            if (a.feature_mode == 1) {
+                const float f = (float)((a.weights ? a.weights[n0 + v] : 1.0) / (wmax + 1e-9));
+                for (int k = 0; k < a.cin; ++k) q1 = fmaf(f, a.W[k * 2 + 1], q1);
+            } else {
+                for (int k = 0; k < a.cin; ++k) q1 = fmaf(a.X[(size_t)(n0 + v) * a.cin + k], a.W[k * 2 + 1], q1);
+            }
+            z1[v] = q1;
+        }
+    }
+    __syncthreads();
+    // ---- one chain per undecided vertex
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        float s = 0.f;  // what a decided vertex reports (general.hip: k_res_scatter)
+        if (st[v] == 0) {
+            float z0 = 0.f, z1v = 0.f;
+            if (a.feature_mode == 1) {
+                const float f = (float)((a.weights ? a.weights[n0 + v] : 1.0) / (wmax + 1e-9));
+                for (int k = 0; k < a.cin; ++k) { z0 = fmaf(f, a.W[k * 2], z0); z1v = fmaf(f, a.W[k * 2 + 1], z1v); }
+            } else {
+                for (int k = 0; k < a.cin; ++k) {
+                    const float x = a.X ? a.X[(size_t)(n0 + v) * a.cin + k] : a.x_const;
+                    z0 = fmaf(x, a.W[k * 2], z0);
+                    z1v = fmaf(x, a.W[k * 2 + 1], z1v);
+                }
+            }
+            const double dvv = dinv[v];
+            const double zd = (double)z1v;
+            double acc = fma(1.0, zd, 0.0);  // the diagonal entry of L comes first
+            const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+            int j = rs;
+            for (; j + 4 <= re; j += 4) {  // four entries' loads in flight, chain order unchanged
+                int u[4];
+                double du[4], zu[4];
+                bool keep[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = wide_col<COLS_LDS>(cl, a.col_idx, j + i, e0, n0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    keep[i] = (unsigned)u[i] < (unsigned)ng;
+                    if (!keep[i]) { fault |= DGCN_FAULT_BAD_COLUMN; u[i] = v; }
+                    if (keep[i] && u[i] == v) fault |= DGCN_FAULT_SELF_LOOP;
+                    if (a.residual) keep[i] = keep[i] && st[u[i]] == 0;
+                    du[i] = dinv[u[i]];
+                    zu[i] = need_z1 ? (double)z1[u[i]] : zd;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (keep[i]) acc = fma((double)(float)(-(du[i] * dvv)), zu[i], acc);
+            }
+            for (; j < re; ++j) {
+                const int u = wide_col<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; continue; }
+                if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                if (a.residual && st[u] != 0) continue;
+                acc = fma((double)(float)(-(dinv[u] * dvv)), need_z1 ? (double)z1[u] : zd, acc);
+            }
+            acc = (double)z0 + acc;
+            if (a.bias) acc += (double)bias;
+            s = apply_act((float)acc, a.act);
+        }
+        a.sc[n0 + v] = s;
+        if (stash) stash[v] = s;
+    }
+}
+
+template <int LPV>
+__global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_raw[];
+    const int g = blockIdx.x;
+    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1], ng = n1 - n0;
+    // carve (lgs.hip's, one more state slot): [f64 prio | f64 reduce[1024] | u64 acc[4] | i32 row offsets | u8 st | u8 nw | u16 cols]
+    double* pr = reinterpret_cast<double*>(wide_raw);
+    double* red = pr + a.max_nodes;
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + 1024);
+    int* rol = reinterpret_cast<int*>(acc64 + 4);
+    uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
+    uint8_t* nw = st + wide_pad16(a.max_nodes + 1);
+    uint16_t* cl = reinterpret_cast<uint16_t*>(nw + wide_pad16(a.max_nodes + 1));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (ng <= 0) {
+        if (threadIdx.x == 0) {
+            if (a.rounds) a.rounds[g] = 0;
+            if (a.totals) a.totals[g] = 0.0;
+            if (a.active) a.active[g] = 0;
+        }
+        return;
+    }
+    int fault = 0;
+    const int e0 = a.row_ptr[n0], e1 = a.row_ptr[n1];
+    const bool cols_lds = (e1 - e0) <= a.cols_cap;
+    // ---- the running state; is anything left to do (residual steps); the graph's columns as 16-bit local ids
+    int cnt = 0, pos = 0;
+    double mx = -1.0 / 0.0;
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        const uint8_t s0 = a.residual ? a.state[n0 + v] : (uint8_t)0;
+        st[v] = s0;
+        nw[v] = 0;
+        if (a.residual) {
+            const bool alive = s0 == 0;
+            const double w = a.weights ? a.weights[n0 + v] : 1.0;
+            cnt += alive;
+            pos |= alive && w > 0.0;
+            if (alive) mx = fmax(mx, w);
+        }
+    }
+    if (threadIdx.x == 0) st[ng] = 3;  // the slot a column outside the graph points to: takes part in nothing
+    if (cols_lds) {
+        for (int base = e0 + threadIdx.x; base < e1; base += kWideBlock * 4) {  // four loads in flight per thread
+            int c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = (base + i * kWideBlock < e1) ? a.col_idx[base + i * kWideBlock] : n0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + i * kWideBlock < e1) {
+                    int u = c[i] - n0;
+                    if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = ng; }
+                    cl[base + i * kWideBlock - e0] = (uint16_t)u;
+                }
+        }
+    }
+    double wmax = 0.0;
+    if (a.residual) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            cnt += __shfl_xor(cnt, off);
+            pos |= __shfl_xor(pos, off);
+            mx = fmax(mx, __shfl_xor(mx, off));
+        }
+        int* ri = reinterpret_cast<int*>(red + 16);
+        if (lane == 0) { red[wave] = mx; ri[wave] = cnt; ri[16 + wave] = pos; }
+        __syncthreads();
+        cnt = 0; pos = 0; mx = -1.0 / 0.0;
+#pragma unroll
+        for (int w = 0; w < kWideBlock / 64; ++w) { cnt += ri[w]; pos |= ri[16 + w]; mx = fmax(mx, red[w]); }
+        wmax = mx;
+        // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286): the graph is left alone
+        if (!pos) {
+            if (threadIdx.x == 0) {
+                if (a.rounds) a.rounds[g] = 0;
+                if (a.totals) a.totals[g] = 0.0;
+                if (a.active) a.active[g] = 0;
+            }
+            if (!a.scores_given) for (int v = threadIdx.x; v < ng; v += kWideBlock) a.sc[n0 + v] = 0.f;
+            if (fault) atomicOr(a.status, fault);
+            return;
+        }
+    } else {
+        __syncthreads();
+    }
+    // ---- scores.  The priorities' space holds d^-1/2 meanwhile, the row offsets' space z1 per vertex or the scores.
+    const bool need_z1 = a.X != nullptr || a.feature_mode == 1;
+    float* z1 = need_z1 ? reinterpret_cast<float*>(rol) : nullptr;
+    float* stash = need_z1 ? nullptr : reinterpret_cast<float*>(rol);
+    if (!a.scores_given) {
+        if (cols_lds) wide_scores<true>(a, n0, ng, e0, st, cl, pr, z1, stash, wmax, fault);
+        else wide_scores<false>(a, n0, ng, e0, st, cl, pr, z1, stash, wmax, fault);
+    } else {
+        stash = nullptr;
+    }
+    __syncthreads();  // every chain has read its d^-1/2 and z1; the scores of this graph are visible to its workgroup
+    // ---- priorities (mwis_dqn_call.py:230-235: float32 x float64 -> float64); a decided vertex: 0, takes part in nothing
+    int bad = 0;
+    double pmine[(kWideMaxNodes + kWideBlock - 1) / kWideBlock];
+#pragma unroll
+    for (int p = 0; p < (kWideMaxNodes + kWideBlock - 1) / kWideBlock; ++p) {
+        const int v = threadIdx.x + p * kWideBlock;
+        double q = 0.0;
+        if (v < ng && st[v] == 0) {
+            q = (double)(stash ? stash[v] : a.sc[n0 + v]);
+            if (a.predict_mwis && a.weights) q *= a.weights[n0 + v];
+            bad |= q != q;
+        }
+        pmine[p] = q;
+    }
+    __syncthreads();  // (the stash lies where the row offsets go)
+#pragma unroll
+    for (int p = 0; p < (kWideMaxNodes + kWideBlock - 1) / kWideBlock; ++p) {
+        const int v = threadIdx.x + p * kWideBlock;
+        if (v < ng) {
+            pr[v] = pmine[p];
+            if (a.prio) a.prio[n0 + v] = pmine[p];
+        }
+    }
+    for (int v = threadIdx.x; v <= ng; v += kWideBlock) rol[v] = a.row_ptr[n0 + v];
+    if (__syncthreads_or(bad)) {
+        // the reference would spin forever on a NaN priority (its argmax would pick it): report, leave the graph as it is
+        if (threadIdx.x == 0) {
+            atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+            if (a.rounds) a.rounds[g] = -1;
+            if (a.totals) a.totals[g] = 0.0;
+            if (a.active) a.active[g] = 0;
+        }
+        if (!a.residual) for (int v = threadIdx.x; v < ng; v += kWideBlock) a.state[n0 + v] = 0;
+        return;
+    }
+    if (threadIdx.x == 0 && a.residual) {
+        if (a.progress) atomicAdd(a.progress, 1);
+        if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)cnt);
+    }
+    if (fault) atomicOr(a.status, fault);
+    if (a.mode == 2) {  // the rollout's candidate / instance / completion / pick launches follow (general.hip)
+        if (threadIdx.x == 0 && a.active) a.active[g] = 1;
+        return;
+    }
+    if (a.mode == 1) {
+        // ---- solve_mwis_cit: the best-priority undecided vertex joins (np.argmax: lowest index among equals), its neighbours leave
+        double bp = 0.0;
+        int bv = -1;
+        for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+            if (st[v] != 0) continue;
+            const double p = pr[v];
+            if (bv < 0 || p > bp) { bp = p; bv = v; }  // ascending v per thread: the first maximum stays
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double op = __shfl_xor(bp, off);
+            const int ov = __shfl_xor(bv, off);
+            if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+        }
+        int* ri = reinterpret_cast<int*>(red + 16);
+        if (lane == 0) { red[wave] = bp; ri[wave] = bv; }
+        __syncthreads();
+        bp = red[0]; bv = ri[0];
+#pragma unroll
+        for (int w = 1; w < kWideBlock / 64; ++w) {
+            const double op = red[w];
+            const int ov = ri[w];
+            if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+        }
+        if (bv < 0) return;  // (cannot happen: the graph has an undecided vertex)
+        for (int j = rol[bv] + (int)threadIdx.x; j < rol[bv + 1]; j += kWideBlock) {
+            const int u = a.col_idx[j] - n0;
+            if ((unsigned)u < (unsigned)ng && u != bv && st[u] == 0) a.state[n0 + u] = 2;
+        }
+        if (threadIdx.x == 0) {
+            a.state[n0 + bv] = 1;
+            if (a.rounds) a.rounds[g] = 1;
+            if (a.totals) a.totals[g] = a.weights ? a.weights[n0 + bv] : bp;
+        }
+        return;
+    }
+    // ---- the local greedy search (heuristics.py:77-116), k_lgs's rounds on the state already in LDS
+    LgsArgs la = {};
+    la.col_idx = a.col_idx;
+    la.max_rounds = a.max_rounds;
+    la.rounds = a.rounds;
+    la.init_state = a.residual ? a.state : nullptr;
+    if (cols_lds) lgs_rounds<LPV, false, true, kWideBlock>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+    else lgs_rounds<LPV, false, false, kWideBlock>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
+    {
+        // state out; totals as k_lgs forms them: strided partials folded to 256 slots, then a binary tree.  A vertex that was a
+        // member before this step is not counted (the total is what joined in THIS call).
+        double part = 0.0;
+        for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+            const uint8_t s1 = st[v];
+            if (a.totals && s1 == 1 && !(a.residual && a.state[n0 + v] == 1)) part += a.weights ? a.weights[n0 + v] : pr[v];
+            a.state[n0 + v] = s1;
+        }
+        red[threadIdx.x] = part;
+    }
+    if (a.totals) {
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            double acc = red[threadIdx.x];
+            for (int k2 = 256; k2 < kWideBlock; k2 += 256) acc += red[threadIdx.x + k2];
+            red[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.totals[g] = red[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// which (batch, model) pairs: one layer F -> 1 over [I, L], F <= 64, graphs of at most 9 600 vertices.  DGCN_WIDE1=0 (read
+// once per process) sends them layer by layer instead (tests compare the two).
+int wide1_takes(const DgcnBatch* b, const DgcnModel* m) {
+    static const bool off = [] { const char* e = getenv("DGCN_WIDE1"); return e && atoi(e) == 0; }();
+    if (off || !b || !m || !m->layers_host || m->num_layers != 1 || m->num_supports != 2) return 0;
+    const DgcnLayer& L = m->layers_host[0];
+    if (!L.weights || L.out_dim != 1 || L.in_dim < 1 || L.in_dim > 64) return 0;
+    return b->max_nodes > 0 && b->max_nodes <= kWideMaxNodes;
+}
+
+template <int LPV>
+static int wide1_launch_l(const WideArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        static std::atomic<int> raised[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!raised[dev & 63].load(std::memory_order_relaxed)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide1<LPV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(DGCN_ERR_LAUNCH, "k_wide1: cannot reserve %zu bytes of LDS", lds);
+            raised[dev & 63].store(1, std::memory_order_relaxed);
+        }
+    }
+    TimedLaunch t(family, s);
+    DGCN_LAUNCH(t, (k_wide1<LPV>), dim3((unsigned)B), dim3(kWideBlock), lds, s, a);
+    return check_launch("k_wide1");
+}
+
+// One launch: dgcn_solve_batch (residual = 0) or one step of dgcn_solve_residual_batch (residual = 1) for a one-layer model.
+// `sc`: the scores array in the original numbering (the caller's, or scratch); `prio` / `active`: mode 2 only.
+int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
+              int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
+              int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
+              double* prio, int32_t* active, unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s) {
+    const DgcnLayer& L = m->layers_host[0];
+    WideArgs a = {};
+    a.graph_ptr = b->graph_ptr; a.row_ptr = b->row_ptr; a.col_idx = b->col_idx;
+    a.dinv = dinv_table; a.table_len = table_len;
+    a.X = X; a.x_const = x_const; a.cin = L.in_dim; a.feature_mode = feature_mode;
+    a.W = L.weights; a.bias = L.bias; a.act = L.act;
+    a.weights = weights; a.predict_mwis = predict_mwis; a.residual = residual; a.scores_given = scores_given; a.mode = mode;
+    a.max_rounds = max_rounds;
+    a.sc = sc; a.state = state; a.rounds = rounds; a.totals = totals; a.status = status; a.progress = progress;
+    a.prio = mode == 2 ? prio : nullptr; a.active = mode == 2 ? active : nullptr;
+    a.tail_word = tail_word; a.tail_tag = tail_tag;
+    a.max_nodes = std::max(b->max_nodes, 16);
+    // the graph's columns in LDS when the largest graph's fit next to the search's state
+    constexpr size_t kLdsMax = 156 * 1024;
+    int cap = std::max(b->max_graph_edges, 0);
+    if (wide_lds_bytes(a.max_nodes, cap) > kLdsMax) cap = 0;
+    a.cols_cap = cap;
+    const size_t lds = wide_lds_bytes(a.max_nodes, cap);
+    if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_wide1: %zu bytes of LDS for graphs of %d vertices", lds, b->max_nodes);
+    const char* family = residual ? "wide_residual" : "wide_solve";
+    // lanes per vertex in the rounds: k_lgs's choice for 1 024-thread workgroups
+    const int lpv = b->max_nodes <= 256 ? 4 : (b->max_nodes <= 512 ? 2 : 1);
+    if (lpv == 4) return wide1_launch_l<4>(a, b->num_graphs, lds, family, s);
+    if (lpv == 2) return wide1_launch_l<2>(a, b->num_graphs, lds, family, s);
+    return wide1_launch_l<1>(a, b->num_graphs, lds, family, s);
+}
+
+}  // namespace dgcn

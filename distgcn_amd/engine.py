@@ -481,11 +481,16 @@ class Engine:
             if max_steps == 1:  # a caller that asks for exactly one step does not need to know whether it decided anything
                 steps = 1
                 break
-            for v in progress.cpu().tolist():
+            # (the status word rides along: a fault such as a NaN priority leaves its graph undecided - "active" - for ever,
+            # and the any-size path counts active graphs as progress; the caller's check_status reports it)
+            words = t.cat([progress, out["status"].reshape(-1)[:1].to(t.int32)]).cpu().tolist()
+            for v in words[:k]:
                 if v == 0:
                     done = True
                     break
                 steps += 1
+            if words[k] != 0:
+                done = True
             group = min(2 * group, 32)  # (a search of ~100 steps: 6 read-backs instead of 14; at most 31 empty launches at its end)
         return {"state": state, "steps": steps, "status": out["status"],
                 "scores": None if out["scores"] is None else out["scores"][:n]}

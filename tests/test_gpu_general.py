@@ -200,6 +200,52 @@ def test_big_graphs_plain_solve_vs_twin(engine, n, p):
     assert np.array_equal(np.asarray(res["scores"]).ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
 
 
+def _hub_graph(n, hubs, p, rng):
+    """ER(n, p) plus `hubs` = [(vertex, degree), ..]: rows far longer than every other row of their sixteen-row tile."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    indptr, indices = datagen.er_graph(n, p, rng)
+    a = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n)).tolil()
+    for v, d in hubs:
+        for u in rng.choice(np.setdiff1d(np.arange(n), [v]), size=d, replace=False):
+            a[v, u] = 1.0
+            a[u, v] = 1.0
+    a = a.tocsr()
+    a.sort_indices()
+    return a
+
+
+@pytest.mark.parametrize("case", ["er900_p0.7", "two_hubs", "hub_classes"])
+def test_big_rows_beyond_575_entries_vs_twin(engine, case):
+    """Rows of 575 and more entries (round 4's row-order counting sort clamped entry counts to 576 bins and sized a tile's
+    trips from its FIRST row: a longer row later in the tile lost the tail of its sum in every layer - advisor finding,
+    round 4).  ER(900, 0.7): every row has ~630 entries; two hubs of degree 600 and 900 in a sparse 950-vertex graph;
+    hubs of 576 .. 940 entries sharing tiles.  Scores, sets and rounds equal to the twin bit for bit, no fault bit."""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    rng = np.random.default_rng(77)
+    if case == "er900_p0.7":
+        hb = datagen.er_batch(2, 900, 0.7, first_index=90)
+    else:
+        if case == "two_hubs":
+            mats = [_hub_graph(950, [(17, 600), (640, 900)], 0.01, rng), _hub_graph(930, [(3, 929), (4, 580)], 0.004, rng)]
+        else:
+            mats = [_hub_graph(976, [(5 + 31 * i, 576 + 19 * i) for i in range(20)], 0.01, rng)]
+        hb = HostBatch.from_scipy(mats, [rng.random(m.shape[0]) for m in mats])
+    layers = datagen.random_model(4, 32, seed=5)
+    dm = DeviceModel(layers, engine.device)
+    db = engine.upload(hb)
+    assert engine.solve_path(db, dm) == 2
+    ref = ctwin.solve(hb, layers)
+    r = engine.solve_fused(db, dm)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(r["rounds"].cpu().numpy(), ref["rounds"])
+
+
 @pytest.mark.parametrize("which", ["dit", "cit", "rollout", "rollout1"])
 def test_big_graph_iterative_solvers_vs_oracle(engine, which):
     """solve_mwis_dit / _cit / _rollout on a 600-vertex graph and on ER(500, 0.1): entirely on the device (the any-size
