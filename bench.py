@@ -59,12 +59,15 @@ def parse(argv=None):
                     help="also time the step issued alternately on two HIP streams (side figure; its overlapping launches would "
                          "blur a kernel trace of the run, so it is not part of the default command)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
-    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5", "ER500", "MC900"], default=None,
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5", "ER500", "MC900", "MC900-l1", "MC1500"], default=None,
                     help="BASELINE.json configuration shortcuts: C2 = 500 ER N=100 l=1; C3 = 500 ER N=200 l=20 (the default line); "
                          "C4 = the 4 000-graph BA batch over the ranks (--layers as given, default 20); C4-share = one GPU's 500 "
                          "graphs of it; C5 = GCN-guided rollout (b=16) on 64 ER N=500 graphs; beyond the fused kernel's 512 vertices / LDS "
                          "budget (the any-size path, csrc/general.hip + big.hip): ER500 = 256 ER N=500 p=0.1 (25 000 entries per graph), "
-                         "MC900 = 256 joint 3-channel conflict graphs of 300 flows (900 vertices, wireless_rollout_test_flood.py:98-133)")
+                         "MC900 = 256 joint 3-channel conflict graphs of 300 flows (900 vertices, wireless_rollout_test_flood.py:98-133); "
+                         "MC900-l1 = the same graphs with the one-layer model the reference's multi-channel launcher runs "
+                         "(bash/twc_major_wireless_mc_test.sh:3 --num_layer=1 --num_channels=3; csrc/wide.hip); "
+                         "MC1500 = 256 joint graphs of 3 x 500 flows (1 500 vertices), l=20")
     ap.add_argument("--parity-seconds", type=float, default=25.0,
                     help="budget of the full-size parity report against the oracle restatement (0 = skip)")
     ap.add_argument("--beam", type=int, default=16, help="C5: rollout candidates per step")
@@ -86,7 +89,11 @@ def parse(argv=None):
         args.family, args.graphs, args.nodes, args.p, args.layers = "er", (args.graphs or 256), 500, 0.1, 20
     elif args.config == "MC900":
         args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 900, 0.03, 20
-    if args.config in ("ER500", "MC900") and args.steps is None:
+    elif args.config == "MC900-l1":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 900, 0.03, 1
+    elif args.config == "MC1500":
+        args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 1500, 0.03, 20
+    if args.config in ("ER500", "MC900", "MC1500") and args.steps is None:
         args.steps = 400
     if args.graphs is None:
         args.graphs = 500
@@ -133,7 +140,10 @@ def workload_name(args):
             return "C4"
         return "C4 (one GPU's share)" if args.graphs == 500 else "custom"
     if args.family == "mc":
-        return "MC900 (joint 3-channel conflict graphs, beyond the fused kernel)" if args.nodes == 900 else "custom"
+        if args.nodes == 900:
+            return ("MC900-l1 (joint 3-channel conflict graphs, the multi-channel launcher's one-layer model)" if args.layers == 1
+                    else "MC900 (joint 3-channel conflict graphs, beyond the fused kernel)")
+        return "MC1500 (joint 3-channel conflict graphs of 500 flows)" if args.nodes == 1500 else "custom"
     key = (args.graphs, args.nodes, args.p, args.layers, args.hidden)
     return {(500, 200, 0.1, 20, 32): "C3", (500, 100, 0.1, 1, 32): "C2",
             (256, 500, 0.1, 20, 32): "ER500 (25 000 entries per graph: beyond the fused kernel)"}.get(key, "custom")
@@ -319,7 +329,7 @@ class GpuWorkload:
     def kernel_times(self):
         fam_ms = {}
         for fam in ("supports", "transform", "spmm", "layer", "lgs", "fused_forward", "fused_solve", "big_forward", "big_solve",
-                    "general_prepare", "general_greedy"):
+                    "general_prepare", "general_greedy", "wide_solve", "wide_residual"):
             ms, n = self.eng.timing_read(fam)
             if n:
                 fam_ms[fam] = (ms, n)
@@ -475,7 +485,7 @@ def roofline_objects(args, wl, fam_ms):
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": avg_bytes,
                         "formula": "SURVEY 8d B_spmm + 4*C*N for the fused '+Z0' read, averaged over the layers"}
-        elif dom in ("fused_forward", "fused_solve", "big_forward", "big_solve"):
+        elif dom in ("fused_forward", "fused_solve", "big_forward", "big_solve", "wide_solve"):
             # one launch = every layer of every graph: SURVEY 8d counts the forward layer by layer
             # (1.658 MB per ER N=200 l=20 graph); the kernel keeps the graph in LDS, so its real HBM
             # traffic ('traffic', from PMC counters) is far BELOW this figure, not above it.
@@ -493,9 +503,13 @@ def roofline_objects(args, wl, fam_ms):
                      if dom == "big_solve" else
                      "k_big (whole forward of graphs beyond the fused kernel's LDS budget, one launch per step; supports and greedy search in launches of their own)"
                      if dom == "big_forward" else
+                     "k_wide1 (one-layer model on graphs of any size: whole path, one launch per step)" if dom == "wide_solve" else
                      "k_shallow (one-layer model: whole path, one launch per step)" if len(layers) == 1 else
                      "k_fused (%s: whole path, one launch per step)" % dom)
-            roofline = {"kernel": kname, "bound": "hbm",
+            # what paces the kernel (the SURVEY 8d figure below is an EQUIVALENT bandwidth: layer-by-layer bytes / time): the
+            # in-LDS deep-stack kernels sit on the LDS array + the fp32 MFMA pipe; the one-layer kernels are chains of dependent
+            # round trips (latency); only the stand-alone SpMM lines are HBM-bound
+            roofline = {"kernel": kname, "bound": "latency" if len(layers) == 1 else "lds+mfma",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": algo,
@@ -513,7 +527,7 @@ def roofline_objects(args, wl, fam_ms):
             if pmc:
                 roofline["on_chip_view"]["pmc_reference"] = pmc
         else:
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": dom, "bound": "latency", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
     kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
     return roofline, kernel_us, traffic_db
@@ -946,7 +960,7 @@ def main(argv=None, workload_factory=None):
         ach = (algo / calls) / avg_s / 1e9 if avg_s > 0 else None
         tms, tn = fam_ms.get("tail_finish", (0.0, 0))
         roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
-                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+                    "bound": "lds+mfma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
                     "traffic": None, "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
                     "empty_launches_per_search": n / max(args.steps, 1) - calls,
                     "algorithmic_bytes_per_launch": algo / calls,
@@ -1018,10 +1032,11 @@ def main(argv=None, workload_factory=None):
             "spmm_kernel_roofline": spmm_line,
             "kernels": kernel_us,
         }
-        if world == 1 and args.cpu_seconds > 0 and isinstance(wl, RolloutWorkload):
+        if isinstance(wl, RolloutWorkload):
             out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on ER N=%d p=%g" % (args.beam, args.nodes, args.p)
             out["config"]["workload"] = ("C5: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per step of the search, "
                                          "~%d calls per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
+        if world == 1 and args.cpu_seconds > 0 and isinstance(wl, RolloutWorkload):
             out["cpu_baseline"] = c5_cpu_baseline(wl, args.cpu_seconds)
         elif world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(hb, wl.layers, args.cpu_seconds)

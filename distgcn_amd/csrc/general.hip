@@ -45,6 +45,14 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
               int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
               hipStream_t s);
 
+// wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
+// in one launch
+int wide1_takes(const DgcnBatch* b, const DgcnModel* m);
+int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
+              int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
+              int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
+              double* prio, int32_t* active, unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s);
+
 constexpr int kResBlock = 1024;  // (graphs of this path are large and batches of them small: 64 graphs x 256 threads left the chip idle)
 constexpr int kMaxBeam = 64;
 
@@ -545,6 +553,13 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     Bump w{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255),
            workspace_bytes >= 256 ? workspace_bytes - 256 : 0};
     if (!workspace) w.ok = false;
+    if (wide1_takes(b, m)) {  // one-layer models: supports, score, priority and greedy search in ONE launch (wide.hip)
+        float* sc1 = scores ? scores : w.take<float>(n);
+        if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
+                               general_workspace(b, m), workspace_bytes);
+        return wide1_run(b, m, dinv_table, table_len, X, x_const, 0, weights, predict_mwis, 0, 0, 0, 0, sc1, state, rounds, totals, nullptr,
+                         status, nullptr, nullptr, nullptr, 0, s);
+    }
     int32_t* lrow = w.take<int32_t>(n + 1);
     int32_t* lcol = w.take<int32_t>(n + e);
     float* lval = w.take<float>(n + e);
@@ -616,12 +631,20 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_residual_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);
-    {
+    const bool wide = wide1_takes(b, m) != 0;
+    if (wide) {
+        // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE
+        // launch on the graph as it lies - no compaction; the rollout's four launches follow on the priorities it leaves
+        const int rc = wide1_run(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, 1, given ? 1 : 0, greedy_mode,
+                                 max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, s);
+        if (rc || greedy_mode != 2) return rc;
+    }
+    if (!wide) {
         TimedLaunch t("general_prepare", s);
         DGCN_LAUNCH(t, k_res_count, gb, tb, 0, s, a);
         if (int rc = check_launch("k_res_count")) return rc;
     }
-    if (!given) {
+    if (!wide && !given) {
         {
             TimedLaunch t("general_prepare", s);
             DGCN_LAUNCH(t, k_res_scan, dim3(1), dim3(1024), 0, s, a);
@@ -643,7 +666,7 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         if (int rc = big ? big_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s) : layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s))
             return rc;
     }
-    {
+    if (!wide) {
         TimedLaunch t("general_prepare", s);
         DGCN_LAUNCH(t, k_res_scatter, gb, tb, 0, s, a);
         if (int rc = check_launch("k_res_scatter")) return rc;

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     } else {
         stash = nullptr;
     }
+    if (fault) atomicOr(a.status, fault);
     __syncthreads();  // every chain has read its d^-1/2 and z1; the scores of this graph are visible to its workgroup
     // ---- priorities (mwis_dqn_call.py:230-235: float32 x float64 -> float64); a decided vertex: 0, takes part in nothing
     int bad = 0;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     if (__syncthreads_or(bad)) {
         // the reference would spin forever on a NaN priority (its argmax would pick it): report, leave the graph as it is
         if (threadIdx.x == 0) {
-            atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
+            atomicOr(a.status, DGCN_FAULT_NAN_PRIORITY);
             if (a.rounds) a.rounds[g] = -1;
             if (a.totals) a.totals[g] = 0.0;
             if (a.active) a.active[g] = 0;
@@ -301,7 +302,6 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
         if (a.progress) atomicAdd(a.progress, 1);
         if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)cnt);
     }
-    if (fault) atomicOr(a.status, fault);
     if (a.mode == 2) {  // the rollout's candidate / instance / completion / pick launches follow (general.hip)
         if (threadIdx.x == 0 && a.active) a.active[g] = 1;
         return;
@@ -392,13 +392,15 @@ int wide1_takes(const DgcnBatch* b, const DgcnModel* m) {
 template <int LPV>
 static int wide1_launch_l(const WideArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
-        static std::atomic<int> raised[64];
+        // (the dynamic limit is raised to what is asked for, not to the CU's 160 KB: the kernel's workgroup votes bring a few
+        // bytes of static LDS with them, and static + dynamic must fit)
+        static std::atomic<size_t> raised[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!raised[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide1<LPV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (raised[dev & 63].load(std::memory_order_relaxed) < lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide1<LPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_wide1: cannot reserve %zu bytes of LDS", lds);
-            raised[dev & 63].store(1, std::memory_order_relaxed);
+            raised[dev & 63].store(lds, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);

@@ -1,0 +1,49 @@
+"""Child process of tests/test_gpu_wide.py: complete dit / cit / rollout searches and a plain solve of a one-layer model on
+three ragged ~900-vertex graphs, results to an .npz.  Run twice - as it is (csrc/wide.hip) and with DGCN_WIDE1=0 (the
+layer-by-layer any-size path that served these shapes before) - the two files must hold the same bytes / bits."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(out_path):
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import Engine, DeviceModel
+    import scipy.sparse as sp
+    rng = np.random.default_rng(99)
+    mats, ws = [], []
+    for n in (900, 871, 640):
+        ip, ix = datagen.er_graph(n, 0.012, rng)
+        mats.append(sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(n, n)))
+        w = rng.random(n)
+        w[rng.random(n) < 0.05] = 0.0  # zero weights inside live graphs
+        ws.append(w)
+    hb = HostBatch.from_scipy(mats, ws)
+    layers = datagen.random_model(1, 32, bias=True, last_act="leaky_relu", seed=12)
+    eng = Engine("cuda:0")
+    db = eng.upload(hb)
+    dm = DeviceModel(layers, eng.device)
+    out = {}
+    r = eng.solve_fused(db, dm)
+    eng.check_status(r["status"])
+    out["plain_state"], out["plain_scores"] = r["state"].cpu().numpy(), r["scores"].cpu().numpy().ravel()
+    out["plain_rounds"], out["plain_totals"] = r["rounds"].cpu().numpy(), r["totals"].cpu().numpy()
+    for name, greedy, predict in (("dit", eng.GREEDY_ROUNDS, "mwis"), ("cit", eng.GREEDY_CENTRAL, "mwis"),
+                                  ("rollout", eng.GREEDY_ROLLOUT, "mwis"), ("dit_mis", eng.GREEDY_ROUNDS, "mis")):
+        state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
+        res = eng.solve_residual(db, dm, state, predict=predict, greedy=greedy, max_rounds=1, beam=5,
+                                 weight_features=predict != "mwis", want_scores=True)
+        eng.check_status(res["status"])
+        out[name + "_state"] = state.cpu().numpy()
+        out[name + "_steps"] = np.array([res["steps"]])
+        out[name + "_scores"] = res["scores"].cpu().numpy().ravel()
+    np.savez(out_path, **out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -610,7 +610,9 @@ def test_bench_contract(force_dist):
     assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    # (the C3 launch never leaves the chip: what paces k_fused is the LDS array + the fp32 MFMA pipe; `achieved` stays the
+    # SURVEY 8d equivalent bandwidth against the HBM peak - round-4 review, hygiene item)
+    assert rf["bound"] == "lds+mfma" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0.05 < rf["frac"] < 1.0
     assert d["value"] == pytest.approx(500 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
     cb = d["cpu_baseline"]

@@ -249,7 +249,9 @@ def test_big_rows_beyond_575_entries_vs_twin(engine, case):
 @pytest.mark.parametrize("which", ["dit", "cit", "rollout", "rollout1"])
 def test_big_graph_iterative_solvers_vs_oracle(engine, which):
     """solve_mwis_dit / _cit / _rollout on a 600-vertex graph and on ER(500, 0.1): entirely on the device (the any-size
-    path), decisions equal to the oracle's solvers fed with the twin's scores."""
+    path), decisions equal to the oracle's solvers fed with the TWIN's scores (`_twin_scores_fn`): the control flow is what
+    this pins - the forward is two hops from the reference here (HIP == twin bit for bit; twin vs restatement: the parity
+    tests); test_big_graph_iterative_solvers_restatement_forward runs the restatement's own forward."""
     import scipy.sparse as sp
     from distgcn_amd import datagen
     from distgcn_amd.mwis_gdpg_call import DQNAgent
@@ -272,6 +274,32 @@ def test_big_graph_iterative_solvers_vs_oracle(engine, which):
             want = orc.solve_mwis_rollout(fn, adj, w, b=4, by_priority=which == "rollout1")
         assert got[0][0] == want[0], (which, n)
         assert np.allclose(got[0][1], want[1], rtol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout"])
+def test_big_graph_iterative_solvers_restatement_forward(engine, which):
+    """test_big_graph_iterative_solvers_vs_oracle feeds the oracle's solvers with the TWIN's scores (control flow pinned by
+    the executed reference, the forward two hops away).  Here the same 600-vertex search against the oracle's solvers fed
+    with the restatement's own float32 forward (oracle/ref_numpy._default_scores_fn - the NumPy restatement of
+    gcn/layers.py:189-216, mwis_gdpg_call.py:211-216): one hop.  (On this graph no decision lies inside the two forwards'
+    rounding distance - the oracle's solvers select the same sets with either forward, checked on the CPU.)"""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(_flags(num_layer=3), seed=21)
+    fn = orc._default_scores_fn(agent.model.layers)
+    n, p = 600, 0.01
+    rng = np.random.default_rng(20230800 + 3)
+    indptr, indices = datagen.er_graph(n, p, rng)
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    w = rng.random(n)
+    got = agent.solve_iterative_batch([adj], [w], which, b=4)
+    assert got is not None
+    want = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit}[which](fn, adj, w) if which != "rollout" else \
+        orc.solve_mwis_rollout(fn, adj, w, b=4)
+    assert got[0][0] == want[0], which
+    assert np.allclose(got[0][1], want[1], rtol=1e-12)
 
 
 @pytest.mark.parametrize("n,p", [(900, 0.01), (1500, 0.004)])

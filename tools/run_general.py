@@ -25,7 +25,7 @@ eng.timing(True)
 for _ in range(iters):
     res = eng.solve_fused(db, model, want_scores=False, out=out)
 torch.cuda.synchronize(); eng.timing(False)
-for fam in ("supports", "big_forward", "big_solve", "lgs", "fused_solve"):
+for fam in ("supports", "big_forward", "big_solve", "lgs", "fused_solve", "wide_solve", "transform", "spmm", "layer"):
     ms, n = eng.timing_read(fam)
     if n:
         print("%s %s l=%d: %.1f us avg over %d launches" % (fam, kind, nl, ms / n * 1e3, n))
