@@ -218,25 +218,9 @@ def build_host_batch(args, rank, world):
 
 
 def multichannel_batch(count, nflows, p, first_index=0, n_ch=3, keep=0.8):
-    """Joint multi-channel conflict graphs as the reference's multi-channel scripts build them
-    (wireless_dqn_test_mc.py:159-161): a single-channel conflict graph (stand-in: ER(nflows, p), the topology generator
-    ``graph_util`` is absent from the reference), ``n_ch`` per-channel copies with every edge kept with probability ``keep``
-    (``multichannel_conflict_simulate``, wireless_rollout_test_flood.py:83-95) and the joint graph on ``n_ch * nflows``
-    vertices - the channels' graphs on the diagonal blocks plus a clique over every flow's copies (``:98-133``)."""
-    import scipy.sparse as sp
-    from distgcn_amd import datagen, wireless
-    from distgcn_amd.batch import HostBatch
-    ps, cs, ws = [], [], []
-    for g in range(first_index, first_index + count):
-        rng = np.random.default_rng(datagen.SEED0 + 2_000_000 + g)
-        ip, ix = datagen.er_graph(nflows, p, rng)
-        base = sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(nflows, nflows))
-        chans = wireless.multichannel_conflict_simulate(base, k=n_ch, p=keep, rng=np.random.RandomState(datagen.SEED0 % 100000 + g))
-        _, joint = wireless.multichannel_conflict_graph(chans)
-        ps.append(joint.indptr.astype(np.int64))
-        cs.append(joint.indices.astype(np.int64))
-        ws.append(rng.random(n_ch * nflows))
-    return HostBatch.from_csr_lists(ps, cs, ws)
+    """(moved to distgcn_amd/datagen.py: the parity configurations use the same generator)"""
+    from distgcn_amd import datagen
+    return datagen.multichannel_batch(count, nflows, p, first_index=first_index, n_ch=n_ch, keep=keep)
 
 
 def graph_sizes(args):

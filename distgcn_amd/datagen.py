@@ -96,3 +96,24 @@ def random_model(num_layer: int, hidden: int, feature_size: int = 1, out_dim: in
         act = last_act if i == num_layer - 1 else "leaky_relu"
         layers.append({"weights": ws, "bias": b, "act": act})
     return layers
+
+
+def multichannel_batch(count, nflows, p, first_index=0, n_ch=3, keep=0.8):
+    """Joint multi-channel conflict graphs as the reference's multi-channel scripts build them
+    (wireless_dqn_test_mc.py:159-161): a single-channel conflict graph (stand-in: ER(nflows, p), the topology generator
+    ``graph_util`` is absent from the reference), ``n_ch`` per-channel copies with every edge kept with probability ``keep``
+    (``multichannel_conflict_simulate``, wireless_rollout_test_flood.py:83-95) and the joint graph on ``n_ch * nflows``
+    vertices - the channels' graphs on the diagonal blocks plus a clique over every flow's copies (``:98-133``)."""
+    import scipy.sparse as sp
+    from . import wireless
+    ps, cs, ws = [], [], []
+    for g in range(first_index, first_index + count):
+        rng = np.random.default_rng(SEED0 + 2_000_000 + g)
+        ip, ix = er_graph(nflows, p, rng)
+        base = sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(nflows, nflows))
+        chans = wireless.multichannel_conflict_simulate(base, k=n_ch, p=keep, rng=np.random.RandomState(SEED0 % 100000 + g))
+        _, joint = wireless.multichannel_conflict_graph(chans)
+        ps.append(joint.indptr.astype(np.int64))
+        cs.append(joint.indices.astype(np.int64))
+        ws.append(rng.random(n_ch * nflows))
+    return HostBatch.from_csr_lists(ps, cs, ws)

@@ -86,6 +86,7 @@ def summarize(reports):
             "abs_restatement_max_err_vs_f64": float(max(r["a3264"] for r in reports)),
             "sets_differing": int(sum(r["set_differs"] for r in reports)),
             "sets_differing_not_flagged_by_margin": int(sum(r["set_differs"] and r["risk_at_2e"] == 0 for r in reports)),
+            "sets_differing_ids": [i for i, r in enumerate(reports) if r["set_differs"]],
             "graphs_at_margin_risk_at_2x_error": int(sum(r["risk_at_2e"] > 0 for r in reports))}
 
 
@@ -107,6 +108,16 @@ def full_size_configs():
         "C4-l1": ("4000 BA test2 mix, DQNBA l=1", 4000, m % ("DQNBA", 1), lambda c, f: datagen.ba_test2_batch(c, first_index=f)),
         "C4-l20": ("4000 BA test2 mix, DQNBA l=20", 4000, m % ("DQNBA", 20), lambda c, f: datagen.ba_test2_batch(c, first_index=f)),
         "C5-size": ("64 ER N=500 p=0.02, IS4SAT l=20", 64, m % ("IS4SAT", 20), lambda c, f: datagen.er_batch(c, 500, 0.02, first_index=f)),
+        # the any-size path's own sizes (csrc/big.hip, wide.hip, the layer-by-layer chain beyond 976 vertices): the shapes of
+        # bench.py --config ER500 / MC900 / MC900-l1 / MC1500 and a sparse 1 500-vertex ER batch
+        "ER500": ("64 ER N=500 p=0.1, IS4SAT l=20", 64, m % ("IS4SAT", 20), lambda c, f: datagen.er_batch(c, 500, 0.1, first_index=f)),
+        "MC900": ("256 joint 3 x 300-flow conflict graphs, IS4SAT l=20", 256, m % ("IS4SAT", 20),
+                  lambda c, f: datagen.multichannel_batch(c, 300, 0.03, first_index=f)),
+        "MC900-l1": ("256 joint 3 x 300-flow conflict graphs, IS4SAT l=1", 256, m % ("IS4SAT", 1),
+                     lambda c, f: datagen.multichannel_batch(c, 300, 0.03, first_index=f)),
+        "N1500": ("64 ER N=1500 p=0.004, IS4SAT l=20", 64, m % ("IS4SAT", 20), lambda c, f: datagen.er_batch(c, 1500, 0.004, first_index=f)),
+        "MC1500": ("64 joint 3 x 500-flow conflict graphs, IS4SAT l=20", 64, m % ("IS4SAT", 20),
+                   lambda c, f: datagen.multichannel_batch(c, 500, 0.03, first_index=f)),
     }
 
 
@@ -157,6 +168,7 @@ def scores_report(name, count, graph_ptr, scores, state, procs=None, chunk=64):
 def twin_report(name, procs=None, chunk=125):
     """The whole configuration on the CPU twin, in forked workers -> (summary dict, per-graph reports)."""
     _, total, _, _ = full_size_configs()[name]
+    chunk = min(chunk, max(8, (total + 7) // 8))  # (small configurations still use every worker)
     jobs = [(name, f, min(chunk, total - f)) for f in range(0, total, chunk)]
     procs = procs or min(len(jobs), max(1, (os.cpu_count() or 2) - 0), 8)
     if procs <= 1:

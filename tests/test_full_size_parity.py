@@ -5,7 +5,8 @@ test_c4_full_batch_and_its_eight_shards) and holds their output against the rest
 (tests/test_gpu_full_size.py::test_full_size_scores_against_the_restatement_on_gpu); here the twin's
 scores and sets for EVERY graph of C2, C3, C4 (all 4 000 graphs, DQNBA l=1 and l=20) and a C5-sized batch are held
 against oracle/ref_numpy (float32 and float64 restatements of the reference's formula, one graph per call) and the
-reference's local greedy search on the restatement's priorities.  oracle/parity.py does the work in forked
+reference's local greedy search on the restatement's priorities - and, since round 5, the any-size path's own sizes: ER500,
+MC900 (l = 20 and the multi-channel launcher's l = 1), a sparse 1 500-vertex ER batch and the joint 3 x 500-flow graphs.  oracle/parity.py does the work in forked
 processes (about a minute on 8 cores); tools/parity_full_size.py writes the same numbers to profiles/.
 """
 import numpy as np
@@ -18,6 +19,7 @@ CONFIGS = list(parity.full_size_configs())
 # them that restatement is the one further from the float64 evaluation (asserted below)
 C4_L20_OVER_F32 = [115, 945, 995, 1105, 1670, 1945, 2280, 2770]
 C4_L20_OVER_F32_ABS = [115, 890, 945, 995, 1105, 1670, 1945, 2280, 2770]
+SETS_DIFFERING = {"MC900": [182]}  # graphs whose set differs from the search on the float32 restatement's priorities (all margin-flagged)
 
 
 @pytest.mark.parametrize("name", CONFIGS)
@@ -41,7 +43,12 @@ def test_full_size_scores_and_sets_against_the_restatement(name):
         assert summ["max_err_vs_f32_restatement"] <= 1.61e-5 and summ["abs_max_err_vs_f32_restatement"] <= 1.61e-5, summ
         assert summ["abs_max_err_vs_f64"] <= 7.4e-6 and summ["abs_graphs_over_1e-5_vs_f64"] == 0, summ
         assert summ["max_err_vs_f64"] < 0.5 * summ["restatement_max_err_vs_f64"], summ  # the kernels' order is the more exact one
-    # (3) selected sets: identical to the reference's local_greedy_search on the restatement's priorities, all graphs
-    assert summ["sets_differing"] == 0, summ
+    # (3) selected sets: identical to the reference's local_greedy_search on the restatement's priorities, all graphs -
+    #     but ONE: graph 182 of the 256 joint 3 x 300-flow graphs (MC900, l = 20) holds a near-tie the two float32 evaluations
+    #     resolve differently (scores within 8.3e-6 of each other; SURVEY 7.3 predicted such flips at this scale).  Every flip
+    #     must be one the margin test flags (an excluded vertex whose exclusion does not survive twice the measured error) -
+    #     a flip it does not flag would be a wrong set, not a near-tie
+    assert summ["sets_differing_ids"] == SETS_DIFFERING.get(name, []), summ
+    assert summ["sets_differing_not_flagged_by_margin"] == 0, summ
     # the per-graph margin report is consistent: a graph whose set could change under twice the measured error is flagged
     assert all(r["risk_at_2e"] >= 0 for r in reports)

@@ -10,7 +10,11 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SHARE = {"C2": 500, "C3": 500, "C4-l1": 500, "C4-l20": 500, "C5-size": 64}  # graphs solved on the GPU per configuration
+# graphs solved on the GPU per configuration; from ER500 on: the any-size path at its own sizes (k_big, k_wide1, the
+# layer-by-layer chain / k_big2 beyond 976 vertices)
+SHARE = {"C2": 500, "C3": 500, "C4-l1": 500, "C4-l20": 500, "C5-size": 64,
+         "ER500": 64, "MC900": 256, "MC900-l1": 256, "N1500": 64, "MC1500": 64}
+SETS_DIFFERING = {"MC900": [182]}  # a near-tie the two float32 evaluations resolve differently; flagged by the margin test (asserted)
 
 
 @pytest.mark.parametrize("name", sorted(SHARE))
@@ -35,5 +39,9 @@ def test_full_size_scores_against_the_restatement_on_gpu(engine, name):
     #     restatement 1.07e-5) - tests/test_full_size_parity.py lists all eight of the 4 000
     assert summ["graphs_over_1e-5_vs_f32_restatement"] == summ["of_those_restatement_further_from_f64"], summ
     assert summ["graphs_over_1e-5_vs_f32_restatement_ids"] == ([115] if name == "C4-l20" else []), summ
-    # (3) the selected sets: identical to the reference's local greedy search on the restatement's priorities, every graph
-    assert summ["sets_differing"] == 0, summ
+    # (3) the selected sets: identical to the reference's local greedy search on the restatement's priorities, every graph -
+    #     except MC900's graph 182 (tests/test_full_size_parity.py), and every flip must be margin-flagged
+    assert summ["sets_differing_ids"] == SETS_DIFFERING.get(name, []), summ
+    assert summ["sets_differing_not_flagged_by_margin"] == 0, summ
+    if name in ("ER500", "MC900", "MC900-l1", "N1500", "MC1500"):
+        assert engine.solve_path(db, dm) == 2
