@@ -483,7 +483,9 @@ def roofline_objects(args, wl, fam_ms):
             # the resources that actually pace these kernels are on the chip (the graph never leaves it): the LDS array (one
             # 128-byte row of Z1 per entry and hidden layer) and the fp32 MFMA pipe - printed beside the SURVEY 8d figure
             lds_bytes = float(sum(128.0 * nnz_l for lyr in layers[1:-1] if lyr["weights"][0].shape[1] == 32))
-            kname = ("k_big (big_solve: whole path of graphs beyond the fused kernel's LDS budget - supports, every layer, priority, greedy search - one launch per step)"
+            kname = ("k_big2 (big_solve: whole path of graphs of 977 .. 1 920 vertices - Z1 in LDS a feature half at a time, two walks per aggregation - supports, every layer, priority, greedy search, one launch per step)"
+                     if dom == "big_solve" and hb.max_nodes > 976 else
+                     "k_big (big_solve: whole path of graphs beyond the fused kernel's LDS budget - supports, every layer, priority, greedy search - one launch per step)"
                      if dom == "big_solve" else
                      "k_big (whole forward of graphs beyond the fused kernel's LDS budget, one launch per step; supports and greedy search in launches of their own)"
                      if dom == "big_forward" else

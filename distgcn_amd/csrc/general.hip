@@ -45,6 +45,16 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
               int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
               hipStream_t s);
 
+// big2.hip: the same for graphs of 977 .. 1 920 vertices (Z1 a feature half at a time)
+int big2_takes(const DgcnBatch* b, const DgcnModel* m);
+size_t big2_workspace(const DgcnBatch* b, const DgcnModel* m);
+int big2_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, const float* X, float x_const, float* scores,
+                 void* lws, void* bws, int32_t* status, hipStream_t s);
+int big2_solve_takes(const DgcnBatch* b, const DgcnModel* m, const float* X);
+int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+               int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
+               hipStream_t s);
+
 // wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
 // in one launch
 int wide1_takes(const DgcnBatch* b, const DgcnModel* m);
@@ -525,7 +535,7 @@ size_t general_workspace(const DgcnBatch* b, const DgcnModel* m) {
     need += al256(n * (size_t)model_in_dim(m) * 4);                      // features of the compact batch
     need += al256(n * 4) + al256(n * 4);                                 // compact scores, full scores when the caller wants none
     need += al256(n * 8);                                                // priorities
-    need += al256(layered_bytes(b, m)) + al256(big_workspace(b, m));
+    need += al256(layered_bytes(b, m)) + al256(std::max(big_workspace(b, m), big2_workspace(b, m)));
     need += al256(B * kMaxBeam * 4) + 2 * al256((size_t)kMaxBeam * n) + al256((size_t)kMaxBeam * B * 4) + al256((size_t)kMaxBeam * B * 8);
     return need;
 }
@@ -566,18 +576,22 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     float* sc = scores ? scores : w.take<float>(n);
     const size_t fbytes = layered_bytes(b, m);
     char* fws = w.take<char>(fbytes);
-    const bool big = big_takes(b, m) != 0;
-    char* bws = big ? w.take<char>(big_workspace(b, m)) : nullptr;
+    const bool big2 = big2_takes(b, m) != 0;  // (977 .. 1 920 vertices; with DGCN_BIG2=1 every shape k_big takes too)
+    const bool big = !big2 && big_takes(b, m) != 0;
+    char* bws = big ? w.take<char>(big_workspace(b, m)) : big2 ? w.take<char>(big2_workspace(b, m)) : nullptr;
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
-    // constant input features on k_big's shapes: the whole path - supports, every layer, priority, greedy search - in ONE launch
+    // constant input features on k_big's / k_big2's shapes: the whole path - supports, every layer, priority, greedy search - in ONE launch
     if (big && big_solve_takes(b, m, X))
         return big_solve(b, m, dinv_table, table_len, x_const, weights, predict_mwis, sc, state, rounds, totals, status, bws, s);
+    if (big2 && big2_solve_takes(b, m, X))
+        return big2_solve(b, m, dinv_table, table_len, x_const, weights, predict_mwis, sc, state, rounds, totals, status, bws, s);
     int rc = dgcn_supports_batch(b, dinv_table, table_len, lrow, lcol, lval, status, s);
     if (rc) return rc;
     DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, lrow, lcol, lval};
     const DgcnCsr* sup[1] = {&L};
-    if ((rc = big ? big_forward(b, &L, m, X, x_const, sc, fws, bws, status, s) : layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
+    if ((rc = big ? big_forward(b, &L, m, X, x_const, sc, fws, bws, status, s)
+              : big2 ? big2_forward(b, &L, m, X, x_const, sc, fws, bws, status, s) : layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
     return lgs_launch_common(b, nullptr, 0, sc, (predict_mwis && weights) ? weights : nullptr, nullptr, 1, 0, state, rounds, nullptr,
                              nullptr, weights, totals, status, s, nullptr);
 }
@@ -613,8 +627,9 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     a.prio = w.take<double>(n);
     const size_t fbytes = layered_bytes(b, m);
     char* fws = w.take<char>(fbytes);
-    const bool big = big_takes(b, m) != 0;
-    char* bws = big ? w.take<char>(big_workspace(b, m)) : nullptr;
+    const bool big2 = big2_takes(b, m) != 0;
+    const bool big = !big2 && big_takes(b, m) != 0;
+    char* bws = big ? w.take<char>(big_workspace(b, m)) : big2 ? w.take<char>(big2_workspace(b, m)) : nullptr;
     a.cid = w.take<int32_t>(B * kMaxBeam);
     uint8_t* inst_state = nullptr;
     int32_t* inst_rounds = nullptr;
@@ -663,7 +678,8 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         cb.col_idx = nullptr;
         DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, a.lrow, a.lcol, a.lval};
         const DgcnCsr* sup[1] = {&L};
-        if (int rc = big ? big_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s) : layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s))
+        if (int rc = big ? big_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s)
+                     : big2 ? big2_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s) : layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s))
             return rc;
     }
     if (!wide) {

@@ -3,4 +3,4 @@
 # Not part of the product: built on demand, selected with DGCN_LIB=distgcn_amd/libdgcn_diag.so.
 cd "$(dirname "$0")/../distgcn_amd/csrc" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DDGCN_DIAG -Wl,-z,defs \
   -o ../libdgcn_diag.so runtime.hip pack.hip supports.hip supports2.hip spmm.hip transform.hip layer.hip forward.hip lgs.hip fused.hip \
-  shallow.hip expand.hip host_solver.hip general.hip big.hip tail.hip wide.hip
+  shallow.hip expand.hip host_solver.hip general.hip big.hip tail.hip wide.hip big2.hip

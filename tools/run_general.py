@@ -11,8 +11,9 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nl = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 if kind == "mc900":
-    import bench
-    hb = bench.multichannel_batch(B, 300, 0.03)
+    hb = datagen.multichannel_batch(B, 300, 0.03)
+elif kind == "mc1500":
+    hb = datagen.multichannel_batch(B, 500, 0.03)
 elif kind == "er500":
     hb = datagen.er_batch(B, 500, 0.1)
 else:

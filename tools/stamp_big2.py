@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Phase clocks of k_big2 (needs the -DDGCN_DIAG build): DGCN_LIB=distgcn_amd/libdgcn_diag.so python tools/stamp_big2.py mc1500|erNxP [layers=20] [graphs=256]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from distgcn_amd import datagen
+from distgcn_amd.engine import Engine, DeviceModel
+kind = sys.argv[1] if len(sys.argv) > 1 else "mc1500"
+nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+if kind == "mc1500":
+    hb = datagen.multichannel_batch(B, 500, 0.03)
+else:
+    n, p = kind[2:].split("x")
+    hb = datagen.er_batch(B, int(n), float(p))
+eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
+out = eng.solve_buffers(db, False)
+for _ in range(10): eng.solve_fused(db, model, want_scores=False, out=out)
+torch.cuda.synchronize()
+st = torch.zeros(hb.num_graphs * 16, dtype=torch.int64, device="cuda")
+os.environ["DGCN_BIG_STAMPS"] = str(st.data_ptr())
+eng.solve_fused(db, model, want_scores=False, out=out); torch.cuda.synchronize()
+os.environ.pop("DGCN_BIG_STAMPS")
+raw = st.cpu().numpy().astype(np.float64).reshape(-1, 16)
+names = ["row lengths, order, tiles, d^-1/2", "records", "layer 0", "S1: Z1 lo = H.W (sum)", "  barrier", "S2: lo walks (sum)", "  barrier",
+         "S3: Z1 hi (sum)", "  barrier", "S4: hi walks, Z0, epilogue (sum)", "  barrier", "last layer walk, search, totals"]
+wall = (raw[:, 13] - raw[:, 12]) / 100.0
+ghz = raw[:, :12].sum(axis=1) / wall / 1e3
+print("%s, %d graphs, %d layers: wave 0 of every workgroup, microseconds at the measured %.2f GHz: mean / max" % (kind, B, nl, ghz.mean()))
+for i, nm in enumerate(names):
+    us = raw[:, i] / (ghz.mean() * 1e3)
+    print("%-42s %8.2f %8.2f" % (nm, us.mean(), us.max()))
+print("%-42s %8.2f %8.2f" % ("workgroup wall time (100 MHz clock)", wall.mean(), wall.max()))
