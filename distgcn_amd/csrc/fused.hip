@@ -80,6 +80,7 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
+    int32_t stagger;           // tuning experiment (DGCN_FUSED_STAGGER, units of 1 024 cycles): the second workgroup of a CU starts this much later
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
@@ -1029,6 +1030,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     // 4 955 vs 4 182 hundred cycles per graph), and the launch ends with the slower one.
     const bool second = (blockIdx.x >> 8) & 1;
     if (a.prio_second && second) __builtin_amdgcn_s_setprio(1);
+    // (round-4 review: start the second co-resident workgroup half a layer late, so that one's MFMA phase meets the other's
+    // LDS phase by construction rather than by drift.  Measured in round 5, DESIGN 9: no gain - off unless the variable is set.)
+    if (a.stagger > 0 && second)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     unsigned long long tclk = 0;
 #ifdef DGCN_DIAG
     tclk = __builtin_amdgcn_s_memtime();
@@ -2355,6 +2360,7 @@ static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* fam
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
     a.prio_gather = getenv("DGCN_FUSED_PRIOG") ? atoi(getenv("DGCN_FUSED_PRIOG")) : 1;
     a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 5;
+    a.stagger = getenv("DGCN_FUSED_STAGGER") ? atoi(getenv("DGCN_FUSED_STAGGER")) : 0;
 #ifdef DGCN_DIAG
     if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
 #endif
