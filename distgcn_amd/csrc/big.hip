@@ -58,7 +58,8 @@ namespace dgcn {
 
 // TILES: sixteen-row tiles a wave keeps in registers (4: up to 64 BLOCK / 64 tiles; 2: half of that, and the freed registers hold
 // a second group of records in flight: the walk asks for its records TWO groups of four trips ahead)
-template <int BLOCK, int TILES>
+// RESID: compiled with the residual-step code (big_residual); the plain kernels do not carry its state through their loops
+template <int BLOCK, int TILES, bool RESID = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_big(BigArgs a) {
     constexpr int kWavesB = BLOCK / 64;
     constexpr int DEPTH = TILES == 2 ? 2 : 1;
@@ -80,7 +81,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     int* ttrips = reinterpret_cast<int*>(big_lds + a.lds_tab_off);                    // [64] trips per tile
     unsigned* tbase = reinterpret_cast<unsigned*>(ttrips + 64);                        // [64] first record of a tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles = (ng + 15) >> 4;
     uint2* rec = a.rec + (size_t)g * a.rec_cap;
     int fault = 0;
 #ifdef DGCN_DIAG
@@ -89,6 +89,39 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)g * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // ---- (residual step) which vertices are undecided, is anything left to do: the alive bytes sit in the Z1 space until the
+    // first transform writes there
+    constexpr bool resid = RESID;
+    uint8_t* alive = reinterpret_cast<uint8_t*>(big_lds);
+    int nr = ng;  // rows of the (residual) graph: its undecided vertices
+    if (resid) {
+        if (threadIdx.x < 2) ttrips[threadIdx.x] = 0;
+        __syncthreads();
+        int c_al = 0, pos = 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {
+            const bool al = a.state[n0 + v] == 0;
+            alive[v] = al ? 1 : 0;
+            c_al += al;
+            pos |= al && (a.weights ? a.weights[n0 + v] : 1.0) > 0.0;
+        }
+        if (c_al) atomicAdd(&ttrips[0], c_al);
+        if (pos) atomicOr(&ttrips[1], 1);
+        __syncthreads();
+        nr = ttrips[0];
+        const int any_pos = ttrips[1];
+        __syncthreads();  // (the tile table's space is written again below)
+        // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286): the graph is left alone
+        if (!any_pos) {
+            if (threadIdx.x == 0) {
+                if (a.rounds) a.rounds[g] = 0;
+                if (a.totals) a.totals[g] = 0.0;
+                if (a.active) a.active[g] = 0;
+            }
+            for (int v = threadIdx.x; v < ng; v += BLOCK) a.scores[n0 + v] = 0.f;
+            return;
+        }
+    }
+    const int tiles = (nr + 15) >> 4;
     // ---- P0: row lengths, row order (counting sort, descending), Z1 of the first aggregation into LDS
     // One bin per possible entry count (a row of a 976-vertex graph has at most 977 entries; a caller's matrix with repeated
     // columns may exceed that: such rows share the last bin, and a tile's trips are the maximum over its sixteen rows, so no
@@ -97,7 +130,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     if (threadIdx.x < 32) reinterpret_cast<float*>(big_lds + zrow)[threadIdx.x] = 0.f;
     __syncthreads();
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
-        const unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
+        unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
+        if (resid) {
+            // degree in the residual graph; a decided vertex has no row at all (count 0: it sorts behind every undecided one)
+            c = 0;
+            if (alive[v]) {
+                c = 1;
+                const int rs = a.arow[n0 + v], re = a.arow[n0 + v + 1];
+#pragma unroll 4
+                for (int j = rs; j < re; ++j) {
+                    const int u = a.acol[j] - n0;
+                    if ((unsigned)u < (unsigned)ng) c += alive[u];
+                }
+            }
+        }
         cnt[v] = (unsigned short)min(c, 65535u);
         atomicAdd(&hist[min((int)c, kBigBins - 1)], 1);
     }
@@ -142,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const int sl = lane * 16 + j;
-                if (sl < ng) longest = max(longest, (int)cnt[perm[sl]]);
+                if (sl < nr) longest = max(longest, (int)cnt[perm[sl]]);
             }
         }
         const int tl = lane < tiles ? max(1, (longest + 3) >> 2) : 0;
@@ -167,7 +213,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         for (int v = threadIdx.x; v < ng; v += BLOCK) {
             const int d = (int)cnt[v] - 1;
             double x = 0.0;
-            if (d < a.table_len) x = a.dinv[d]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+            if (d >= a.table_len) fault |= DGCN_FAULT_DEGREE_RANGE;
+            else if (d >= 0) x = a.dinv[d];  // (a decided vertex of a residual step has no row: nobody reads its slot)
             dvl[v] = x;
         }
     }
@@ -179,13 +226,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);
         const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);
         const int slot = t * 16 + s16;
-        const bool has = slot < ng;
+        const bool has = slot < nr;
         const int v = has ? (int)perm[slot] : 0;
         const int start = has ? (a.arow ? a.arow[n0 + v] : a.lrow[n0 + v]) : 0;
         const int c = has ? (a.arow ? a.arow[n0 + v + 1] - start + 1 : a.lrow[n0 + v + 1] - start) : 0;
         const double dv = (a.arow && has) ? dvl[v] : 0.0;
         uint2* out = rec + base + lane;
         const uint2 nothing = make_uint2(0x80000000u, zrow);  // {-0.0f, zero row}: fmaf(-0.0f, +0.0f, acc) == acc for every acc
+        if (resid) {
+            // The row of the RESIDUAL graph: the diagonal, then the undecided neighbours in CSR order - the re-sliced row of
+            // mwis_gdpg_call.py:284-285 without re-slicing.  The row's four lanes take four raw entries at a time, keep the undecided
+            // ones and place them by a prefix count within the quad (entry p of the row is record 64 (p >> 2) + 4 s16 + (p & 3) of
+            // the tile: written by whichever lane finds it, read by lane p & 3 of the quad after the workgroup barrier below).
+            uint2* rowout = rec + base + s16 * 4;
+            const int raw = has ? c - 1 : 0;
+            if (has && kq4 == 0) rowout[0] = make_uint2(__float_as_uint(1.0f), big_word(v));
+            int pos = has ? 1 : 0;
+            for (int j0 = 0; __any(j0 < raw); j0 += 4) {  // (every lane of the wave takes part in the ballot)
+                const int j = j0 + kq4;
+                int u = -1;
+                if (j < raw) {
+                    u = a.acol[start + j] - n0;
+                    if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = -1; }
+                    else {
+                        if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                        if (!alive[u]) u = -1;
+                    }
+                }
+                const bool keep = u >= 0;
+                const unsigned q = (unsigned)(__ballot(keep) >> (lane & ~3)) & 0xfu;
+                if (keep) {
+                    const int p = pos + __popc(q & ((1u << kq4) - 1u));
+                    if (p < 4 * trips) rowout[(p >> 2) * 64 + (p & 3)] = make_uint2(__float_as_uint((float)(-(dvl[u] * dv))), big_word(u));
+                }
+                pos += __popc(q);
+            }
+            for (int p = pos + kq4; p < 4 * trips; p += 4) rowout[(p >> 2) * 64 + (p & 3)] = nothing;
+        } else
         for (int t0 = 0; t0 < trips; t0 += 4) {  // four trips' loads in flight (the walk is a chain of global round trips otherwise)
             int uu[4];
             float vv[4];
@@ -249,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         const int t = wave + kWavesB * k;                                                                              \
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);                                                   \
         const int slot = t * 16 + s16;                                                                                 \
-        const bool has = slot < ng;                                                                                    \
+        const bool has = slot < nr;                                                                                    \
         (void)has;
     // The records of a wave's tiles are one stream of GROUPS (four trips each, tile after tile); every trip needs a record
     // from global memory (L2 / MALL: 500 .. 2 000 cycles), so the stream is requested DEPTH groups ahead of the walk - a
@@ -382,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                     zo[2 * cp + 1] = make_float4((float)acc1[0], (float)acc1[1], (float)acc1[2], (float)acc1[3]);
                 }
                 const int mslot = t * 16 + mr;
-                if (mslot < ng) {
+                if (mslot < nr) {
                     const int v = (int)perm[mslot];
                     *reinterpret_cast<float4*>(bufB + v * kBH + ((mq ^ big_key(v)) << 2)) = zo[2];
                     *reinterpret_cast<float4*>(bufB + v * kBH + (((4 + mq) ^ big_key(v)) << 2)) = zo[3];
@@ -495,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfrag[s][ct], pz[k][s], acc[ct], 0, 0, 0);
                 const int mslot = t * 16 + mr;
-                if (mslot < ng) {
+                if (mslot < nr) {
                     const int v = (int)perm[mslot];
 #pragma unroll
                     for (int ct = 2; ct < 4; ++ct) {
@@ -518,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #pragma unroll
     for (int k = 0; k < TILES; ++k) {
         const int slot = (wave + kWavesB * k) * 16 + s16;
-        if (slot < ng && kq4 == 0) zl[perm[slot]] = zz1[k];
+        if (slot < nr && kq4 == 0) zl[perm[slot]] = zz1[k];
     }
     if (threadIdx.x == 0) zl[a.max_nodes] = 0.f;  // the neutral record's neighbour
     __syncthreads();
@@ -571,10 +648,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         __syncthreads();  // every score of the graph is computed, every walk over z1 done
         const int W64 = (ng + 63) >> 6;
         const int tv = threadIdx.x;
+        // (residual step) who takes part: the vertices that were undecided when the launch began (read again: the Z1 space held the
+        // alive bytes only until the first transform).  A decided vertex reports score 0 and carries a NaN priority - never ahead
+        // of anybody in the masks below.
+        bool part = tv < ng;
+        if (resid && tv < ng) {
+            part = a.state[n0 + tv] == 0;
+            if (!part) {
+                a.scores[n0 + tv] = 0.f;
+                pr[tv] = __longlong_as_double(0x7ff8000000000001ll);
+            }
+        }
         int bad = 0;
         if (tv < ng) {
             const double p = pr[tv];
-            bad = p != p;
+            bad = part && p != p;
             st[tv] = 0;
         }
         // (no __syncthreads_or: ockl's workgroup reductions bring static LDS with them, and bufB must stay at LDS offset 0)
@@ -587,22 +675,77 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                 atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
                 if (a.rounds) a.rounds[g] = -1;
                 if (a.totals) a.totals[g] = 0.0;
+                if (a.active) a.active[g] = 0;
             }
-            for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = 0;
+            if (!resid) for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = 0;
+            return;
+        }
+        if (resid && threadIdx.x == 0) {
+            if (a.progress) atomicAdd(a.progress, 1);
+            if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)nr);
+        }
+        if (resid && a.greedy_mode == 2) {
+            // the rollout: priorities out (a decided vertex: 0, as k_res_scatter leaves it); candidates, instances, completions
+            // and the pick are general.hip's launches
+            if (tv < ng) a.prio_out[n0 + tv] = part ? pr[tv] : 0.0;
+            if (threadIdx.x == 0 && a.active) a.active[g] = 1;
+            if (fault) atomicOr(a.status, fault);
+            return;
+        }
+        if (resid && a.greedy_mode == 1) {
+            // solve_mwis_cit: the best-priority undecided vertex joins (np.argmax: lowest index among equals), its neighbours leave
+            double bp = part ? pr[tv] : 0.0;
+            int bv = part ? tv : -1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double op = __shfl_xor(bp, off);
+                const int ov = __shfl_xor(bv, off);
+                if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+            }
+            int* ri = reinterpret_cast<int*>(red + 16);
+            if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = bp; ri[threadIdx.x >> 6] = bv; }
+            __syncthreads();
+            bp = red[0]; bv = ri[0];
+#pragma unroll
+            for (int w = 1; w < BLOCK / 64; ++w) {
+                const double op = red[w];
+                const int ov = ri[w];
+                if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+            }
+            if (bv >= 0) {
+                for (int j = a.arow[n0 + bv] + (int)threadIdx.x; j < a.arow[n0 + bv + 1]; j += BLOCK) {
+                    const int u = a.acol[j] - n0;
+                    if ((unsigned)u < (unsigned)ng && u != bv && a.state[n0 + u] == 0) a.state[n0 + u] = 2;
+                }
+                if (threadIdx.x == 0) {
+                    a.state[n0 + bv] = 1;
+                    if (a.rounds) a.rounds[g] = 1;
+                    if (a.totals) a.totals[g] = a.weights ? a.weights[n0 + bv] : bp;
+                }
+            }
+            if (fault) atomicOr(a.status, fault);
             return;
         }
         lgs_mask_build<BLOCK>(a.arow, a.acol, n0, ng, pr, am, W64);
-        const int rounds = lgs_mask_rounds<BLOCK>(tv, tv < ng, am, W64, liveA, liveB, wonm, st, 0);
+        const int rounds = lgs_mask_rounds<BLOCK>(tv, part, am, W64, liveA, liveB, wonm, st, resid ? a.max_rounds : 0);
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
         {
-            // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots)
-            double part = 0.0;
+            // state out; total weight of the set: the reduction tree of k_lgs<.., 1024> (strided partials, folded to 256 slots).
+            // A residual step writes what it decided and counts what joined in THIS step; whoever was decided before stays as it was.
+            double partial = 0.0;
             for (int v = threadIdx.x; v < ng; v += BLOCK) {
                 const uint8_t s1 = st[v];
-                if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
-                a.state[n0 + v] = s1;
+                if (resid) {
+                    if (s1 != 0) {  // (only vertices that took part get a state in the rounds)
+                        if (a.totals && s1 == 1) partial += a.weights ? a.weights[n0 + v] : pr[v];
+                        a.state[n0 + v] = s1;
+                    }
+                } else {
+                    if (a.totals && s1 == 1) partial += a.weights ? a.weights[n0 + v] : pr[v];
+                    a.state[n0 + v] = s1;
+                }
             }
-            red[threadIdx.x] = part;
+            red[threadIdx.x] = partial;
         }
         if (a.totals) {
             __syncthreads();
@@ -797,20 +940,20 @@ static void big_fill_model(BigArgs& a, const DgcnModel* m, float x_const) {
     }
 }
 
-template <int BLOCK, int TILES>
+template <int BLOCK, int TILES, bool RESID = false>
 static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<int> reserved[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big<BLOCK, TILES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big<BLOCK, TILES, RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_big: cannot reserve %zu bytes of LDS", lds);
             reserved[dev & 63].store(1, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_big<BLOCK, TILES>), dim3((unsigned)B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_big<BLOCK, TILES, RESID>), dim3((unsigned)B), dim3(BLOCK), lds, s, a);
     return check_launch("k_big");
 }
 
@@ -822,6 +965,10 @@ static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* fami
 #endif
     // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
     const bool two = a.max_nodes <= 16 * 2 * (block / 64) && big_env_tiles() != 4;
+    if (a.residual) {
+        if (block == 512) return two ? big_launch_b<512, 2, true>(a, B, lds, family, s) : big_launch_b<512, 4, true>(a, B, lds, family, s);
+        return two ? big_launch_b<1024, 2, true>(a, B, lds, family, s) : big_launch_b<1024, 4, true>(a, B, lds, family, s);
+    }
     if (block == 512) return two ? big_launch_b<512, 2>(a, B, lds, family, s) : big_launch_b<512, 4>(a, B, lds, family, s);
     return two ? big_launch_b<1024, 2>(a, B, lds, family, s) : big_launch_b<1024, 4>(a, B, lds, family, s);
 }
@@ -852,6 +999,48 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
                        big_lgs_lds(a.max_nodes, b->max_graph_edges));
     }
     return big_launch(a, b->num_graphs, lds, block, "big_solve", s);
+}
+
+// One step of dgcn_solve_residual_batch in ONE launch (constant input features, k_big's shapes): the residual graph's support
+// from the adjacency and the running state, every layer, priorities, and the greedy step - local rounds (solve_mwis_dit,
+// mwis_gdpg_call.py:278-318) or the central pick (solve_mwis_cit, :343-384); for the rollouts (:596-659) the priorities are
+// left in `prio` and general.hip's candidate / completion / pick launches follow.  DGCN_BIG_RESIDUAL=0: the compaction
+// launches + k_big + k_lgs instead (tests compare the two).
+int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options) {
+    static const int on = env_once("DGCN_BIG_RESIDUAL");
+    if (on == 0 || feature_mode != 0 || (options & DGCN_RESIDUAL_SCORES_GIVEN)) return 0;
+    return big_solve_takes(b, m, X);
+}
+
+int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+                 int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
+                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
+                 unsigned long long tail_tag, void* bws, hipStream_t s) {
+    BigArgs a = {};
+    a.graph_ptr = b->graph_ptr;
+    a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
+    a.rec = reinterpret_cast<uint2*>((reinterpret_cast<uintptr_t>(bws) + 255) & ~(uintptr_t)255);
+    a.status = status;
+    a.rec_cap = big_rec_cap(b);
+    a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
+    a.front = 1;
+    a.scores = scores;
+    a.do_lgs = 1; a.predict_mwis = predict_mwis; a.lgs_cols_lds = 1;
+    a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
+    a.residual = 1; a.greedy_mode = greedy_mode; a.max_rounds = max_rounds;
+    a.progress = progress; a.tail_word = tail_word; a.tail_tag = tail_tag;
+    a.prio_out = greedy_mode == 2 ? prio : nullptr;
+    a.active = greedy_mode == 2 ? active : nullptr;
+    big_fill_model(a, m, x_const);
+    int block = big_block(a.max_nodes);
+    size_t lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                          big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    if (block == 512 && lds > 80 * 1024 && big_env_block() < 0) {
+        block = 1024;
+        lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                       big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    }
+    return big_launch(a, b->num_graphs, lds, block, "big_residual", s);
 }
 
 }  // namespace dgcn

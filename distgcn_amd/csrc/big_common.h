@@ -46,6 +46,16 @@ struct BigArgs {
     uint8_t* state;
     int32_t* rounds;
     double* totals;
+    // a residual step of dgcn_solve_residual_batch in the same launch (with `arow`, constant input features): `state` is the
+    // running state (0 = undecided) - the residual graph's support is formed from the adjacency and the state while the records are
+    // written, the greedy step runs on the undecided vertices (general.hip's k_res_count / _scan / _fill / _scatter, k_lgs and
+    // k_res_central in one launch)
+    int32_t residual, greedy_mode, max_rounds;  // greedy_mode 0 rounds (max_rounds), 1 central pick, 2 priorities only (rollout)
+    int32_t* progress;
+    int32_t* active;       // greedy_mode 2: [num_graphs] out
+    double* prio_out;      // greedy_mode 2: [num_nodes] out
+    unsigned long long* tail_word;
+    unsigned long long tail_tag;
     const float* Zin;      // front == 0: [num_nodes][64] Z0 | Z1 of layer index 1 (explicit input features: the caller ran
                            // layer 0 and the transform of layer 1 with the layer-by-layer kernels)
     BigFront first;        // front == 1

@@ -45,6 +45,12 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
               int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
               hipStream_t s);
 
+int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options);
+int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+                 int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
+                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
+                 unsigned long long tail_tag, void* bws, hipStream_t s);
+
 // big2.hip: the same for graphs of 977 .. 1 920 vertices (Z1 a feature half at a time)
 int big2_takes(const DgcnBatch* b, const DgcnModel* m);
 size_t big2_workspace(const DgcnBatch* b, const DgcnModel* m);
@@ -646,7 +652,16 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_residual_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);
-    const bool wide = wide1_takes(b, m) != 0;
+    bool wide = wide1_takes(b, m) != 0;
+    if (!wide && big && big_residual_takes(b, m, X, feature_mode, options)) {
+        // deep c32 stacks on graphs k_big takes, constant input features: activity test, the residual graph's support, every layer,
+        // priorities and the greedy step (rounds / central pick) in ONE launch on the graph as it lies - no compaction, no k_lgs;
+        // the rollout's four launches follow on the priorities it leaves
+        const int rc = big_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
+                                    state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, bws, s);
+        if (rc || greedy_mode != 2) return rc;
+        wide = true;  // (what follows is the same as behind the one-layer kernel: the rollout's launches)
+    } else
     if (wide) {
         // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE
         // launch on the graph as it lies - no compaction; the rollout's four launches follow on the priorities it leaves

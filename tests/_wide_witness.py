@@ -1,6 +1,8 @@
-"""Child process of tests/test_gpu_wide.py: complete dit / cit / rollout searches and a plain solve of a one-layer model on
-three ragged ~900-vertex graphs, results to an .npz.  Run twice - as it is (csrc/wide.hip) and with DGCN_WIDE1=0 (the
-layer-by-layer any-size path that served these shapes before) - the two files must hold the same bytes / bits."""
+"""Child process of tests/test_gpu_wide.py / test_gpu_general.py: complete dit / cit / rollout searches and a plain solve on
+three ragged ~900-vertex graphs, results to an .npz: python _wide_witness.py out.npz [num_layer=1].  Run twice - as built
+and with a switch of the library set in the environment (DGCN_WIDE1=0: one-layer models layer by layer instead of
+csrc/wide.hip; DGCN_BIG_RESIDUAL=0: the residual steps of deep models through the compaction launches + k_big + k_lgs
+instead of one launch of k_big) - the two files must hold the same bytes / bits."""
 import os
 import sys
 
@@ -9,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(out_path):
+def main(out_path, num_layer=1):
     import torch
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
@@ -24,7 +26,7 @@ def main(out_path):
         w[rng.random(n) < 0.05] = 0.0  # zero weights inside live graphs
         ws.append(w)
     hb = HostBatch.from_scipy(mats, ws)
-    layers = datagen.random_model(1, 32, bias=True, last_act="leaky_relu", seed=12)
+    layers = datagen.random_model(num_layer, 32, bias=True, last_act="leaky_relu", seed=12)
     eng = Engine("cuda:0")
     db = eng.upload(hb)
     dm = DeviceModel(layers, eng.device)
@@ -46,4 +48,4 @@ def main(out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -423,3 +423,29 @@ def test_wide_deep_model_runs_on_the_device(engine, golden):
     assert got is not None
     want = orc.solve_mwis_cit(fn, adj, w)
     assert got[0][0] == want[0]
+
+
+def test_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp_path):
+    """A residual step of a deep model on graphs k_big takes is ONE launch (big.hip: the residual graph's support from the
+    adjacency and the running state, every layer, the greedy step).  Second witness besides the fused kernel (the step-by-step
+    test above, on fixture graphs): complete dit / cit / rollout searches on three ragged ~900-vertex graphs - zero weights
+    inside live graphs, biases, a leaky last layer - by a child process as built and by one with DGCN_BIG_RESIDUAL=0, the
+    compaction launches + k_big + k_lgs that ran before: same states, step counts, score bits."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_wide_witness.py")
+    files = {}
+    for tag, val in (("one_launch", "1"), ("compaction", "0")):
+        files[tag] = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, script, files[tag], "5"], check=True, env=dict(os.environ, DGCN_BIG_RESIDUAL=val), timeout=900)
+    a, b = np.load(files["one_launch"]), np.load(files["compaction"])
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k.endswith("_scores"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        elif k.endswith("_totals"):
+            assert np.allclose(a[k], b[k], rtol=1e-12), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+    assert a["cit_steps"][0] > 100

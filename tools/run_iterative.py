@@ -33,8 +33,7 @@ def main():
     from distgcn_amd.runtime_config import FLAGS
     eng = get_engine()
     if args.family == "mc":
-        import bench
-        hb = bench.multichannel_batch(args.graphs, args.n // 3, args.p)
+        hb = datagen.multichannel_batch(args.graphs, args.n // 3, args.p)
     else:
         hb = datagen.er_batch(args.graphs, args.n, args.p)
     flags = FLAGS.copy(feature_size=1, hidden1=32, num_layer=args.layers, diver_num=1, max_degree=1, predict="mwis")
@@ -61,6 +60,19 @@ def main():
         line = {"solver": which, "graphs": args.graphs, "n": args.n, "layers": args.layers, "steps": res["steps"],
                 "seconds": round(dt, 4), "graphs_per_s": round(args.graphs / dt, 2),
                 "ms_per_step": round(1e3 * dt / max(res["steps"], 1), 4), "mean_total": round(tot / args.graphs, 4)}
+        # one more search with the kernel families timed (HIP events round every launch): where a search's GPU time goes
+        state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
+        eng.timing(True)
+        eng.solve_residual(db, dm, state, greedy=greedy[which], max_rounds=1, beam=args.beam)
+        torch.cuda.synchronize()
+        eng.timing(False)
+        fams = {}
+        for fam in ("fused_residual", "tail_finish", "big_residual", "big_forward", "general_prepare", "general_greedy", "lgs", "wide_residual",
+                    "supports", "transform", "spmm", "layer"):
+            ms, n = eng.timing_read(fam)
+            if n:
+                fams[fam] = {"ms": round(ms, 3), "launches": n}
+        line["gpu_ms_by_family"] = fams
         if args.host:
             agent.device_iterative = False
             n0 = int(hb.graph_ptr[1])

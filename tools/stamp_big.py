@@ -9,8 +9,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "er500"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 if kind == "mc900":
-    import bench
-    hb = bench.multichannel_batch(B, 300, 0.03)
+    hb = datagen.multichannel_batch(B, 300, 0.03)
 else:
     hb = datagen.er_batch(B, 500, 0.1)
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(nl, 32), "cuda:0")
