@@ -80,13 +80,6 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
-    // The two workgroups that share a CU take TURNS in the aggregation phase (a word per pair in the caller's scratch, tagged
-    // with the launch's number so that nothing has to be cleared): while one gathers from the LDS the other one transforms on
-    // the matrix pipes - in anti-phase by construction instead of drifting in and out of it.  Timing only, never correctness:
-    // a bounded spin, and a wrong guess about which workgroups share a CU costs the atomics' round trips and nothing else.
-    unsigned long long* turn;  // [turn_pairs] or null
-    unsigned long long turn_tag;
-    int32_t turn_pairs;
     int32_t stagger;           // tuning experiment (DGCN_FUSED_STAGGER, units of 1 024 cycles): the second workgroup of a CU starts this much later
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
@@ -1038,7 +1031,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     const bool second = (blockIdx.x >> 8) & 1;
     if (a.prio_second && second) __builtin_amdgcn_s_setprio(1);
     // (round-4 review: start the second co-resident workgroup half a layer late, so that one's MFMA phase meets the other's
-    // LDS phase by construction rather than by drift.  Measured in round 5, DESIGN 9: no gain - off unless the variable is set.)
+    // LDS phase by construction rather than by drift.  Measured in round 5, DESIGN 9: no gain - off unless the variable is set.
+    // The stricter form - the two workgroups taking turns in the aggregation phase through a word in global memory - costs 23 %:
+    // profiles/r05_fused_turns.txt.)
     if (a.stagger > 0 && second)
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     unsigned long long tclk = 0;
@@ -1457,7 +1452,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         __syncthreads();
         l_first = 1;
     }
-    bool turn_held = false;
     for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
         // fp32 MFMAs and VALU work exclude each other on a SIMD and the older wave wins (tools/micro/mfma_valu.hip):
@@ -1496,18 +1490,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
             STAMP(a, g, 5, tclk);  // transform body (wave 0)
-            if constexpr (!CLUSTER) {
-                if (a.turn && threadIdx.x == 0) {  // this workgroup's turn at the LDS array (see FusedArgs::turn)
-                    unsigned long long* tw = a.turn + (blockIdx.x % (unsigned)a.turn_pairs);
-                    const unsigned long long mine = (a.turn_tag << 1) | 1ull;
-                    for (int spin = 0; spin < 256 && !turn_held; ++spin) {
-                        unsigned long long v = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((v >> 1) != a.turn_tag || !(v & 1ull))
-                            turn_held = __hip_atomic_compare_exchange_strong(tw, &v, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!turn_held) __builtin_amdgcn_s_sleep(4);
-                    }
-                }
-            }
             __syncthreads();
             STAMP(a, g, 6, tclk);  // wait at the barrier after transforms
 #ifdef DGCN_DIAG
@@ -1546,12 +1528,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 }
             }
             __syncthreads();
-            if constexpr (!CLUSTER) {
-                if (turn_held) {  // (thread 0 only) every wave of this workgroup has left the gather phase
-                    __hip_atomic_store(a.turn + (blockIdx.x % (unsigned)a.turn_pairs), a.turn_tag << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    turn_held = false;
-                }
-            }
             STAMP(a, g, 8, tclk);  // wait at the barrier after gathers
         } else {
             // last layer: width 1.  z0 stays in a register, z1 goes to bufB[v] (bufB is free: the
@@ -2207,8 +2183,6 @@ static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
 }
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
-constexpr size_t kTurnBytes = 1024 * sizeof(unsigned long long) + 256;  // a word per CU (<= 1 024 CUs)
-
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
                          void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool no_cluster = false) {
     if (!fused_shape_ok(m))
@@ -2302,22 +2276,6 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     }
     a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
     if (a->cluster > 1) a->order = nullptr;
-    a->turn = nullptr;
-    a->turn_pairs = 0;
-    {
-        // turns at the LDS array: one wave of workgroups, two per CU (more graphs than CUs, at most twice as many), the 512-thread kernel
-        static const int turn_env = [] { const char* e = getenv("DGCN_FUSED_TURN"); return e ? atoi(e) : 1; }();
-        const int ncu = device_cus();
-        const size_t need = kTurnBytes;
-        if (turn_env && ncu <= 1024 && a->cluster <= 1 && b->num_graphs > ncu && b->num_graphs <= 2 * ncu && workspace && workspace_bytes >= need) {
-            a->turn = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-            a->turn_pairs = ncu;
-            static std::atomic<unsigned long long> turn_calls{1};
-            a->turn_tag = turn_calls.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffffffffffull;
-            workspace = static_cast<char*>(workspace) + need;
-            workspace_bytes -= need;
-        }
-    }
     a->cluster_inject = getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT") ? atoi(getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT")) : 0;
     if (a->cluster > 1) {
         const size_t need = fused_cluster_bytes(b, a->cluster);
@@ -2431,7 +2389,6 @@ static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
     need += (size_t)b->num_graphs * fused_rec_cap(meta_cap, b->max_nodes) * sizeof(uint2) + 256;  // entry records of the hidden aggregation
     need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
-    need += kTurnBytes;                                               // the turn words of co-resident workgroups
     need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);
     return need;
 }
