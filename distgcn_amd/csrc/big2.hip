@@ -94,6 +94,28 @@ __device__ __forceinline__ void b2_mma2(const float (&b)[8], const float (&h0)[8
     o0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
     o1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
 }
+__device__ __forceinline__ void b2_mma2b(const float (&b0)[8], const float (&b1)[8], const float (&h)[8], bool f64, float4& o0, float4& o1) {
+    if (f64) {
+        bf64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double hd = (double)h[s];
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b0[s], hd, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b1[s], hd, a1, 0, 0, 0);
+        }
+        o0 = make_float4((float)a0[0], (float)a0[1], (float)a0[2], (float)a0[3]);
+        o1 = make_float4((float)a1[0], (float)a1[1], (float)a1[2], (float)a1[3]);
+        return;
+    }
+    bf32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[s], h[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[s], h[s], a1, 0, 0, 0);
+    }
+    o0 = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    o1 = make_float4(a1[0], a1[1], a1[2], a1[3]);
+}
 __device__ __forceinline__ void b2_mma3(const float (&b0)[8], const float (&b1)[8], const float (&b2)[8], const float (&h)[8], bool f64,
                                         float4& o0, float4& o1, float4& o2) {
     if (f64) {
@@ -452,22 +474,31 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         const float* Wz = i == 0 ? a.first.W1 : a.layers[i - 1].Wnext;  // the transform in front of this aggregation
         const bool f64 = i == 0;  // layer index 1: every chain in double, rounded once (include/dgcn.h)
         float bcol[8];
+        // FUSE (twelve tiles per wave): Z0's lo half and the lo half of H' are formed in S2 behind the tile's walk, beside other
+        // waves' walks, where the matrix pipes idle; what is left of the MFMA-only phase S3 is Z1 hi and Z0's hi half.  MC1500:
+        // S3 248 -> 148 us, S2 206 -> 263 us per launch, 1 076 -> 1 036 us.  (Eight tiles per wave - two record groups in flight -
+        // lose by it: ER(1 000, 0.01) 750 -> 778 us.  The next layer's Z1 lo formed in S4's epilogue into the lo sums' registers,
+        // so that S1 only stores: those registers then live through S4's walk, H spills at twelve tiles - 104 registers -, and
+        // at eight it costs another 15 us: dropped.)
+        constexpr bool FUSE = TILES == 12;
         // -------- S1: Z1 lo = H.W1[:, 0:16] -> LDS (every gather of the previous aggregation is behind a barrier)
-        b2_load_bcol(Wz, 2, f64, bcol);
+        {
+            b2_load_bcol(Wz, 2, f64, bcol);
 #pragma unroll 1
-        for (int k = 0; k < TILES; k += 2) {  // two tiles at a time: two independent MFMA chains
-            const int t = wave + kB2Waves * k;
-            if (t < tiles) {
-                B2_LAUNDER
-                const int k1 = min(k + 1, TILES - 1);  // (the second tile may not exist: its product is not stored then)
-                float h0[8], h1[8];
-                B2_GET_H(k, h0)
-                B2_GET_H(k1, h1)
-                float4 o0, o1;
-                b2_mma2(bcol, h0, h1, f64, o0, o1);
-                const int mslot = t * 16 + mr, mslot1 = mslot + kB2Waves * 16;
-                if (mslot < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o0;
-                if (k + 1 < TILES && mslot1 < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot1] * 16 + 4 * mq) = o1;
+            for (int k = 0; k < TILES; k += 2) {  // two tiles at a time: two independent MFMA chains
+                const int t = wave + kB2Waves * k;
+                if (t < tiles) {
+                    B2_LAUNDER
+                    const int k1 = min(k + 1, TILES - 1);  // (the second tile may not exist: its product is not stored then)
+                    float h0[8], h1[8];
+                    B2_GET_H(k, h0)
+                    B2_GET_H(k1, h1)
+                    float4 o0, o1;
+                    b2_mma2(bcol, h0, h1, f64, o0, o1);
+                    const int mslot = t * 16 + mr, mslot1 = mslot + kB2Waves * 16;
+                    if (mslot < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o0;
+                    if (k + 1 < TILES && mslot1 < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot1] * 16 + 4 * mq) = o1;
+                }
             }
         }
         B2_STAMP(3);  // S1 (sum over the layers)
@@ -479,6 +510,8 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) alo[j] = (vtile)(0.f);
         }
+        float bz0[8];
+        if (FUSE) b2_load_bcol(Wz, 0, f64, bz0);
         B2_FIRST_GROUP
 #pragma unroll 1
         for (int k = 0; k < TILES; ++k) {
@@ -486,19 +519,36 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                 B2_TILE_HEAD
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 B2_WALK(B2_TRIP)
+                if (FUSE) {
+                    // Z0's lo half and the lo half of H' = act(Z0 + L.Z1 + b) right here: the tile's lo sums are complete
+                    float hh[8];
+                    B2_GET_H(k, hh)
+                    const float4 z0a = b2_mma(bz0, hh, f64);
+                    *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = z0a;  // MFMA layout (row mr, chunk mq) ->
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 yA = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2));  // aggregation layout
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_wave_barrier();
+                    acc = make_float4(yA.x + acc.x, yA.y + acc.y, yA.z + acc.z, yA.w + acc.w);
+                    if (L.bias) {
+                        const float4 biasA = *reinterpret_cast<const float4*>(L.bias + 4 * cfirst);
+                        acc.x += biasA.x; acc.y += biasA.y; acc.z += biasA.z; acc.w += biasA.w;
+                    }
+                    acc.x = big_act(acc.x, L.act); acc.y = big_act(acc.y, L.act); acc.z = big_act(acc.z, L.act); acc.w = big_act(acc.w, L.act);
+                }
                 B2_LO_PUT(k, acc)
             }
         }
         b2_load_bcol(Wz, 3, f64, bcol);  // (requested here: they land while this wave waits at the barrier)
+        float bz1[8];
+        b2_load_bcol(Wz, 1, f64, bz1);
+        if (!FUSE) b2_load_bcol(Wz, 0, f64, bz0);
         B2_STAMP(5);  // S2
         __syncthreads();  // every lo gather has read Z1h
         B2_STAMP(6);
-        // -------- S3: Z1 hi = H.W1[:, 16:32] -> LDS; Z0 = H.W0; the lo half of H' = act(Z0 + L.Z1 + b) - its sums are complete.
-        // (All the MFMA work that is left sits here, where no walk's registers are live; H is dead afterwards: its registers
-        // carry Z0's hi half to S4.)
-        float bz0[8], bz1[8];
-        b2_load_bcol(Wz, 0, f64, bz0);
-        b2_load_bcol(Wz, 1, f64, bz1);
+        // -------- S3: Z1 hi = H.W1[:, 16:32] -> LDS; Z0's hi half (FUSE: its lo half and the lo half of H' were formed in S2).
+        // H is dead afterwards: its registers carry Z0's hi half [0..3] and the lo half of H' [4..7] (aggregation layout) to S4.
 #pragma unroll 1
         for (int k = 0; k < TILES; ++k) {
             const int t = wave + kB2Waves * k;
@@ -506,29 +556,32 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                 B2_LAUNDER
                 float hh[8];
                 B2_GET_H(k, hh)
-                float4 o, z0a, z0b;
-                b2_mma3(bcol, bz0, bz1, hh, f64, o, z0a, z0b);
+                float4 o, z0a = make_float4(0.f, 0.f, 0.f, 0.f), z0b;
+                if (FUSE) b2_mma2b(bcol, bz1, hh, f64, o, z0b);
+                else b2_mma3(bcol, bz0, bz1, hh, f64, o, z0a, z0b);
                 const int mslot = t * 16 + mr;
                 if (mslot < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o;
                 // MFMA output layout (row mr: chunk mq of z0a, chunk 4 + mq of z0b) -> aggregation layout
-                *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = z0a;
+                if (!FUSE) *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = z0a;
                 *reinterpret_cast<float4*>(stg + mr * kBH + (((4 + mq) ^ (mr & 7)) << 2)) = z0b;
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
-                const float4 yA = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2));
+                float4 yA = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!FUSE) yA = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((cfirst ^ (s16 & 7)) << 2));
                 const float4 yB = *reinterpret_cast<const float4*>(stg + s16 * kBH + ((csecond ^ (s16 & 7)) << 2));
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
                 float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
                 B2_LO_GET(k, lo)
-                float4 oA = make_float4(yA.x + lo.x, yA.y + lo.y, yA.z + lo.z, yA.w + lo.w);
-                if (L.bias) {
-                    const float4 biasA = *reinterpret_cast<const float4*>(L.bias + 4 * cfirst);
-                    oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
+                float4 oA = lo;  // FUSE: the lo half of H' already
+                if (!FUSE) {
+                    oA = make_float4(yA.x + lo.x, yA.y + lo.y, yA.z + lo.z, yA.w + lo.w);
+                    if (L.bias) {
+                        const float4 biasA = *reinterpret_cast<const float4*>(L.bias + 4 * cfirst);
+                        oA.x += biasA.x; oA.y += biasA.y; oA.z += biasA.z; oA.w += biasA.w;
+                    }
+                    oA.x = big_act(oA.x, L.act); oA.y = big_act(oA.y, L.act); oA.z = big_act(oA.z, L.act); oA.w = big_act(oA.w, L.act);
                 }
-                oA.x = big_act(oA.x, L.act); oA.y = big_act(oA.y, L.act); oA.z = big_act(oA.z, L.act); oA.w = big_act(oA.w, L.act);
-                // H is dead: its registers carry Z0's hi half [0..3] and the lo half of H' [4..7] (aggregation layout) to S4 -
-                // the lo sums' registers are free from here to the next layer's S2
                 hh[0] = yB.x; hh[1] = yB.y; hh[2] = yB.z; hh[3] = yB.w;
                 hh[4] = oA.x; hh[5] = oA.y; hh[6] = oA.z; hh[7] = oA.w;
                 B2_SET_H(k, hh)
