@@ -520,10 +520,12 @@ def roofline_objects(args, wl, fam_ms):
 
 
 def fused_pmc_reference(args, dom):
-    """SQ counters of the C3 launch from an earlier PMC pass of the same kernel (profiles/r03_fused_pmc.txt: per-launch sums
+    """SQ counters of the C3 launch from a PMC pass of the same kernel build (profiles/r05_fused_pmc.txt: per-launch sums
     over the chip), as fractions: how long the LDS was active, how much of that was bank conflicts, how busy the MFMA pipes
     were.  Only for the configuration the pass was taken on; not measured in this run."""
-    path = os.path.join(ROOT, "profiles", "r03_fused_pmc.txt")
+    path = os.path.join(ROOT, "profiles", "r05_fused_pmc.txt")  # retaken on the round-5 build (tools/collect_profiles_r05.sh)
+    if not os.path.isfile(path):
+        return None
     if dom != "fused_solve" or args.family != "er" or (args.nodes, args.graphs, args.layers) != (200, 500, 20) or not os.path.isfile(path):
         return None
     c = {}
@@ -534,7 +536,7 @@ def fused_pmc_reference(args, dom):
     need = ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA")
     if any(k not in c for k in need):
         return None
-    return {"source": "profiles/r03_fused_pmc.txt (rocprofv3 --pmc passes of this kernel on this configuration, round 3; not measured in this run)",
+    return {"source": "profiles/r05_fused_pmc.txt (rocprofv3 --pmc passes of this kernel on this configuration, retaken on the round-5 build; not measured in this run)",
             "lds_active_frac_of_cu_busy_cycles": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"],
             "lds_bank_conflict_frac_of_lds_active": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
             "mfma_busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]),
@@ -945,9 +947,14 @@ def main(argv=None, workload_factory=None):
         algo = float(sum(per_step[:calls]))
         ach = (algo / calls) / avg_s / 1e9 if avg_s > 0 else None
         tms, tn = fam_ms.get("tail_finish", (0.0, 0))
+        c5_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(tpath):  # FETCH_SIZE / WRITE_SIZE passes of a whole search, averaged over its k_fused launches (the empty ones included)
+            c5_traffic = json.load(open(tpath)).get("fused_residual|%dx%d|l%d" % (args.graphs, args.nodes, args.layers), {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
                     "bound": "lds+mfma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
+                    "traffic": c5_traffic,
+                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE passes of tools/run_iterative.py --only rollout on this configuration (profiles/hbm_traffic.json): average over ALL k_fused launches of a search, the empty ones behind its end included", "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
                     "empty_launches_per_search": n / max(args.steps, 1) - calls,
                     "algorithmic_bytes_per_launch": algo / calls,
                     "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's k_fused launches",

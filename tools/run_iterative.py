@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--host", type=int, default=1)
+    ap.add_argument("--only", default=None, help="run this solver only (dit / cit / rollout)")
     ap.add_argument("--family", choices=["er", "mc"], default="er", help="mc: joint 3-channel conflict graphs of n // 3 flows (bench.multichannel_batch)")
     args = ap.parse_args()
     import torch
@@ -45,6 +46,8 @@ def main():
     print(json.dumps({"path": {1: "fused kernel", 2: "any-size path (general.hip + big.hip)"}[path]}), flush=True)
     greedy = {"dit": eng.GREEDY_ROUNDS, "cit": eng.GREEDY_CENTRAL, "rollout": eng.GREEDY_ROLLOUT}
     for which in ("dit", "cit", "rollout"):
+        if args.only and which != args.only:
+            continue
         dt = None
         for rep in range(4):  # (the first run loads the kernels; the best of the others counts)
             state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=eng.device)
