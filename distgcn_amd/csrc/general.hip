@@ -386,11 +386,38 @@ __global__ __launch_bounds__(kResBlock) void k_res_central(ResArgs a) {
 }
 
 // ---- greedy_mode 2, first launch: the first `beam` undecided vertices under (priority desc, index asc) - the stable
-// argsort of -gcn_wts (mwis_gdpg_call.py:624-626) - by counting, for every undecided vertex, the ones ahead of it.
-// `lpv` lanes share a vertex and split the count; four independent compares in flight per lane (the first version walked
-// the graph in one dependent chain per thread with an early exit: 343 us per launch at 900 vertices).
+// argsort of -gcn_wts (mwis_gdpg_call.py:624-626).  Every wave selects ITS first `beam` (a thread keeps its <= 10 vertices'
+// priorities in registers; `beam` rounds of: best of my vertices not taken yet, wave-wide argmax, its owner marks it taken);
+// the waves' lists - sorted, and together they contain the graph's first `beam` - are ranked against each other: a candidate's
+// rank is the sum over the lists of the entries ahead of it, a binary search per list, all 1 024 threads on (candidate, list) pairs.
+// (Round 4's form counted, for EVERY undecided vertex, the vertices ahead of it - N^2 / 1 024 float64 compares per thread: 56 us
+// per launch at 900 vertices, the largest single item of a rollout step on the any-size path.  First version of this one: the
+// vertices' state and priority loaded one dependent pair after the other (18 us), the wave-wide argmax by __shfl_xor - six
+// ds_bpermute round trips of three words through an LDS crossbar sixteen waves queue on (22 us for 16 rounds) -, the ranking a
+// linear scan by 256 threads (20 us): 59 us, nothing gained.  Now: all loads in flight at once, the argmax inside a row of
+// sixteen lanes by DPP moves and across the four rows by v_readlane, the ranking as above.)
+struct CandKey { double p; int v; };  // v < 0: nobody
+__device__ __forceinline__ bool cand_ahead(double p, int v, double q, int u) {  // is (p, v) ahead of (q, u)?  (both somebody)
+    return p > q || (p == q && v < u);
+}
+template <int CTRL>
+__device__ __forceinline__ void cand_dpp_max(double& p, int& v) {
+    const int lo = __double2loint(p), hi = __double2hiint(p);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const int ov = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+    const double op = __hiloint2double(ohi, olo);
+    if (ov >= 0 && (v < 0 || cand_ahead(op, ov, p, v))) { p = op; v = ov; }
+}
+
 __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cand_lds[];
+    (void)lds_nodes;
+    constexpr int kPer = (9600 + kResBlock - 1) / kResBlock;  // vertices per thread at most (general_takes: <= 9 600 vertices)
+    constexpr int kWavesR = kResBlock / 64;
+    __shared__ double wl_p[kWavesR * kMaxBeam];
+    __shared__ int wl_v[kWavesR * kMaxBeam];
+    __shared__ int wl_n[kWavesR];
+    __shared__ int rank[kWavesR * kMaxBeam];
     __shared__ int s_bad;
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1], ng = n1 - n0;
@@ -398,58 +425,81 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
     if (threadIdx.x < kMaxBeam) cid[threadIdx.x] = -1;
     if (!a.active[g]) return;
     if (threadIdx.x == 0) s_bad = 0;
-    const bool in_lds = ng <= lds_nodes;
-    double* pl = reinterpret_cast<double*>(cand_lds);
-    __syncthreads();
-    // a decided vertex takes part as "-inf, never ahead of anybody": its priority is replaced by a NaN-free sentinel and its
-    // liveness is folded into the compare below through the sentinel (no undecided vertex can have priority -inf AND lose
-    // to it: equal priorities are ordered by index, and a sentinel never counts)
-    int bad = 0;
-    for (int v = threadIdx.x; v < ng; v += kResBlock) {
-        const double p = a.prio[n0 + v];
-        const bool alive = a.state[n0 + v] == 0;
-        bad |= alive && p != p;
-        if (in_lds) pl[v] = alive ? p : __longlong_as_double(0x7ff8000000000001ll);  // quiet NaN: compares false both ways
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int beam = min(a.beam, kMaxBeam);
+    const int per = (ng + kResBlock - 1) / kResBlock;  // (uniform) my vertices: threadIdx.x + i * kResBlock, i < per
+    double pv[kPer];
+    uint8_t sv[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {  // every load in flight before the first one is looked at
+        const int v = (int)threadIdx.x + i * kResBlock;
+        const bool in = i < per && v < ng;
+        sv[i] = in ? a.state[n0 + v] : (uint8_t)1;
+        pv[i] = in ? a.prio[n0 + v] : 0.0;
     }
+    unsigned have = 0u;  // bit i: my vertex i is undecided and not selected yet
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i)
+        if (sv[i] == 0) {
+            bad |= pv[i] != pv[i];
+            have |= 1u << i;
+        }
+    for (int c = threadIdx.x; c < kWavesR * kMaxBeam; c += kResBlock) rank[c] = 0;
+    __syncthreads();
     if (bad) s_bad = 1;
     __syncthreads();
     if (s_bad) {
         if (threadIdx.x == 0) atomicOr(a.status, DGCN_FAULT_NAN_PRIORITY);
         return;  // no candidates: k_res_pick leaves the graph alone
     }
-    const int beam = min(a.beam, kMaxBeam);
-    int lsh = 0;
-    while (lsh < 3 && (ng << (lsh + 1)) <= kResBlock) ++lsh;
-    const int lpv = 1 << lsh;
-    const int sub = threadIdx.x & (lpv - 1);
-    for (int v0 = 0; v0 < ng; v0 += kResBlock >> lsh) {  // (uniform trip count: the shuffles below need every lane)
-        const int v = v0 + ((int)threadIdx.x >> lsh);
-        const bool mine = v < ng && a.state[n0 + v] == 0;
-        int cnt = 0;
-        if (mine) {
-            const double pv = a.prio[n0 + v];
-            if (in_lds) {
-                int w = sub;
-                for (; w + 3 * lpv < ng; w += 4 * lpv) {
-                    const double p0 = pl[w], p1 = pl[w + lpv], p2 = pl[w + 2 * lpv], p3 = pl[w + 3 * lpv];
-                    cnt += (p0 > pv) || (p0 == pv && w < v);
-                    cnt += (p1 > pv) || (p1 == pv && w + lpv < v);
-                    cnt += (p2 > pv) || (p2 == pv && w + 2 * lpv < v);
-                    cnt += (p3 > pv) || (p3 == pv && w + 3 * lpv < v);
-                }
-                for (; w < ng; w += lpv) {
-                    const double pw = pl[w];
-                    cnt += (pw > pv) || (pw == pv && w < v);
-                }
-            } else {
-                for (int w = sub; w < ng; w += lpv) {
-                    const double pw = a.prio[n0 + w];
-                    cnt += a.state[n0 + w] == 0 && ((pw > pv) || (pw == pv && w < v));
-                }
-            }
+    int mine_n = 0;
+    for (int it = 0; it < beam; ++it) {
+        double bp = 0.0;
+        int bv = -1;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)  // ascending vertex index: the first maximum stays
+            if (((have >> i) & 1u) && (bv < 0 || pv[i] > bp)) { bp = pv[i]; bv = (int)threadIdx.x + i * kResBlock; }
+        // the best of the wave: inside a row of sixteen lanes by DPP (quad swaps, half-row and row mirrors: every lane ends with
+        // its row's best), across the four rows through scalar registers
+        cand_dpp_max<0xB1>(bp, bv);   // quad_perm [1, 0, 3, 2]
+        cand_dpp_max<0x4E>(bp, bv);   // quad_perm [2, 3, 0, 1]
+        cand_dpp_max<0x141>(bp, bv);  // row_half_mirror
+        cand_dpp_max<0x140>(bp, bv);  // row_mirror
+        double wp = 0.0;
+        int wv = -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rv = __builtin_amdgcn_readlane(bv, 16 * r);
+            const double rp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bp), 16 * r), __builtin_amdgcn_readlane(__double2loint(bp), 16 * r));
+            if (rv >= 0 && (wv < 0 || cand_ahead(rp, rv, wp, wv))) { wp = rp; wv = rv; }
         }
-        for (int off = 1; off < lpv; off <<= 1) cnt += __shfl_xor(cnt, off);
-        if (mine && sub == 0 && cnt < beam) cid[cnt] = v;
+        if (wv < 0) break;  // (wave-uniform: this wave has no undecided vertex left)
+        if ((wv & (kResBlock - 1)) == (int)threadIdx.x) have &= ~(1u << (wv / kResBlock));
+        if (lane == 0) { wl_p[wave * kMaxBeam + it] = wp; wl_v[wave * kMaxBeam + it] = wv; }
+        mine_n = it + 1;
+    }
+    if (lane == 0) wl_n[wave] = mine_n;
+    __syncthreads();
+    // rank the waves' lists against each other: (candidate c = (w, k), list w2) pairs over all threads; the entries of list w2
+    // ahead of the candidate form a prefix of it (the lists are sorted): binary search, summed into the candidate's rank
+    for (int idx = threadIdx.x; idx < kWavesR * beam * kWavesR; idx += kResBlock) {
+        const int w2 = idx % kWavesR, c = idx / kWavesR;
+        const int w = c / beam, k = c - w * beam;
+        if (k >= wl_n[w]) continue;
+        const double p = wl_p[w * kMaxBeam + k];
+        const int v = wl_v[w * kMaxBeam + k];
+        int lo = 0, hi = wl_n[w2];  // entries [0, lo) are ahead, [hi, ..) are not
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cand_ahead(wl_p[w2 * kMaxBeam + mid], wl_v[w2 * kMaxBeam + mid], p, v)) lo = mid + 1; else hi = mid;
+        }
+        if (lo) atomicAdd(&rank[w * kMaxBeam + k], lo);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < kWavesR * beam; c += kResBlock) {
+        const int w = c / beam, k = c - w * beam;
+        if (k < wl_n[w] && rank[w * kMaxBeam + k] < beam) cid[rank[w * kMaxBeam + k]] = wl_v[w * kMaxBeam + k];
     }
 }
 
@@ -711,14 +761,8 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         return check_launch("k_res_central");
     }
     {
-        // priorities of one graph in LDS when they fit (8 bytes per vertex; a decided vertex as a NaN: never ahead of anybody)
-        const int lds_nodes = b->max_nodes <= 7000 ? b->max_nodes : 0;
-        const size_t lds = (size_t)lds_nodes * 8 + 16;
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res_cand), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(DGCN_ERR_LAUNCH, "k_res_cand: cannot reserve %zu bytes of LDS", lds);
         TimedLaunch t("general_greedy", s);
-        DGCN_LAUNCH(t, k_res_cand, gb, tb, lds, s, a, lds_nodes);
+        DGCN_LAUNCH(t, k_res_cand, gb, tb, 0, s, a, 0);
         if (int rc = check_launch("k_res_cand")) return rc;
     }
     {
