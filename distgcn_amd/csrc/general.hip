@@ -63,7 +63,7 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
 
 // wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
 // in one launch
-int wide1_takes(const DgcnBatch* b, const DgcnModel* m);
+int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode);
 int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
               int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
               int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
@@ -619,7 +619,7 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     Bump w{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255),
            workspace_bytes >= 256 ? workspace_bytes - 256 : 0};
     if (!workspace) w.ok = false;
-    if (wide1_takes(b, m)) {  // one-layer models: supports, score, priority and greedy search in ONE launch (wide.hip)
+    if (wide1_takes(b, m, X, 0)) {  // one- and two-layer models: supports, score, priority and greedy search in ONE launch (wide.hip)
         float* sc1 = scores ? scores : w.take<float>(n);
         if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                                general_workspace(b, m), workspace_bytes);
@@ -702,7 +702,7 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_residual_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                            general_workspace(b, m), workspace_bytes);
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);
-    bool wide = wide1_takes(b, m) != 0;
+    bool wide = wide1_takes(b, m, X, feature_mode) != 0;
     if (!wide && big && big_residual_takes(b, m, X, feature_mode, options)) {
         // deep c32 stacks on graphs k_big takes, constant input features: activity test, the residual graph's support, every layer,
         // priorities and the greedy step (rounds / central pick) in ONE launch on the graph as it lies - no compaction, no k_lgs;

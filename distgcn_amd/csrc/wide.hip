@@ -1,4 +1,4 @@
-// One-layer models (F -> 1) on graphs of ANY size the any-size path takes (<= 9 600 vertices), adjacency in, set out, ONE launch:
+// One-layer models (F -> 1) - and, further down, two-layer models (F -> C -> 1) on constant features - on graphs of ANY size the any-size path takes (<= 9 600 vertices), adjacency in, set out, ONE launch:
 // what the reference's multi-channel launchers actually run - `--num_layer=1 --num_channels=3` on the joint conflict graph of
 // K * nflows vertices (bash/twc_major_wireless_mc_test.sh:3,6,9, bash/test_wireless_gcn_rollout.sh:6-8,
 // wireless_dqn_test_mc.py:161, 244-289) - and every residual step of solve_mwis_dit / _cit / the rollouts on such a model
@@ -46,9 +46,14 @@ struct WideArgs {
     const float* X;            // [num_nodes][cin] or null
     float x_const;
     int32_t cin, feature_mode; // feature_mode 1: x = weight / (largest undecided weight + 1e-9) (mwis_gdpg_call.py:88)
-    const float* W;            // [cin][2]
-    const float* bias;         // [1] or null
+    const float* W;            // [cin][2] (two layers: [cin][2 C])
+    const float* bias;         // [1] or null (two layers: [C])
     int32_t act;
+    // two-layer models (F -> C -> 1, C <= 64, constant input features): the second layer
+    int32_t two, C;
+    const float* W2;           // [C][2]
+    const float* bias2;        // [1] or null
+    int32_t act2;
     const double* weights;     // or null
     int32_t predict_mwis, residual, scores_given, mode, max_rounds;
     float* sc;                 // [num_nodes] scores, original numbering: out (in with scores_given); never null
@@ -167,6 +172,130 @@ __device__ __forceinline__ void wide_scores(const WideArgs& a, int n0, int ng, i
     }
 }
 
+// ---- two-layer models F -> C -> 1 on constant input features (the reference's l = 2 launchers and checkpoints; C <= 64).  Layer 0's
+// output is again a function of the vertex's (residual) neighbourhood's d^-1/2 only - every row of Z = x.[W0 | W1] is the same 2 C
+// numbers (z0c | z1c, formed once per workgroup into LDS) - so H never exists as a matrix: a thread forms its vertex's H sixteen
+// features at a time (the contract's double chains over [diagonal, undecided neighbours in CSR order]: orc_spmm_f64) and feeds
+// them straight into the second layer's transform, two fma chains in double over k = 0 .. C - 1 (layer index 1: orc_transform_f64)
+// - z0 goes to the scores array (this thread reads it back below), z1 into LDS.  Then the second layer's aggregation at width 1,
+// a float32 fmaf chain over [diagonal, neighbours] (orc_spmm), + z0, + bias, activation.  Two walks over the adjacency.
+template <bool COLS_LDS>
+__device__ __forceinline__ void wide_scores2(const WideArgs& a, int n0, int ng, int e0, const uint8_t* st, const uint16_t* cl, double* dinv,
+                                             float* z1, float* cst, int& fault) {
+    const int C = a.C;
+    float* z0c = cst;            // [C]
+    float* z1c = cst + 64;       // [C]
+    float* w2 = cst + 128;       // [C][2]
+    float* b0 = cst + 256;       // [C]
+    for (int k = threadIdx.x; k < C; k += kWideBlock) {
+        float q0 = 0.f, q1 = 0.f;
+        for (int kk = 0; kk < a.cin; ++kk) {
+            q0 = fmaf(a.x_const, a.W[kk * 2 * C + k], q0);
+            q1 = fmaf(a.x_const, a.W[kk * 2 * C + C + k], q1);
+        }
+        z0c[k] = q0;
+        z1c[k] = q1;
+        w2[2 * k] = a.W2[2 * k];
+        w2[2 * k + 1] = a.W2[2 * k + 1];
+        b0[k] = a.bias ? a.bias[k] : 0.f;
+    }
+    // (residual) degrees -> d^-1/2 per vertex
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        if (st[v] != 0) continue;
+        const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+        int deg = re - rs;
+        if (a.residual) {
+            deg = 0;
+#pragma unroll 4
+            for (int j = rs; j < re; ++j) {
+                const int u = wide_col<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; continue; }
+                deg += st[u] == 0;
+            }
+        }
+        double dv = 0.0;
+        if (deg < a.table_len) dv = a.dinv[deg]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+        dinv[v] = dv;
+    }
+    __syncthreads();
+    // ---- first walk: layer 0 and the second layer's transform
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        if (st[v] != 0) continue;
+        const double dvv = dinv[v];
+        const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+        double z0d = 0.0, z1d = 0.0;
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            double zc[16], acc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                zc[k] = c0 + k < C ? (double)z1c[c0 + k] : 0.0;
+                acc[k] = fma(1.0, zc[k], 0.0);  // the diagonal entry of L comes first
+            }
+            for (int j = rs; j < re; ++j) {
+                const int u = wide_col<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; continue; }
+                if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                if (a.residual && st[u] != 0) continue;
+                const double vd = (double)(float)(-(dinv[u] * dvv));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = fma(vd, zc[k], acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (c0 + k < C) {
+                    double d = (double)z0c[c0 + k] + acc[k];
+                    if (a.bias) d += (double)b0[c0 + k];
+                    const double h = (double)apply_act((float)d, a.act);
+                    z0d = fma(h, (double)w2[2 * (c0 + k)], z0d);
+                    z1d = fma(h, (double)w2[2 * (c0 + k) + 1], z1d);
+                }
+            }
+        }
+        z1[v] = (float)z1d;
+        a.sc[n0 + v] = (float)z0d;  // (read back by this thread below)
+    }
+    __syncthreads();
+    // ---- second walk: the second layer's aggregation at width 1
+    const float bias2 = a.bias2 ? a.bias2[0] : 0.f;
+    for (int v = threadIdx.x; v < ng; v += kWideBlock) {
+        float s = 0.f;
+        if (st[v] == 0) {
+            const double dvv = dinv[v];
+            const int rs = a.row_ptr[n0 + v], re = a.row_ptr[n0 + v + 1];
+            float acc = fmaf(1.0f, z1[v], 0.f);
+            int j = rs;
+            for (; j + 4 <= re; j += 4) {  // four entries' loads in flight, chain order unchanged
+                int u[4];
+                bool keep[4];
+                float val[4], zu[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = wide_col<COLS_LDS>(cl, a.col_idx, j + i, e0, n0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    keep[i] = (unsigned)u[i] < (unsigned)ng;
+                    if (!keep[i]) u[i] = v;
+                    if (a.residual) keep[i] = keep[i] && st[u[i]] == 0;
+                    val[i] = (float)(-(dinv[u[i]] * dvv));
+                    zu[i] = z1[u[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (keep[i]) acc = fmaf(val[i], zu[i], acc);
+            }
+            for (; j < re; ++j) {
+                const int u = wide_col<COLS_LDS>(cl, a.col_idx, j, e0, n0);
+                if ((unsigned)u >= (unsigned)ng) continue;
+                if (a.residual && st[u] != 0) continue;
+                acc = fmaf((float)(-(dinv[u] * dvv)), z1[u], acc);
+            }
+            s = a.sc[n0 + v] + acc;
+            if (a.bias2) s = s + bias2;
+            s = apply_act(s, a.act2);
+        }
+        a.sc[n0 + v] = s;
+    }
+}
+
 template <int LPV>
 __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_raw[];
@@ -252,11 +381,14 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
         __syncthreads();
     }
     // ---- scores.  The priorities' space holds d^-1/2 meanwhile, the row offsets' space z1 per vertex or the scores.
-    const bool need_z1 = a.X != nullptr || a.feature_mode == 1;
+    const bool need_z1 = a.X != nullptr || a.feature_mode == 1 || a.two;
     float* z1 = need_z1 ? reinterpret_cast<float*>(rol) : nullptr;
     float* stash = need_z1 ? nullptr : reinterpret_cast<float*>(rol);
     if (!a.scores_given) {
-        if (cols_lds) wide_scores<true>(a, n0, ng, e0, st, cl, pr, z1, stash, wmax, fault);
+        if (a.two) {  // (the layers' constants in the reduction array's space: free until the totals)
+            if (cols_lds) wide_scores2<true>(a, n0, ng, e0, st, cl, pr, z1, reinterpret_cast<float*>(red + 32), fault);
+            else wide_scores2<false>(a, n0, ng, e0, st, cl, pr, z1, reinterpret_cast<float*>(red + 32), fault);
+        } else if (cols_lds) wide_scores<true>(a, n0, ng, e0, st, cl, pr, z1, stash, wmax, fault);
         else wide_scores<false>(a, n0, ng, e0, st, cl, pr, z1, stash, wmax, fault);
     } else {
         stash = nullptr;
@@ -381,12 +513,18 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // which (batch, model) pairs: one layer F -> 1 over [I, L], F <= 64, graphs of at most 9 600 vertices.  DGCN_WIDE1=0 (read
 // once per process) sends them layer by layer instead (tests compare the two).
-int wide1_takes(const DgcnBatch* b, const DgcnModel* m) {
+int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode) {
     static const bool off = [] { const char* e = getenv("DGCN_WIDE1"); return e && atoi(e) == 0; }();
-    if (off || !b || !m || !m->layers_host || m->num_layers != 1 || m->num_supports != 2) return 0;
+    if (off || !b || !m || !m->layers_host || m->num_supports != 2) return 0;
+    if (b->max_nodes <= 0 || b->max_nodes > kWideMaxNodes) return 0;
     const DgcnLayer& L = m->layers_host[0];
-    if (!L.weights || L.out_dim != 1 || L.in_dim < 1 || L.in_dim > 64) return 0;
-    return b->max_nodes > 0 && b->max_nodes <= kWideMaxNodes;
+    if (!L.weights || L.in_dim < 1 || L.in_dim > 64) return 0;
+    if (m->num_layers == 1) return L.out_dim == 1;
+    // two layers F -> C -> 1, C <= 64, on constant input features (per-vertex features would need the neighbours' C-wide rows)
+    static const bool off2 = [] { const char* e = getenv("DGCN_WIDE2"); return e && atoi(e) == 0; }();
+    if (m->num_layers != 2 || off2 || X || feature_mode != 0) return 0;
+    const DgcnLayer& L1 = m->layers_host[1];
+    return L.out_dim >= 1 && L.out_dim <= 64 && L1.weights && L1.in_dim == L.out_dim && L1.out_dim == 1;
 }
 
 template <int LPV>
@@ -420,6 +558,10 @@ int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     a.dinv = dinv_table; a.table_len = table_len;
     a.X = X; a.x_const = x_const; a.cin = L.in_dim; a.feature_mode = feature_mode;
     a.W = L.weights; a.bias = L.bias; a.act = L.act;
+    if (m->num_layers == 2) {
+        const DgcnLayer& L1 = m->layers_host[1];
+        a.two = 1; a.C = L.out_dim; a.W2 = L1.weights; a.bias2 = L1.bias; a.act2 = L1.act;
+    }
     a.weights = weights; a.predict_mwis = predict_mwis; a.residual = residual; a.scores_given = scores_given; a.mode = mode;
     a.max_rounds = max_rounds;
     a.sc = sc; a.state = state; a.rounds = rounds; a.totals = totals; a.status = status; a.progress = progress;

@@ -312,3 +312,107 @@ def test_one_layer_paths_agree_with_the_layer_by_layer_path(engine, tmp_path):
         else:
             assert np.array_equal(a[k], b[k]), k
     assert a["cit_steps"][0] > 100
+
+
+# ------------------------------------------------------------------------------------------------ two-layer models (F -> C -> 1)
+@pytest.mark.parametrize("n,p,count", [(600, 0.01, 3), (900, 0.02, 2), (513, 0.1, 2), (1500, 0.004, 2), (3000, 0.002, 2), (9600, 0.0005, 1)])
+@pytest.mark.parametrize("hidden,bias", [(32, False), (64, True), (5, True), (16, False)])
+def test_two_layer_solve_any_size_vs_twin(engine, n, p, count, hidden, bias):
+    """The reference launches and ships two-layer models too (num_layer=2 in 13 launcher lines; c32 / c64 / c16 .. l2 checkpoints).
+    Beyond 512 vertices they ran layer by layer; on constant input features wide.hip takes them in one launch (H is formed sixteen
+    features at a time and fed straight into the second layer's transform: no N x C matrix anywhere).  Scores (bits), sets,
+    rounds, totals against the twin; hidden widths 5 .. 64."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    hb = datagen.er_batch(count, n, p, first_index=80)
+    layers = datagen.random_model(2, hidden, bias=bias, seed=hidden)
+    dm = DeviceModel(layers, engine.device)
+    db = engine.upload(hb)
+    assert engine.solve_path(db, dm) == 2
+    ref = ctwin.solve(hb, layers)
+    r = engine.solve_fused(db, dm)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(r["rounds"].cpu().numpy(), ref["rounds"])
+    assert np.allclose(r["totals"].cpu().numpy(), ref["totals"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["dit", "lgs_all", "cit", "rollout", "rollout00", "rollout1"])
+def test_two_layer_residual_steps_equal_the_fused_kernel(engine, golden, general_switch, which):
+    """Two-layer GCN2_DQN (biases, leaky last layer), step by step against the fused residual kernel on fixture graphs - as
+    test_one_layer_residual_steps_equal_the_fused_kernel."""
+    import torch
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    mode_name, max_rounds, (given, by_prio), predict = STEPPERS[which]
+    agent = DQNAgent(_flags(num_layer=2, predict=predict), seed=19)
+    rng = np.random.default_rng(15)
+    for k in agent.model.vars:
+        if k.endswith("/bias"):
+            agent.model.vars[k] = rng.uniform(-0.2, 0.2, agent.model.vars[k].shape).astype(np.float32)
+    agent.model._device_model = None
+    hb = golden.host_batch([2, 7, 1, 0, 12, 8])
+    sl = hb.graph_slices()
+    hb.weights[sl[4][0]:sl[4][1]] = 0.0
+    hb.weights[sl[2][0]:sl[2][0] + 5] = 0.0
+    db = engine.upload(hb)
+    dm = agent.model.device_model(engine)
+    init = np.where(rng.random(hb.num_nodes) < 0.2, rng.integers(1, 3, hb.num_nodes), 0).astype(np.uint8)
+    init[sl[3][0]:sl[3][1]] = 2
+    greedy = getattr(engine, mode_name)
+    options = (engine.SCORES_GIVEN if given else 0) | (engine.COMPLETE_BY_PRIORITY if by_prio else 0)
+    full_scores = None
+    if given:
+        general_switch(None)
+        full_scores = agent.model.forward_batch(engine, db, X=agent._features(hb), mode=1).clone()
+    states, outs = {}, {}
+    for path in (None, 1):
+        general_switch(path)
+        assert engine.solve_path(db, dm) == (1 if path is None else 2)
+        states[path] = torch.from_numpy(init.copy()).to(engine.device)
+        outs[path] = engine.solve_buffers(db, True)
+    steps = 0
+    while True:
+        snap = {}
+        for path in (None, 1):
+            general_switch(path)
+            res = engine.solve_residual(db, dm, states[path], predict=predict, greedy=greedy, max_rounds=max_rounds, beam=6,
+                                        want_scores=True, max_steps=1, out=outs[path], options=options,
+                                        scores=None if full_scores is None else full_scores.clone())
+            engine.check_status(res["status"])
+            snap[path] = (states[path].cpu().numpy().copy(), outs[path]["rounds"].cpu().numpy().copy(),
+                          outs[path]["totals"].cpu().numpy().copy(),
+                          None if given else outs[path]["scores"].cpu().numpy().ravel().copy())
+        a, b = snap[None], snap[1]
+        assert np.array_equal(a[0], b[0]), (which, steps)
+        assert np.array_equal(a[1], b[1]), (which, steps, a[1], b[1])
+        assert np.allclose(a[2], b[2], rtol=1e-12, atol=0), (which, steps)
+        if not given:
+            assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), (which, steps)
+        steps += 1
+        if not a[1].any():
+            break
+        assert steps < 400
+    assert steps > 1
+
+
+@pytest.mark.parametrize("which,n,p", [("dit", 900, 0.01), ("cit", 900, 0.01), ("rollout", 900, 0.01), ("dit", 2000, 0.003)])
+def test_two_layer_iterative_solvers_vs_oracle(engine, which, n, p):
+    """Complete searches with a two-layer model on 900 / 2 000-vertex graphs against the oracle's solvers fed with the twin's scores."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    agent = DQNAgent(_flags(num_layer=2), seed=23)
+    fn = _twin_scores_fn(agent.model.layers)
+    rng = np.random.default_rng(20231100 + n)
+    indptr, indices = datagen.er_graph(n, p, rng)
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    w = rng.random(n)
+    got = agent.solve_iterative_batch([adj], [w], which, b=4)
+    assert got is not None
+    want = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit}[which](fn, adj, w) if which != "rollout" else \
+        orc.solve_mwis_rollout(fn, adj, w, b=4)
+    assert got[0][0] == want[0], (which, n)
+    assert np.allclose(got[0][1], want[1], rtol=1e-12)
