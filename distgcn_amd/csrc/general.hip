@@ -528,26 +528,31 @@ __global__ __launch_bounds__(64) void k_res_pick(ResArgs a) {
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int32_t* cid = a.cid + (size_t)g * kMaxBeam;
-    if (threadIdx.x == 0) {
+    {
+        // a lane per candidate (one wave): its vertex, weight + completion total; the largest by a shuffle tree (a maximum: the
+        // order of the compares does not matter), then the FIRST candidate within 1e-12 relative of it
+        // (first form: thread 0 alone, sixteen dependent pairs of global round trips - 11 us per launch)
+        const int beam = min(a.beam, kMaxBeam);
+        const int lane = threadIdx.x;
+        const bool on = a.active[g] != 0;
+        const int my = (on && lane < beam) ? cid[lane] : -1;
+        double cand = 0.0;
+        if (my >= 0) cand = a.weights[n0 + my] + a.inst_totals[(size_t)lane * a.num_graphs + g];
+        // candidates fill cid from the front: the first -1 ends the list (a lane behind a gap does not count)
+        const unsigned long long valid = __ballot(my >= 0);
+        const int nc = valid == ~0ull ? 64 : __ffsll((long long)~valid) - 1;
+        const bool counts = lane < nc;
+        double mx = counts ? cand : -1.0 / 0.0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        const unsigned long long tied = __ballot(counts && fabs(cand - mx) <= 1e-12 * fabs(mx));
         int c = -1;
-        if (a.active[g] && cid[0] >= 0) {
-            const int beam = min(a.beam, kMaxBeam);
-            int nc = 0;
-            while (nc < beam && cid[nc] >= 0) ++nc;
-            double cand[kMaxBeam];
-            double mx = 0.0;
-            for (int i = 0; i < nc; ++i) {
-                cand[i] = a.weights[n0 + cid[i]] + a.inst_totals[(size_t)i * a.num_graphs + g];
-                mx = i == 0 ? cand[0] : fmax(mx, cand[i]);
-            }
-            int best = 0;
-            for (int i = 0; i < nc; ++i)
-                if (fabs(cand[i] - mx) <= 1e-12 * fabs(mx)) { best = i; break; }
-            c = cid[best];
+        if (nc > 0 && tied) c = __shfl(my, __ffsll((long long)tied) - 1);
+        if (threadIdx.x == 0) {
+            s_c = c;
+            if (a.rounds) a.rounds[g] = c < 0 ? 0 : 1;
+            if (a.totals) a.totals[g] = c < 0 ? 0.0 : a.weights[n0 + c];
         }
-        s_c = c;
-        if (a.rounds) a.rounds[g] = c < 0 ? 0 : 1;
-        if (a.totals) a.totals[g] = c < 0 ? 0.0 : a.weights[n0 + c];
     }
     __syncthreads();
     const int c = s_c;
