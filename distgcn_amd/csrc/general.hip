@@ -459,7 +459,9 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
         int bv = -1;
 #pragma unroll
         for (int i = 0; i < kPer; ++i)  // ascending vertex index: the first maximum stays
-            if (((have >> i) & 1u) && (bv < 0 || pv[i] > bp)) { bp = pv[i]; bv = (int)threadIdx.x + i * kResBlock; }
+            if (i < per) {  // (uniform: a graph of up to 1 024 vertices has one vertex per thread)
+                if (((have >> i) & 1u) && (bv < 0 || pv[i] > bp)) { bp = pv[i]; bv = (int)threadIdx.x + i * kResBlock; }
+            }
         // the best of the wave: inside a row of sixteen lanes by DPP (quad swaps, half-row and row mirrors: every lane ends with
         // its row's best), across the four rows through scalar registers
         cand_dpp_max<0xB1>(bp, bv);   // quad_perm [1, 0, 3, 2]
