@@ -144,7 +144,10 @@ __device__ __forceinline__ void b2_mma3(const float (&b0)[8], const float (&b1)[
     o2 = make_float4(a2[0], a2[1], a2[2], a2[3]);
 }
 
-template <int TILES>
+// RESID: compiled with the residual-step code (big2_residual; big.hip's k_big<.., RESID> is the model): `state` is the running
+// state, the residual graph's support is formed from the adjacency and the state while the records are written, the greedy step
+// (rounds / central pick / priorities out) runs on the undecided vertices
+template <int TILES, bool RESID = false>
 __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
     const int g = blockIdx.x;
@@ -164,9 +167,39 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
     int* ttrips = reinterpret_cast<int*>(b2_lds + a.lds_tab_off);  // [kB2MaxTiles] trips per tile
     unsigned* tbase = reinterpret_cast<unsigned*>(ttrips + kB2MaxTiles);  // [kB2MaxTiles] first record of a tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles = (ng + 15) >> 4;
     uint2* rec = a.rec + (size_t)g * a.rec_cap;
     int fault = 0;
+    constexpr bool resid = RESID;
+    uint8_t* alive = reinterpret_cast<uint8_t*>(b2_lds);  // (residual steps) in the Z1h space until S1 of the first layer writes there
+    int nr = ng;  // rows of the (residual) graph: its undecided vertices
+    if (resid) {
+        if (threadIdx.x < 2) ttrips[threadIdx.x] = 0;
+        __syncthreads();
+        int c_al = 0, pos = 0;
+        for (int v = threadIdx.x; v < ng; v += kB2Block) {
+            const bool al = a.state[n0 + v] == 0;
+            alive[v] = al ? 1 : 0;
+            c_al += al;
+            pos |= al && (a.weights ? a.weights[n0 + v] : 1.0) > 0.0;
+        }
+        if (c_al) atomicAdd(&ttrips[0], c_al);
+        if (pos) atomicOr(&ttrips[1], 1);
+        __syncthreads();
+        nr = ttrips[0];
+        const int any_pos = ttrips[1];
+        __syncthreads();
+        // nothing left, or no positive weight left (np.sum(wts_nn) <= 0 -> break, mwis_gdpg_call.py:286): the graph is left alone
+        if (!any_pos) {
+            if (threadIdx.x == 0) {
+                if (a.rounds) a.rounds[g] = 0;
+                if (a.totals) a.totals[g] = 0.0;
+                if (a.active) a.active[g] = 0;
+            }
+            for (int v = threadIdx.x; v < ng; v += kB2Block) a.scores[n0 + v] = 0.f;
+            return;
+        }
+    }
+    const int tiles = (nr + 15) >> 4;
 #ifdef DGCN_DIAG
     unsigned long long b2_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long b2_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -178,7 +211,19 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
     if (threadIdx.x < 16) reinterpret_cast<float*>(b2_lds + zrow)[threadIdx.x] = 0.f;
     __syncthreads();
     for (int v = threadIdx.x; v < ng; v += kB2Block) {
-        const unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
+        unsigned c = a.arow ? (unsigned)(a.arow[n0 + v + 1] - a.arow[n0 + v]) + 1u : (unsigned)(a.lrow[n0 + v + 1] - a.lrow[n0 + v]);
+        if (resid) {  // degree in the residual graph; a decided vertex has no row (count 0: it sorts behind every undecided one)
+            c = 0;
+            if (alive[v]) {
+                c = 1;
+                const int rs = a.arow[n0 + v], re = a.arow[n0 + v + 1];
+#pragma unroll 4
+                for (int j = rs; j < re; ++j) {
+                    const int u = a.acol[j] - n0;
+                    if ((unsigned)u < (unsigned)ng) c += alive[u];
+                }
+            }
+        }
         cnt[v] = (unsigned short)min(c, 65535u);
         atomicAdd(&hist[min((int)c, kB2Bins - 1)], 1);
     }
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
 #pragma unroll 4
                 for (int j = 0; j < 16; ++j) {
                     const int sl = tt * 16 + j;
-                    if (sl < ng) longest = max(longest, (int)cnt[perm[sl]]);
+                    if (sl < nr) longest = max(longest, (int)cnt[perm[sl]]);
                 }
             }
             tl[r] = tt < tiles ? max(1, (longest + 3) >> 2) : 0;
@@ -245,7 +290,8 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         for (int v = threadIdx.x; v < ng; v += kB2Block) {
             const int d = (int)cnt[v] - 1;
             double x = 0.0;
-            if (d < a.table_len) x = a.dinv[d]; else fault |= DGCN_FAULT_DEGREE_RANGE;
+            if (d >= a.table_len) fault |= DGCN_FAULT_DEGREE_RANGE;
+            else if (d >= 0) x = a.dinv[d];  // (a decided vertex of a residual step has no row: nobody reads its slot)
             dvl[v] = x;
         }
     }
@@ -257,13 +303,41 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);
         const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[t]);
         const int slot = t * 16 + s16;
-        const bool has = slot < ng;
+        const bool has = slot < nr;
         const int v = has ? (int)perm[slot] : 0;
         const int start = has ? (a.arow ? a.arow[n0 + v] : a.lrow[n0 + v]) : 0;
         const int c = has ? (a.arow ? a.arow[n0 + v + 1] - start + 1 : a.lrow[n0 + v + 1] - start) : 0;
         const double dv = (a.arow && has) ? dvl[v] : 0.0;
         uint2* out = rec + base + lane;
         const uint2 nothing = make_uint2(0x80000000u, zrow);  // {-0.0f, zero row}: fmaf(-0.0f, +0.0f, acc) == acc for every acc
+        if (resid) {
+            // the row of the RESIDUAL graph: the diagonal, then the undecided neighbours in CSR order, compacted by a prefix count
+            // within the row's quad (big.hip: k_big<.., RESID>)
+            uint2* rowout = rec + base + s16 * 4;
+            const int raw = has ? c - 1 : 0;
+            if (has && kq4 == 0) rowout[0] = make_uint2(__float_as_uint(1.0f), b2_word(v));
+            int pos = has ? 1 : 0;
+            for (int j0 = 0; __any(j0 < raw); j0 += 4) {
+                const int j = j0 + kq4;
+                int u = -1;
+                if (j < raw) {
+                    u = a.acol[start + j] - n0;
+                    if ((unsigned)u >= (unsigned)ng) { fault |= DGCN_FAULT_BAD_COLUMN; u = -1; }
+                    else {
+                        if (u == v) fault |= DGCN_FAULT_SELF_LOOP;
+                        if (!alive[u]) u = -1;
+                    }
+                }
+                const bool keep = u >= 0;
+                const unsigned q = (unsigned)(__ballot(keep) >> (lane & ~3)) & 0xfu;
+                if (keep) {
+                    const int p = pos + __popc(q & ((1u << kq4) - 1u));
+                    if (p < 4 * trips) rowout[(p >> 2) * 64 + (p & 3)] = make_uint2(__float_as_uint((float)(-(dvl[u] * dv))), b2_word(u));
+                }
+                pos += __popc(q);
+            }
+            for (int p = pos + kq4; p < 4 * trips; p += 4) rowout[(p >> 2) * 64 + (p & 3)] = nothing;
+        } else
         for (int t0 = 0; t0 < trips; t0 += 4) {
             int uu[4];
             float vv[4];
@@ -337,7 +411,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         const int t = wave + kB2Waves * k;                                                                             \
         const int trips = __builtin_amdgcn_readfirstlane(ttrips[t]);                                                   \
         const int slot = t * 16 + s16;                                                                                 \
-        const bool has = slot < ng;                                                                                    \
+        const bool has = slot < nr;                                                                                    \
         (void)has;
     // the records of a wave's tiles as one stream of groups (four trips each), requested two groups ahead of the walk (big.hip)
 #define B2_PREFETCH(X)                                                                                                   \
@@ -496,8 +570,8 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                     float4 o0, o1;
                     b2_mma2(bcol, h0, h1, f64, o0, o1);
                     const int mslot = t * 16 + mr, mslot1 = mslot + kB2Waves * 16;
-                    if (mslot < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o0;
-                    if (k + 1 < TILES && mslot1 < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot1] * 16 + 4 * mq) = o1;
+                    if (mslot < nr) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o0;
+                    if (k + 1 < TILES && mslot1 < nr) *reinterpret_cast<float4*>(bufH + (int)perm[mslot1] * 16 + 4 * mq) = o1;
                 }
             }
         }
@@ -560,7 +634,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                 if (FUSE) b2_mma2b(bcol, bz1, hh, f64, o, z0b);
                 else b2_mma3(bcol, bz0, bz1, hh, f64, o, z0a, z0b);
                 const int mslot = t * 16 + mr;
-                if (mslot < ng) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o;
+                if (mslot < nr) *reinterpret_cast<float4*>(bufH + (int)perm[mslot] * 16 + 4 * mq) = o;
                 // MFMA output layout (row mr: chunk mq of z0a, chunk 4 + mq of z0b) -> aggregation layout
                 if (!FUSE) *reinterpret_cast<float4*>(stg + mr * kBH + ((mq ^ (mr & 7)) << 2)) = z0a;
                 *reinterpret_cast<float4*>(stg + mr * kBH + (((4 + mq) ^ (mr & 7)) << 2)) = z0b;
@@ -645,7 +719,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         const int slot = (wave + kB2Waves * k) * 16 + s16;
         float4 zq01 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (wave + kB2Waves * k < tiles) B2_LO_GET(k, zq01)
-        if (slot < ng && kq4 == 0) zl[perm[slot]] = zq01.y;
+        if (slot < nr && kq4 == 0) zl[perm[slot]] = zq01.y;
     }
     if (threadIdx.x == 0) zl[a.max_nodes] = 0.f;  // the neutral record's neighbour
     __syncthreads();
@@ -701,9 +775,17 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         __syncthreads();  // every priority is written, every walk over z1 done
         int bad = 0;
         for (int v = threadIdx.x; v < ng; v += kB2Block) {
-            const double p = pr[v];
-            bad |= p != p;
-            st[v] = 0;
+            // (residual step) who takes part: the vertices that were undecided when the launch began (read again: the Z1h space held
+            // the alive bytes only until the first layer); a decided vertex reports score 0 and keeps state 3 = "not part of this"
+            const bool part = !resid || a.state[n0 + v] == 0;
+            if (part) {
+                const double p = pr[v];
+                bad |= p != p;
+            } else {
+                a.scores[n0 + v] = 0.f;
+                pr[v] = 0.0;
+            }
+            st[v] = part ? 0 : 3;
             nw[v] = 0;
         }
         for (int v = threadIdx.x; v <= ng; v += kB2Block) rol[v] = a.arow[n0 + v];
@@ -726,22 +808,81 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                 atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
                 if (a.rounds) a.rounds[g] = -1;
                 if (a.totals) a.totals[g] = 0.0;
+                if (a.active) a.active[g] = 0;
             }
-            for (int v = threadIdx.x; v < ng; v += kB2Block) a.state[n0 + v] = 0;
+            if (!resid) for (int v = threadIdx.x; v < ng; v += kB2Block) a.state[n0 + v] = 0;
             return;
         }
         __syncthreads();  // (acc64[3] is the rounds' vote word from here on)
+        if (resid && threadIdx.x == 0) {
+            if (a.progress) atomicAdd(a.progress, 1);
+            if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)nr);
+        }
+        if (resid && a.greedy_mode == 2) {  // the rollout: priorities out; candidates, instances, completions and the pick are general.hip's launches
+            for (int v = threadIdx.x; v < ng; v += kB2Block) a.prio_out[n0 + v] = st[v] == 0 ? pr[v] : 0.0;
+            if (threadIdx.x == 0 && a.active) a.active[g] = 1;
+            if (fault) atomicOr(a.status, fault);
+            return;
+        }
+        if (resid && a.greedy_mode == 1) {
+            // solve_mwis_cit: the best-priority undecided vertex joins (np.argmax: lowest index among equals), its neighbours leave
+            double bp = 0.0;
+            int bv = -1;
+            for (int v = threadIdx.x; v < ng; v += kB2Block) {
+                if (st[v] != 0) continue;
+                const double p = pr[v];
+                if (bv < 0 || p > bp) { bp = p; bv = v; }  // ascending v per thread: the first maximum stays
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double op = __shfl_xor(bp, off);
+                const int ov = __shfl_xor(bv, off);
+                if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+            }
+            int* ri = reinterpret_cast<int*>(red + 16);
+            if (lane == 0) { red[wave] = bp; ri[wave] = bv; }
+            __syncthreads();
+            bp = red[0]; bv = ri[0];
+#pragma unroll
+            for (int w = 1; w < kB2Waves; ++w) {
+                const double op = red[w];
+                const int ov = ri[w];
+                if (ov >= 0 && (bv < 0 || op > bp || (op == bp && ov < bv))) { bp = op; bv = ov; }
+            }
+            if (bv >= 0) {
+                for (int j = rol[bv] + (int)threadIdx.x; j < rol[bv + 1]; j += kB2Block) {
+                    const int u = a.acol[j] - n0;
+                    if ((unsigned)u < (unsigned)ng && u != bv && st[u] == 0) a.state[n0 + u] = 2;
+                }
+                if (threadIdx.x == 0) {
+                    a.state[n0 + bv] = 1;
+                    if (a.rounds) a.rounds[g] = 1;
+                    if (a.totals) a.totals[g] = a.weights ? a.weights[n0 + bv] : bp;
+                }
+            }
+            if (fault) atomicOr(a.status, fault);
+            return;
+        }
         LgsArgs la = {};
         la.col_idx = a.acol;
         la.rounds = a.rounds;
+        la.max_rounds = resid ? a.max_rounds : 0;
+        la.init_state = resid ? a.state : nullptr;  // (only its being there matters: the rounds count who takes part from `st`)
         if (cols_lds) lgs_rounds<1, false, true, kB2Block, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
         else lgs_rounds<1, false, false, kB2Block, true>(la, g, n0, ng, e0, pr, st, nw, nullptr, acc64, rol);
         {
             double part = 0.0;
             for (int v = threadIdx.x; v < ng; v += kB2Block) {
                 const uint8_t s1 = st[v];
-                if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
-                a.state[n0 + v] = s1;
+                if (resid) {
+                    if (s1 == 1 || s1 == 2) {  // (3: decided before this step, 0: still undecided after max_rounds rounds)
+                        if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
+                        a.state[n0 + v] = s1;
+                    }
+                } else {
+                    if (a.totals && s1 == 1) part += a.weights ? a.weights[n0 + v] : pr[v];
+                    a.state[n0 + v] = s1;
+                }
             }
             red[threadIdx.x] = part;
         }
@@ -850,20 +991,20 @@ static void b2_carve(BigArgs& a, const DgcnBatch* b, void* bws) {
     a.stash = reinterpret_cast<float4*>(w + b2_256(B * (size_t)b2_rec_cap(b) * 8));
 }
 
-template <int TILES>
+template <int TILES, bool RESID = false>
 static int big2_launch_t(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         static std::atomic<int> reserved[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!reserved[dev & 63].load(std::memory_order_relaxed)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big2<TILES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big2<TILES, RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(DGCN_ERR_LAUNCH, "k_big2: cannot reserve %zu bytes of LDS", lds);
             reserved[dev & 63].store(1, std::memory_order_relaxed);
         }
     }
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_big2<TILES>), dim3((unsigned)B), dim3(kB2Block), lds, s, a);
+    DGCN_LAUNCH(t, (k_big2<TILES, RESID>), dim3((unsigned)B), dim3(kB2Block), lds, s, a);
     return check_launch("k_big2");
 }
 
@@ -873,6 +1014,11 @@ static int big2_launch(BigArgs& a, int B, size_t lds, const char* family, hipStr
     a.stamps = getenv("DGCN_BIG_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_BIG_STAMPS"), nullptr, 0) : nullptr;
 #endif
     const int per_wave = (a.max_nodes / 16 + kB2Waves - 1) / kB2Waves;  // tiles a wave owns at most
+    if (a.residual) {
+        if (per_wave <= 8) return big2_launch_t<8, true>(a, B, lds, family, s);
+        if (per_wave <= 12) return big2_launch_t<12, true>(a, B, lds, family, s);
+        return big2_launch_t<15, true>(a, B, lds, family, s);
+    }
     if (per_wave <= 8) return big2_launch_t<8>(a, B, lds, family, s);
     if (per_wave <= 12) return big2_launch_t<12>(a, B, lds, family, s);
     return big2_launch_t<15>(a, B, lds, family, s);
@@ -954,6 +1100,39 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
     const size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
                                 b2_lgs_lds(a.max_nodes));
     return big2_launch(a, b->num_graphs, lds, "big_solve", s);
+}
+
+// One step of dgcn_solve_residual_batch in ONE launch on k_big2's shapes (constant input features): big.hip's big_residual for
+// graphs of 977 .. 1 920 vertices.  DGCN_BIG_RESIDUAL=0: the compaction launches + k_big2 + k_lgs instead.
+int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options) {
+    static const int on = [] { const char* e = getenv("DGCN_BIG_RESIDUAL"); return e ? atoi(e) : -1; }();
+    if (on == 0 || feature_mode != 0 || (options & DGCN_RESIDUAL_SCORES_GIVEN)) return 0;
+    return big2_solve_takes(b, m, X);
+}
+
+int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
+                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
+                  unsigned long long tail_tag, void* bws, hipStream_t s) {
+    BigArgs a = {};
+    a.graph_ptr = b->graph_ptr;
+    a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
+    b2_carve(a, b, bws);
+    a.status = status;
+    a.rec_cap = b2_rec_cap(b);
+    a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
+    a.front = 1;
+    a.scores = scores;
+    a.do_lgs = 1; a.predict_mwis = predict_mwis;
+    a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
+    a.residual = 1; a.greedy_mode = greedy_mode; a.max_rounds = max_rounds;
+    a.progress = progress; a.tail_word = tail_word; a.tail_tag = tail_tag;
+    a.prio_out = greedy_mode == 2 ? prio : nullptr;
+    a.active = greedy_mode == 2 ? active : nullptr;
+    big2_fill_model(a, m, x_const);
+    const size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                                b2_lgs_lds(a.max_nodes));
+    return big2_launch(a, b->num_graphs, lds, "big_residual", s);
 }
 
 }  // namespace dgcn

@@ -61,6 +61,12 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
                int32_t predict_mwis, float* scores, uint8_t* state, int32_t* rounds, double* totals, int32_t* status, void* bws,
                hipStream_t s);
 
+int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options);
+int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
+                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
+                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
+                  unsigned long long tail_tag, void* bws, hipStream_t s);
+
 // wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
 // in one launch
 int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode);
@@ -718,6 +724,11 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
                                     state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, bws, s);
         if (rc || greedy_mode != 2) return rc;
         wide = true;  // (what follows is the same as behind the one-layer kernel: the rollout's launches)
+    } else if (!wide && big2 && big2_residual_takes(b, m, X, feature_mode, options)) {  // the same for 977 .. 1 920 vertices (k_big2)
+        const int rc = big2_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
+                                     state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, bws, s);
+        if (rc || greedy_mode != 2) return rc;
+        wide = true;
     } else
     if (wide) {
         // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE

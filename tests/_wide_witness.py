@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_wide.py / test_gpu_general.py: complete dit / cit / rollout searches and a plain solve on
-three ragged ~900-vertex graphs, results to an .npz: python _wide_witness.py out.npz [num_layer=1].  Run twice - as built
+three ragged ~900-vertex graphs (or ~`nodes`), results to an .npz: python _wide_witness.py out.npz [num_layer=1] [nodes=900].  Run twice - as built
 and with a switch of the library set in the environment (DGCN_WIDE1=0: one-layer models layer by layer instead of
 csrc/wide.hip; DGCN_BIG_RESIDUAL=0: the residual steps of deep models through the compaction launches + k_big + k_lgs
 instead of one launch of k_big) - the two files must hold the same bytes / bits."""
@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(out_path, num_layer=1):
+def main(out_path, num_layer=1, nodes=900):
     import torch
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
@@ -19,7 +19,7 @@ def main(out_path, num_layer=1):
     import scipy.sparse as sp
     rng = np.random.default_rng(99)
     mats, ws = [], []
-    for n in (900, 871, 640):
+    for n in (nodes, nodes - 29, nodes - 260 if nodes < 1200 else nodes - 400):
         ip, ix = datagen.er_graph(n, 0.012, rng)
         mats.append(sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(n, n)))
         w = rng.random(n)
@@ -48,4 +48,4 @@ def main(out_path, num_layer=1):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 900)

@@ -140,3 +140,25 @@ def test_any_size_suite_through_big2(engine):
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_big2_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp_path):
+    """A residual step on 977 .. 1 920-vertex graphs is one launch of k_big2<.., RESID> too (the residual graph's support from the
+    adjacency and the running state).  Complete dit / cit / rollout searches on three ragged ~1 500-vertex graphs (zero weights
+    inside live graphs, biases, leaky last layer) by a child process as built and by one with DGCN_BIG_RESIDUAL=0 - the compaction
+    launches + k_big2 + k_lgs: same states, step counts, score bits."""
+    script = os.path.join(ROOT, "tests", "_wide_witness.py")
+    files = {}
+    for tag, val in (("one_launch", "1"), ("compaction", "0")):
+        files[tag] = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, script, files[tag], "4", "1500"], check=True, env=dict(os.environ, DGCN_BIG_RESIDUAL=val), timeout=900)
+    a, b = np.load(files["one_launch"]), np.load(files["compaction"])
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k.endswith("_scores"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        elif k.endswith("_totals"):
+            assert np.allclose(a[k], b[k], rtol=1e-12), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+    assert a["cit_steps"][0] > 100
