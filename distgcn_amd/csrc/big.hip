@@ -37,6 +37,13 @@
 
 namespace dgcn {
 
+// (DGCN_DIAG builds, DGCN_BIG_DIAG_REC=1: every walk reads its tile's FIRST record group again and again - wrong results, a timing
+// experiment: what would the launch cost if the support's records did not have to stream from the L2 / MALL?)
+#ifdef DGCN_DIAG
+#define BIG_DIAG_SAME_GROUP (a.lgs_cols_lds == 2)
+#else
+#define BIG_DIAG_SAME_GROUP false
+#endif
 #ifdef DGCN_DIAG
 #define BIG_STAMP(i)                                                   \
     do {                                                               \
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             if (pf_k < TILES && pt_ < tiles) { /* (wave-uniform) */                                                    \
                 const int ptr_ = __builtin_amdgcn_readfirstlane(ttrips[pt_]);                                          \
                 const unsigned pb_ = (unsigned)__builtin_amdgcn_readfirstlane((int)tbase[pt_]);                        \
-                big_load_group(X, reinterpret_cast<const char*>(rec + pb_) + (size_t)pf_j * 2048 + voff); /* (its last trips may lie past the tile: never walked) */ \
+                big_load_group(X, reinterpret_cast<const char*>(rec + pb_) + (size_t)(BIG_DIAG_SAME_GROUP ? 0 : pf_j) * 2048 + voff); /* (its last trips may lie past the tile: never walked) */ \
                 pf_j += 1;                                                                                             \
                 if (pf_j * 4 >= ptr_) { pf_j = 0; pf_k += 1; }                                                         \
             }                                                                                                          \
@@ -962,6 +969,7 @@ static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* fami
 #ifdef DGCN_DIAG
     a.stamps = getenv("DGCN_BIG_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_BIG_STAMPS"), nullptr, 0) : nullptr;
     a.num_graphs_diag = B;
+    if (getenv("DGCN_BIG_DIAG_REC") && atoi(getenv("DGCN_BIG_DIAG_REC"))) a.lgs_cols_lds = 2;
 #endif
     // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
     const bool two = a.max_nodes <= 16 * 2 * (block / 64) && big_env_tiles() != 4;
