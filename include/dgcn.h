@@ -302,9 +302,12 @@ int dgcn_lgs_masked_batch(const DgcnBatch* batch, const double* prio, int64_t pr
 int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
 /* Graphs beyond that (the multi-channel joint conflict graphs of wireless_dqn_test_mc.py:161 have K * nflows vertices;
  * ER(500, 0.1) already has more entries than one CU's LDS holds) and layer stacks wider than 32 take the ANY-SIZE path
- * inside the same two entry points: the residual graph is re-sliced on the device (renumbered, with its own support),
- * the forward pass runs layer by layer (mode 0's kernels: same bits), the greedy step in kernels of its own - nothing
- * returns to the host, nothing changes in the results.  dgcn_solve_path: 1 = fused kernels, 2 = any-size path (graphs
+ * inside the same two entry points.  One launch where a kernel takes the shape: one- and two-layer models (the multi-channel
+ * launchers' own --num_layer=1, bash/twc_major_wireless_mc_test.sh:3) up to 9 600 vertices, deep c32 stacks up to 976 vertices
+ * with any number of entries and up to 1 920 vertices beyond that - a residual step likewise (the residual graph's support is
+ * formed from the adjacency and the running state inside the launch).  Otherwise the residual graph is re-sliced on the device
+ * (renumbered, with its own support), the forward pass runs layer by layer (mode 0's kernels: same bits), the greedy step in
+ * kernels of its own.  Nothing returns to the host, nothing changes in the results.  dgcn_solve_path: 1 = fused kernels, 2 = any-size path (graphs
  * up to 9 600 vertices, [I, L] models with one output per vertex), 0 = neither (DGCN_ERR_UNSUPPORTED).
  * dgcn_set_general(1) sends every shape down the any-size path (tests, A/B runs); -1 = automatic (default; initialised
  * once from the environment variable DGCN_GENERAL). */
