@@ -45,6 +45,32 @@ def test_generators_deterministic_and_well_formed():
     assert m.nnz // 2 == (100 - 21) * 20 + 20
 
 
+def test_multichannel_batch_generator_is_seeded_and_well_formed():
+    """datagen.multichannel_batch (the MC900 / MC900-l1 / MC1500 bench and parity configurations): K per-channel copies of a
+    seeded conflict graph joined as wireless_rollout_test_flood.py:98-133 joins them - K * nflows vertices, symmetric, no
+    self-loops, every flow's copies a clique across the channels; the same graphs for the same index whatever the batch
+    they are drawn in (a rank of a sharded job generates its own range)."""
+    from distgcn_amd import datagen
+    a = datagen.multichannel_batch(3, 40, 0.1, first_index=5)
+    b = datagen.multichannel_batch(1, 40, 0.1, first_index=6)
+    assert a.num_graphs == 3 and a.max_nodes == 120 and np.all(np.diff(a.graph_ptr) == 120)
+    g1 = a.scipy_graph(1).tocsr()
+    assert (g1 != b.scipy_graph(0).tocsr()).nnz == 0 and np.array_equal(a.weights[120:240], b.weights)
+    assert g1.diagonal().sum() == 0 and (g1 != g1.T).nnz == 0
+    dense = g1.toarray()
+    for f in range(40):  # the copies of flow f on the three channels conflict with each other
+        for c1 in range(3):
+            for c2 in range(3):
+                if c1 != c2:
+                    assert dense[c1 * 40 + f, c2 * 40 + f] == 1.0
+    # nothing links different flows across channels
+    for c1 in range(3):
+        for c2 in range(3):
+            if c1 != c2:
+                blk = dense[c1 * 40:(c1 + 1) * 40, c2 * 40:(c2 + 1) * 40]
+                assert np.array_equal(blk, np.eye(40))
+
+
 def test_shard_ranges_cover_and_balance():
     hb = datagen.ba_test2_batch(50)
     for world in (1, 2, 3, 8):
