@@ -34,6 +34,7 @@
 #include "common.h"
 #include "lgs_rounds.h"
 #include "big_common.h"
+#include "cand_select.h"
 
 namespace dgcn {
 
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
     extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
+    if (RESID && a.cid && threadIdx.x < kCandMaxBeam) a.cid[(size_t)g * kCandMaxBeam + threadIdx.x] = -1;  // (a graph left alone has no candidates)
     if (ng <= 0) {
         if (a.do_lgs && threadIdx.x == 0) {  // an empty graph: no rounds, total 0 (heuristics.py's loops do not run)
             if (a.rounds) a.rounds[g] = 0;
@@ -697,6 +699,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
             if (tv < ng) a.prio_out[n0 + tv] = part ? pr[tv] : 0.0;
             if (threadIdx.x == 0 && a.active) a.active[g] = 1;
             if (fault) atomicOr(a.status, fault);
+            if (a.cid) {  // the candidates right here (a thread per vertex, the priorities at hand): no k_res_cand launch
+                int32_t* cid = a.cid + (size_t)g * kCandMaxBeam;
+                double pv[kCandPer];
+#pragma unroll
+                for (int i = 0; i < kCandPer; ++i) pv[i] = 0.0;
+                pv[0] = part ? pr[tv] : 0.0;
+                __syncthreads();  // (the staging tiles' space is free: the last walk is behind the barriers above)
+                cand_select<BLOCK>(pv, part ? 1u : 0u, 1, min(a.beam, kCandMaxBeam), cid, big_lds + a.lds_stage_off);
+            }
             return;
         }
         if (resid && a.greedy_mode == 1) {
@@ -1022,8 +1033,8 @@ int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, i
 
 int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
-                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
-                 unsigned long long tail_tag, void* bws, hipStream_t s) {
+                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
+                 unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s) {
     BigArgs a = {};
     a.graph_ptr = b->graph_ptr;
     a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
@@ -1039,6 +1050,8 @@ int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tabl
     a.progress = progress; a.tail_word = tail_word; a.tail_tag = tail_tag;
     a.prio_out = greedy_mode == 2 ? prio : nullptr;
     a.active = greedy_mode == 2 ? active : nullptr;
+    a.cid = greedy_mode == 2 ? cid : nullptr;
+    a.beam = beam;
     big_fill_model(a, m, x_const);
     int block = big_block(a.max_nodes);
     size_t lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),

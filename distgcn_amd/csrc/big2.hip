@@ -26,6 +26,7 @@
 #include "common.h"
 #include "lgs_rounds.h"
 #include "big_common.h"
+#include "cand_select.h"
 
 namespace dgcn {
 
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], ng = a.graph_ptr[g + 1] - n0;
+    if (RESID && a.cid && threadIdx.x < kCandMaxBeam) a.cid[(size_t)g * kCandMaxBeam + threadIdx.x] = -1;  // (a graph left alone has no candidates)
     if (ng <= 0) {
         if (a.do_lgs && threadIdx.x == 0) {
             if (a.rounds) a.rounds[g] = 0;
@@ -822,6 +824,21 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
             for (int v = threadIdx.x; v < ng; v += kB2Block) a.prio_out[n0 + v] = st[v] == 0 ? pr[v] : 0.0;
             if (threadIdx.x == 0 && a.active) a.active[g] = 1;
             if (fault) atomicOr(a.status, fault);
+            if (a.cid) {  // the candidates right here: no k_res_cand launch (cand_select.h; the staging tiles' space is free)
+                static_assert(kCandPer * kB2Block >= kB2MaxNodes, "a thread holds its vertices' priorities in registers");
+                int32_t* cid = a.cid + (size_t)g * kCandMaxBeam;
+                double pv[kCandPer];
+                unsigned have = 0u;
+                const int per = (ng + kB2Block - 1) / kB2Block;
+#pragma unroll
+                for (int i = 0; i < kCandPer; ++i) {
+                    const int v = (int)threadIdx.x + i * kB2Block;
+                    pv[i] = 0.0;
+                    if (i < per && v < ng && st[v] == 0) { pv[i] = pr[v]; have |= 1u << i; }
+                }
+                __syncthreads();
+                cand_select<kB2Block>(pv, have, per, min(a.beam, kCandMaxBeam), cid, b2_lds + a.lds_stage_off);
+            }
             return;
         }
         if (resid && a.greedy_mode == 1) {
@@ -1112,8 +1129,8 @@ int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, 
 
 int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                   int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
-                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
-                  unsigned long long tail_tag, void* bws, hipStream_t s) {
+                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
+                  unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s) {
     BigArgs a = {};
     a.graph_ptr = b->graph_ptr;
     a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
@@ -1129,6 +1146,8 @@ int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     a.progress = progress; a.tail_word = tail_word; a.tail_tag = tail_tag;
     a.prio_out = greedy_mode == 2 ? prio : nullptr;
     a.active = greedy_mode == 2 ? active : nullptr;
+    a.cid = greedy_mode == 2 ? cid : nullptr;
+    a.beam = beam;
     big2_fill_model(a, m, x_const);
     const size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
                                 b2_lgs_lds(a.max_nodes));

@@ -54,6 +54,8 @@ struct BigArgs {
     int32_t* progress;
     int32_t* active;       // greedy_mode 2: [num_graphs] out
     double* prio_out;      // greedy_mode 2: [num_nodes] out
+    int32_t* cid;          // greedy_mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
+    int32_t beam;
     unsigned long long* tail_word;
     unsigned long long tail_tag;
     const float* Zin;      // front == 0: [num_nodes][64] Z0 | Z1 of layer index 1 (explicit input features: the caller ran

@@ -938,6 +938,80 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
     return r;
 }
 
+// Ranks under (value desc, index asc) of the ng <= 512 vertices of an image (every one of them takes part):
+//     rank[v] = #{w : val[w] > val[v]} + #{w < v : val[w] == val[v]}
+// NK arrays at once (the rollout ranks priorities and weights).  First form: a lane or two per vertex, looping over every w -
+// one float64 LDS read per PAIR of vertices, and the LDS pipe's time with it: 49 of a rollout step's 306 us at 500 vertices
+// (profiles/r04_residual_step_phases.txt).  Here a lane keeps four vertices' values in registers and a wave meets each w of
+// its share once, a read all its lanes share: a quarter-thousand reads per wave instead of sixty thousand, two VALU
+// instructions per pair.  The waves split the w range; their partial counts meet in LDS counters.  Only `>` is counted: values
+// that are all different give counts that add up to ng (ng - 1) / 2, equal values share a count and the sum falls short - then
+// (and only then) every vertex adds the equal values below its index.  `cnt`: NK * cstride + NK words of LDS, cstride >= ng.
+// Barriers inside; the caller passes one before (values written) and one after (ranks written).
+template <int BLOCK, int NK>
+__device__ __forceinline__ void rank_blocked(int ng, const double* val0, const double* val1, unsigned* cnt, int cstride,
+                                             unsigned short* out0, unsigned short* out1) {
+    constexpr int W = BLOCK / 64, KV = 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tv = threadIdx.x;
+    for (int i = threadIdx.x; i < NK * cstride + NK; i += BLOCK) cnt[i] = 0u;
+    __syncthreads();
+    const int VB = (ng + 64 * KV - 1) / (64 * KV);  // blocks of 256 vertices: 1 or 2
+    const int WS = W / VB;                          // waves per block: each takes a share of the w range
+    const int vb = wave % VB, ws = wave / VB;
+    if (ws < WS) {
+        const int w_lo = ws * ng / WS, w_hi = (ws + 1) * ng / WS;
+#pragma unroll
+        for (int key = 0; key < NK; ++key) {
+            const double* val = key ? val1 : val0;
+            double pv[KV];
+            int c[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int v = (vb * KV + k) * 64 + lane;
+                pv[k] = v < ng ? val[v] : 1.0 / 0.0;
+                c[k] = 0;
+            }
+            int w = w_lo;
+            for (; w + 3 < w_hi; w += 4) {  // four reads in flight
+                const double p0 = val[w], p1 = val[w + 1], p2 = val[w + 2], p3 = val[w + 3];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) c[k] += (int)(p0 > pv[k]) + (int)(p1 > pv[k]) + (int)(p2 > pv[k]) + (int)(p3 > pv[k]);
+            }
+            for (; w < w_hi; ++w) {
+                const double p0 = val[w];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) c[k] += (int)(p0 > pv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int v = (vb * KV + k) * 64 + lane;
+                if (v < ng && c[k]) atomicAdd(&cnt[key * cstride + v], (unsigned)c[k]);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned r[NK];
+#pragma unroll
+    for (int key = 0; key < NK; ++key) {
+        r[key] = tv < ng ? cnt[key * cstride + tv] : 0u;
+        unsigned sum = r[key];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += (unsigned)__shfl_xor((int)sum, off);
+        if (lane == 0 && sum) atomicAdd(&cnt[NK * cstride + key], sum);
+    }
+    __syncthreads();
+    const unsigned want = (unsigned)ng * (unsigned)(ng - 1) / 2u;
+#pragma unroll
+    for (int key = 0; key < NK; ++key) {
+        if (cnt[NK * cstride + key] != want && tv < ng) {  // equal values somewhere (workgroup-uniform): index order among them
+            const double* val = key ? val1 : val0;
+            const double mine = val[tv];
+            for (int w = 0; w < tv; ++w) r[key] += val[w] == mine;
+        }
+        if (tv < ng) (key ? out1 : out0)[tv] = (unsigned short)r[key];
+    }
+}
+
 // Row order of the cluster variant: every workgroup of a graph must arrive at the SAME order (it decides who owns which
 // rows), so the position of a row is its rank under (entry count desc, index asc), not the order atomics happened to
 // take.  Keys = count << 16 | ~index in LDS (`key`: scratch for ng rounded up to 4 words), four per ds_read_b128, the
@@ -1687,27 +1761,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         const int lpv = 1 << lsh;
         const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
         const bool mine = vv < ng;
-        {
-            int cnt = 0, cntw = 0;
-            const bool alive_v = mine && st[vv] == 0;
-            if (alive_v) {
-                const double pvv = pr[vv], wvv = wl[vv];
-                for (int w = sub; w < ng; w += lpv) {
-                    if (st[w] != 0) continue;
-                    const double pw = pr[w];
-                    cnt += (pw > pvv) || (pw == pvv && w < vv);
-                    if (a.greedy_mode == 2) {
-                        const double ww = wl[w];
-                        cntw += (ww > wvv) || (ww == wvv && w < vv);
-                    }
-                }
+        // (every vertex of the image is undecided - the renumbering in P0 - so all ng of them are ranked)
+        unsigned* rcnt = reinterpret_cast<unsigned*>(reinterpret_cast<int*>(cand + 64) + 64);  // behind pick / cand / cid: the completions' space
+        if (a.greedy_mode == 2) {
+            rank_blocked<BLOCK, 2>(ng, pr, wl, rcnt, a.max_nodes, gkey, wkey);
+            if (tv < ng) key[tv] = gkey[tv];
+        } else if (a.greedy_mode == 0) {
+            rank_blocked<BLOCK, 1>(ng, pr, nullptr, rcnt, a.max_nodes, key, nullptr);
+        } else {
+            // solve_mwis_cit needs the best vertex only (np.argmax: the first among equals): a reduction, not a ranking
+            double bp = tv < ng ? pr[tv] : -1.0 / 0.0;
+            int bv = tv < ng ? tv : 0x7fffffff;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double op = __shfl_xor(bp, off);
+                const int ov = __shfl_xor(bv, off);
+                if (op > bp || (op == bp && ov < bv)) { bp = op; bv = ov; }
             }
-            for (int off = 1; off < lpv; off <<= 1) { cnt += __shfl_xor(cnt, off); cntw += __shfl_xor(cntw, off); }
-            if (mine && sub == 0) {
-                key[vv] = alive_v ? (unsigned short)cnt : (unsigned short)kDead;
-                gkey[vv] = key[vv];
-                wkey[vv] = alive_v ? (unsigned short)cntw : (unsigned short)kDead;
+            int* redv = reinterpret_cast<int*>(red + BLOCK / 64);
+            if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = bp; redv[threadIdx.x >> 6] = bv; }
+            __syncthreads();
+            bp = red[0]; bv = redv[0];
+#pragma unroll
+            for (int w = 1; w < BLOCK / 64; ++w) {
+                const double op = red[w];
+                const int ov = redv[w];
+                if (op > bp || (op == bp && ov < bv)) { bp = op; bv = ov; }
             }
+            if (tv < ng) key[tv] = tv == bv ? (unsigned short)0 : (unsigned short)1;  // (greedy_rounds, central: rank 0 joins)
         }
         __syncthreads();
         const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;

@@ -17,7 +17,9 @@
 //   k_res_scatter  scores back to the original numbering (0 for decided vertices), priorities score * weight in float64
 //   then one of    k_lgs with the running state as its mask            (greedy_mode 0: solve_mwis_dit, :278-318)
 //                  k_res_central                                       (greedy_mode 1: solve_mwis_cit, :343-384)
-//                  k_res_cand -> k_res_inst -> k_lgs (beam instances) -> k_res_pick   (greedy_mode 2: the rollout, :596-659)
+//                  k_res_cand -> k_lgs (beam instances, each masking its candidate's closed neighbourhood) -> k_res_pick
+//                                                                      (greedy_mode 2: the rollout, :596-659; behind k_big / k_big2 /
+//                                                                      k_wide1 the candidates come out of that launch: cand_select.h)
 //
 // Every step is integer / compare work or an expression that also appears in fused.hip, so states and scores equal the
 // fused kernel's bit for bit on shapes both take (tests/test_gpu_general.py forces this path with dgcn_set_general(1)).
@@ -25,6 +27,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "cand_select.h"
 
 namespace dgcn {
 
@@ -33,7 +36,7 @@ int layered_forward(const DgcnBatch* b, const DgcnCsr* const* sup, const DgcnMod
 int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores, const double* weights,
                       const uint8_t* init_state, int32_t num_instances, int32_t max_rounds, uint8_t* state, int32_t* rounds,
                       int64_t* stats, int32_t* overhead, const double* sum_weights, double* totals, int32_t* status, void* stream,
-                      const int32_t* active);  // lgs.hip
+                      const int32_t* active, const int32_t* cand);  // lgs.hip
 
 // big.hip: the hidden stack of a deep c32 model in one launch (graphs up to 976 vertices); same bits as layered_forward
 int big_takes(const DgcnBatch* b, const DgcnModel* m);
@@ -48,8 +51,8 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
 int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options);
 int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
-                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
-                 unsigned long long tail_tag, void* bws, hipStream_t s);
+                 double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
+                 unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s);
 
 // big2.hip: the same for graphs of 977 .. 1 920 vertices (Z1 a feature half at a time)
 int big2_takes(const DgcnBatch* b, const DgcnModel* m);
@@ -64,8 +67,8 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
 int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options);
 int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                   int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
-                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, unsigned long long* tail_word,
-                  unsigned long long tail_tag, void* bws, hipStream_t s);
+                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
+                  unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s);
 
 // wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
 // in one launch
@@ -73,7 +76,8 @@ int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t 
 int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
               int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
               int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
-              double* prio, int32_t* active, unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s);
+              double* prio, int32_t* active, int32_t* cid, int32_t beam, unsigned long long* tail_word, unsigned long long tail_tag,
+              hipStream_t s);
 
 constexpr int kResBlock = 1024;  // (graphs of this path are large and batches of them small: 64 graphs x 256 threads left the chip idle)
 constexpr int kMaxBeam = 64;
@@ -108,7 +112,6 @@ struct ResArgs {
     float* scores;             // caller's array (original numbering): output, or input with scores_given
     double* prio;              // [num_nodes] priorities, original numbering
     int32_t* cid;              // [B][64] rollout candidates (local vertex ids), -1 = none
-    uint8_t* inst_init;        // [beam][num_nodes]
     const double* inst_totals; // [beam][B]
     int32_t* rounds;
     double* totals;
@@ -402,28 +405,10 @@ __global__ __launch_bounds__(kResBlock) void k_res_central(ResArgs a) {
 // ds_bpermute round trips of three words through an LDS crossbar sixteen waves queue on (22 us for 16 rounds) -, the ranking a
 // linear scan by 256 threads (20 us): 59 us, nothing gained.  Now: all loads in flight at once, the argmax inside a row of
 // sixteen lanes by DPP moves and across the four rows by v_readlane, the ranking as above.)
-struct CandKey { double p; int v; };  // v < 0: nobody
-__device__ __forceinline__ bool cand_ahead(double p, int v, double q, int u) {  // is (p, v) ahead of (q, u)?  (both somebody)
-    return p > q || (p == q && v < u);
-}
-template <int CTRL>
-__device__ __forceinline__ void cand_dpp_max(double& p, int& v) {
-    const int lo = __double2loint(p), hi = __double2hiint(p);
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    const int ov = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-    const double op = __hiloint2double(ohi, olo);
-    if (ov >= 0 && (v < 0 || cand_ahead(op, ov, p, v))) { p = op; v = ov; }
-}
-
 __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes) {
     (void)lds_nodes;
-    constexpr int kPer = (9600 + kResBlock - 1) / kResBlock;  // vertices per thread at most (general_takes: <= 9 600 vertices)
-    constexpr int kWavesR = kResBlock / 64;
-    __shared__ double wl_p[kWavesR * kMaxBeam];
-    __shared__ int wl_v[kWavesR * kMaxBeam];
-    __shared__ int wl_n[kWavesR];
-    __shared__ int rank[kWavesR * kMaxBeam];
+    static_assert(kCandPer * kResBlock >= 9600, "a thread holds its vertices' priorities in registers");
+    __shared__ __attribute__((aligned(8))) unsigned char scratch[cand_scratch_bytes(kResBlock)];
     __shared__ int s_bad;
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1], ng = n1 - n0;
@@ -431,13 +416,12 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
     if (threadIdx.x < kMaxBeam) cid[threadIdx.x] = -1;
     if (!a.active[g]) return;
     if (threadIdx.x == 0) s_bad = 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int beam = min(a.beam, kMaxBeam);
     const int per = (ng + kResBlock - 1) / kResBlock;  // (uniform) my vertices: threadIdx.x + i * kResBlock, i < per
-    double pv[kPer];
-    uint8_t sv[kPer];
+    double pv[kCandPer];
+    uint8_t sv[kCandPer];
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {  // every load in flight before the first one is looked at
+    for (int i = 0; i < kCandPer; ++i) {  // every load in flight before the first one is looked at
         const int v = (int)threadIdx.x + i * kResBlock;
         const bool in = i < per && v < ng;
         sv[i] = in ? a.state[n0 + v] : (uint8_t)1;
@@ -446,12 +430,11 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
     unsigned have = 0u;  // bit i: my vertex i is undecided and not selected yet
     int bad = 0;
 #pragma unroll
-    for (int i = 0; i < kPer; ++i)
+    for (int i = 0; i < kCandPer; ++i)
         if (sv[i] == 0) {
             bad |= pv[i] != pv[i];
             have |= 1u << i;
         }
-    for (int c = threadIdx.x; c < kWavesR * kMaxBeam; c += kResBlock) rank[c] = 0;
     __syncthreads();
     if (bad) s_bad = 1;
     __syncthreads();
@@ -459,75 +442,12 @@ __global__ __launch_bounds__(kResBlock) void k_res_cand(ResArgs a, int lds_nodes
         if (threadIdx.x == 0) atomicOr(a.status, DGCN_FAULT_NAN_PRIORITY);
         return;  // no candidates: k_res_pick leaves the graph alone
     }
-    int mine_n = 0;
-    for (int it = 0; it < beam; ++it) {
-        double bp = 0.0;
-        int bv = -1;
-#pragma unroll
-        for (int i = 0; i < kPer; ++i)  // ascending vertex index: the first maximum stays
-            if (i < per) {  // (uniform: a graph of up to 1 024 vertices has one vertex per thread)
-                if (((have >> i) & 1u) && (bv < 0 || pv[i] > bp)) { bp = pv[i]; bv = (int)threadIdx.x + i * kResBlock; }
-            }
-        // the best of the wave: inside a row of sixteen lanes by DPP (quad swaps, half-row and row mirrors: every lane ends with
-        // its row's best), across the four rows through scalar registers
-        cand_dpp_max<0xB1>(bp, bv);   // quad_perm [1, 0, 3, 2]
-        cand_dpp_max<0x4E>(bp, bv);   // quad_perm [2, 3, 0, 1]
-        cand_dpp_max<0x141>(bp, bv);  // row_half_mirror
-        cand_dpp_max<0x140>(bp, bv);  // row_mirror
-        double wp = 0.0;
-        int wv = -1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rv = __builtin_amdgcn_readlane(bv, 16 * r);
-            const double rp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bp), 16 * r), __builtin_amdgcn_readlane(__double2loint(bp), 16 * r));
-            if (rv >= 0 && (wv < 0 || cand_ahead(rp, rv, wp, wv))) { wp = rp; wv = rv; }
-        }
-        if (wv < 0) break;  // (wave-uniform: this wave has no undecided vertex left)
-        if ((wv & (kResBlock - 1)) == (int)threadIdx.x) have &= ~(1u << (wv / kResBlock));
-        if (lane == 0) { wl_p[wave * kMaxBeam + it] = wp; wl_v[wave * kMaxBeam + it] = wv; }
-        mine_n = it + 1;
-    }
-    if (lane == 0) wl_n[wave] = mine_n;
-    __syncthreads();
-    // rank the waves' lists against each other: (candidate c = (w, k), list w2) pairs over all threads; the entries of list w2
-    // ahead of the candidate form a prefix of it (the lists are sorted): binary search, summed into the candidate's rank
-    for (int idx = threadIdx.x; idx < kWavesR * beam * kWavesR; idx += kResBlock) {
-        const int w2 = idx % kWavesR, c = idx / kWavesR;
-        const int w = c / beam, k = c - w * beam;
-        if (k >= wl_n[w]) continue;
-        const double p = wl_p[w * kMaxBeam + k];
-        const int v = wl_v[w * kMaxBeam + k];
-        int lo = 0, hi = wl_n[w2];  // entries [0, lo) are ahead, [hi, ..) are not
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cand_ahead(wl_p[w2 * kMaxBeam + mid], wl_v[w2 * kMaxBeam + mid], p, v)) lo = mid + 1; else hi = mid;
-        }
-        if (lo) atomicAdd(&rank[w * kMaxBeam + k], lo);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < kWavesR * beam; c += kResBlock) {
-        const int w = c / beam, k = c - w * beam;
-        if (k < wl_n[w] && rank[w * kMaxBeam + k] < beam) cid[rank[w * kMaxBeam + k]] = wl_v[w * kMaxBeam + k];
-    }
+    cand_select<kResBlock>(pv, have, per, beam, cid, scratch);
 }
 
-// ---- second launch: instance i of graph g = the residual graph minus the closed neighbourhood of candidate i
-// (mwis_gdpg_call.py:629-643), as the mask the multi-instance greedy search (k_lgs) starts from
-__global__ __launch_bounds__(kResBlock) void k_res_inst(ResArgs a) {
-    const int inst = blockIdx.x / a.num_graphs, g = blockIdx.x - inst * a.num_graphs;
-    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
-    uint8_t* init = a.inst_init + (size_t)inst * a.num_nodes;
-    const int c = a.active[g] ? a.cid[(size_t)g * kMaxBeam + inst] : -1;
-    for (int v = n0 + threadIdx.x; v < n1; v += kResBlock) init[v] = c < 0 ? (uint8_t)3 : a.state[v];
-    if (c < 0) return;  // fewer undecided vertices than candidates: nothing to search (every vertex masked)
-    __syncthreads();
-    const int rs = a.row_ptr[n0 + c], re = a.row_ptr[n0 + c + 1];
-    for (int j = rs + threadIdx.x; j < re; j += kResBlock) {
-        const int u = a.col_idx[j];
-        if (u >= n0 && u < n1) init[u] = 3;
-    }
-    if (threadIdx.x == 0) init[n0 + c] = 3;
-}
+// ---- (instance i of graph g = the residual graph minus the closed neighbourhood of candidate i, mwis_gdpg_call.py:629-643:
+// k_lgs makes that mask in its own LDS from the running state and the candidate list - LgsArgs::cand - so no launch writes
+// beam x num_nodes mask bytes out first)
 
 // ---- last launch: the candidate with the largest weight + completion total joins (totals within 1e-12 relative count
 // as tied, the first one wins: np.isclose(cand, cand.max(), rtol=1e-12, atol=0), as in fused.hip)
@@ -605,7 +525,7 @@ size_t general_workspace(const DgcnBatch* b, const DgcnModel* m) {
     need += al256(n * 4) + al256(n * 4);                                 // compact scores, full scores when the caller wants none
     need += al256(n * 8);                                                // priorities
     need += al256(layered_bytes(b, m)) + al256(std::max(big_workspace(b, m), big2_workspace(b, m)));
-    need += al256(B * kMaxBeam * 4) + 2 * al256((size_t)kMaxBeam * n) + al256((size_t)kMaxBeam * B * 4) + al256((size_t)kMaxBeam * B * 8);
+    need += al256(B * kMaxBeam * 4) + al256((size_t)kMaxBeam * n) + al256((size_t)kMaxBeam * B * 4) + al256((size_t)kMaxBeam * B * 8);
     return need;
 }
 
@@ -637,7 +557,7 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
         if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                                general_workspace(b, m), workspace_bytes);
         return wide1_run(b, m, dinv_table, table_len, X, x_const, 0, weights, predict_mwis, 0, 0, 0, 0, sc1, state, rounds, totals, nullptr,
-                         status, nullptr, nullptr, nullptr, 0, s);
+                         status, nullptr, nullptr, nullptr, 0, nullptr, 0, s);
     }
     int32_t* lrow = w.take<int32_t>(n + 1);
     int32_t* lcol = w.take<int32_t>(n + e);
@@ -662,7 +582,7 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     if ((rc = big ? big_forward(b, &L, m, X, x_const, sc, fws, bws, status, s)
               : big2 ? big2_forward(b, &L, m, X, x_const, sc, fws, bws, status, s) : layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
     return lgs_launch_common(b, nullptr, 0, sc, (predict_mwis && weights) ? weights : nullptr, nullptr, 1, 0, state, rounds, nullptr,
-                             nullptr, weights, totals, status, s, nullptr);
+                             nullptr, weights, totals, status, s, nullptr, nullptr);
 }
 
 int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X,
@@ -704,7 +624,6 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     int32_t* inst_rounds = nullptr;
     double* inst_totals = nullptr;
     if (greedy_mode == 2) {
-        a.inst_init = w.take<uint8_t>((size_t)beam * n);
         inst_state = w.take<uint8_t>((size_t)beam * n);
         inst_rounds = w.take<int32_t>((size_t)beam * B);
         inst_totals = w.take<double>((size_t)beam * B);
@@ -716,26 +635,31 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
                            general_workspace(b, m), workspace_bytes);
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);
     bool wide = wide1_takes(b, m, X, feature_mode) != 0;
+    bool cand_done = false;  // the rollout's candidates were selected inside the step's own launch (cand_select.h)
     if (!wide && big && big_residual_takes(b, m, X, feature_mode, options)) {
         // deep c32 stacks on graphs k_big takes, constant input features: activity test, the residual graph's support, every layer,
         // priorities and the greedy step (rounds / central pick) in ONE launch on the graph as it lies - no compaction, no k_lgs;
         // the rollout's four launches follow on the priorities it leaves
         const int rc = big_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
-                                    state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, bws, s);
+                                    state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word, tail_tag, bws, s);
         if (rc || greedy_mode != 2) return rc;
         wide = true;  // (what follows is the same as behind the one-layer kernel: the rollout's launches)
+        cand_done = true;  // (the candidates were selected at the end of that launch)
     } else if (!wide && big2 && big2_residual_takes(b, m, X, feature_mode, options)) {  // the same for 977 .. 1 920 vertices (k_big2)
         const int rc = big2_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
-                                     state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, bws, s);
+                                     state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word, tail_tag, bws, s);
         if (rc || greedy_mode != 2) return rc;
         wide = true;
+        cand_done = true;
     } else
     if (wide) {
         // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE
         // launch on the graph as it lies - no compaction; the rollout's four launches follow on the priorities it leaves
         const int rc = wide1_run(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, 1, given ? 1 : 0, greedy_mode,
-                                 max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, tail_word, tail_tag, s);
+                                 max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word,
+                                 tail_tag, s);
         if (rc || greedy_mode != 2) return rc;
+        cand_done = true;
     }
     if (!wide) {
         TimedLaunch t("general_prepare", s);
@@ -772,24 +696,19 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     }
     if (greedy_mode == 0)
         return lgs_launch_common(b, a.prio, 0, nullptr, nullptr, state, 1, max_rounds, state, rounds, nullptr, nullptr,
-                                 weights /* null: the priorities */, totals, status, s, a.active);
+                                 weights /* null: the priorities */, totals, status, s, a.active, nullptr);
     if (greedy_mode == 1) {
         TimedLaunch t("general_greedy", s);
         DGCN_LAUNCH(t, k_res_central, gb, tb, 0, s, a);
         return check_launch("k_res_central");
     }
-    {
+    if (!cand_done) {
         TimedLaunch t("general_greedy", s);
         DGCN_LAUNCH(t, k_res_cand, gb, tb, 0, s, a, 0);
         if (int rc = check_launch("k_res_cand")) return rc;
     }
-    {
-        TimedLaunch t("general_greedy", s);
-        DGCN_LAUNCH(t, k_res_inst, dim3((unsigned)(b->num_graphs * beam)), tb, 0, s, a);
-        if (int rc = check_launch("k_res_inst")) return rc;
-    }
-    if (int rc = lgs_launch_common(b, a.by_priority ? a.prio : weights, 0, nullptr, nullptr, a.inst_init, beam, 0, inst_state, inst_rounds,
-                                   nullptr, nullptr, weights, inst_totals, status, s, a.active))
+    if (int rc = lgs_launch_common(b, a.by_priority ? a.prio : weights, 0, nullptr, nullptr, state, beam, 0, inst_state, inst_rounds,
+                                   nullptr, nullptr, weights, inst_totals, status, s, a.active, a.cid))
         return rc;
     TimedLaunch t("general_greedy", s);
     DGCN_LAUNCH(t, k_res_pick, gb, dim3(64), 0, s, a);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(BLOCK) void k_lgs(LgsArgs a) {
     if (inst) {
         const size_t no = (size_t)inst * a.num_nodes, go = (size_t)inst * a.num_graphs;
         a.state += no;
-        if (a.init_state) a.init_state += no;
+        if (a.init_state && !a.cand) a.init_state += no;
         if (a.overhead) a.overhead += no;
         if (a.rounds) a.rounds += go;
         if (a.totals) a.totals += go;
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(BLOCK) void k_lgs(LgsArgs a) {
         if (a.prio) a.prio += (size_t)inst * a.prio_stride;
     }
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
-    const int ng = (a.active && !a.active[g]) ? 0 : n1 - n0;
+    const int cnd = a.cand ? a.cand[(size_t)g * 64 + inst] : 0;  // (fewer undecided vertices than candidates: nothing to search)
+    const int ng = ((a.active && !a.active[g]) || cnd < 0) ? 0 : n1 - n0;
     // carve: [f64 prio | f64 reduce[256] | u64 acc[4] | i32 row offsets | u8 st | u8 nw | u16 cols]
     double* pr = reinterpret_cast<double*>(lds_raw);
     double* red = pr + a.max_nodes;
@@ -79,6 +80,15 @@ __global__ __launch_bounds__(BLOCK) void k_lgs(LgsArgs a) {
             for (int i = 0; i < 4; ++i)
                 if (base + i * BLOCK < e1) cl[base + i * BLOCK - e0] = (uint16_t)(c[i] - n0);
         }
+    }
+    if (a.cand) {  // this instance's start: the candidate and its neighbours do not take part
+        __syncthreads();
+        const int rs = a.row_ptr[n0 + cnd], re = a.row_ptr[n0 + cnd + 1];
+        for (int j = rs + threadIdx.x; j < re; j += BLOCK) {
+            const int u = a.col_idx[j] - n0;
+            if ((unsigned)u < (unsigned)ng) st[u] = 3;
+        }
+        if (threadIdx.x == 0) st[cnd] = 3;
     }
     if (__syncthreads_or(bad)) {
         // the reference would spin forever on a NaN priority: report instead
@@ -212,7 +222,8 @@ namespace dgcn {
 int lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
                       const double* weights, const uint8_t* init_state, int32_t num_instances,
                       int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
-                      const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active = nullptr);
+                      const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active = nullptr,
+                      const int32_t* cand = nullptr);
 }
 
 extern "C" int dgcn_lgs_batch(const DgcnBatch* b, const double* prio, const float* scores, const double* weights,
@@ -235,7 +246,8 @@ extern "C" int dgcn_lgs_masked_batch(const DgcnBatch* b, const double* prio, int
 int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_stride, const float* scores,
                             const double* weights, const uint8_t* init_state, int32_t num_instances,
                             int32_t max_rounds, uint8_t* state, int32_t* rounds, int64_t* stats, int32_t* overhead,
-                            const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active) {
+                            const double* sum_weights, double* totals, int32_t* status, void* stream, const int32_t* active,
+                            const int32_t* cand) {
     if (!b || !state || !status) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: null argument");
     if (!prio && !scores) return fail(DGCN_ERR_ARG, "dgcn_lgs_batch: need prio or scores");
     if (b->num_graphs <= 0) return DGCN_OK;
@@ -255,6 +267,7 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     a.num_nodes = b->num_nodes;
     a.prio_stride = prio_stride;
     a.active = active;
+    a.cand = cand;
     // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
     // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
     int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;

@@ -30,6 +30,11 @@ struct LgsArgs {
     long prio_stride;
     const int32_t* active;      // [num_graphs] or null: 0 = leave this graph alone (rounds 0, total 0, state untouched) -
                                 // the "nothing left / no positive weight left" graphs of a residual step (general.hip)
+    // the rollout's instances (general.hip): init_state is the RUNNING state, shared by every instance ([num_nodes], no slice
+    // per instance), and instance k of graph g starts from it minus the closed neighbourhood of vertex cand[g * 64 + k]
+    // (mwis_gdpg_call.py:629-643; a negative entry: no such candidate, the instance has nothing to search) - the mask is made in
+    // LDS, no launch writes it out first
+    const int32_t* cand;
 };
 
 template <bool COLS_LDS>

@@ -31,6 +31,7 @@
 
 #include "common.h"
 #include "lgs_rounds.h"
+#include "cand_select.h"
 
 namespace dgcn {
 
@@ -64,6 +65,8 @@ struct WideArgs {
     int32_t* progress;
     double* prio;              // mode 2: [num_nodes] out
     int32_t* active;           // mode 2: [num_graphs] out
+    int32_t* cid;              // mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
+    int32_t beam;
     unsigned long long* tail_word;
     unsigned long long tail_tag;
     int32_t max_nodes, cols_cap;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     uint8_t* nw = st + wide_pad16(a.max_nodes + 1);
     uint16_t* cl = reinterpret_cast<uint16_t*>(nw + wide_pad16(a.max_nodes + 1));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.cid && threadIdx.x < kCandMaxBeam) a.cid[(size_t)g * kCandMaxBeam + threadIdx.x] = -1;  // (a graph left alone has no candidates)
     if (ng <= 0) {
         if (threadIdx.x == 0) {
             if (a.rounds) a.rounds[g] = 0;
@@ -436,6 +440,18 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     }
     if (a.mode == 2) {  // the rollout's candidate / instance / completion / pick launches follow (general.hip)
         if (threadIdx.x == 0 && a.active) a.active[g] = 1;
+        if (a.cid) {  // the candidates right here, the priorities still in registers: no k_res_cand launch
+            static_assert(kCandPer * kWideBlock >= kWideMaxNodes && kCandPer == (kWideMaxNodes + kWideBlock - 1) / kWideBlock, "pmine is the selection's layout");
+            unsigned have = 0u;
+#pragma unroll
+            for (int p = 0; p < kCandPer; ++p) {
+                const int v = threadIdx.x + p * kWideBlock;
+                if (v < ng && st[v] == 0) have |= 1u << p;
+            }
+            __syncthreads();  // (the selection's scratch takes the carve from its start: nothing of it is read again)
+            cand_select<kWideBlock>(pmine, have, (ng + kWideBlock - 1) / kWideBlock, min(a.beam, kCandMaxBeam),
+                                    a.cid + (size_t)g * kCandMaxBeam, wide_raw);
+        }
         return;
     }
     if (a.mode == 1) {
@@ -551,7 +567,8 @@ static int wide1_launch_l(const WideArgs& a, int B, size_t lds, const char* fami
 int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
               int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
               int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
-              double* prio, int32_t* active, unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s) {
+              double* prio, int32_t* active, int32_t* cid, int32_t beam, unsigned long long* tail_word, unsigned long long tail_tag,
+              hipStream_t s) {
     const DgcnLayer& L = m->layers_host[0];
     WideArgs a = {};
     a.graph_ptr = b->graph_ptr; a.row_ptr = b->row_ptr; a.col_idx = b->col_idx;
@@ -566,6 +583,7 @@ int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     a.max_rounds = max_rounds;
     a.sc = sc; a.state = state; a.rounds = rounds; a.totals = totals; a.status = status; a.progress = progress;
     a.prio = mode == 2 ? prio : nullptr; a.active = mode == 2 ? active : nullptr;
+    a.cid = mode == 2 ? cid : nullptr; a.beam = beam;
     a.tail_word = tail_word; a.tail_tag = tail_tag;
     a.max_nodes = std::max(b->max_nodes, 16);
     // the graph's columns in LDS when the largest graph's fit next to the search's state
@@ -573,7 +591,8 @@ int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     int cap = std::max(b->max_graph_edges, 0);
     if (wide_lds_bytes(a.max_nodes, cap) > kLdsMax) cap = 0;
     a.cols_cap = cap;
-    const size_t lds = wide_lds_bytes(a.max_nodes, cap);
+    size_t lds = wide_lds_bytes(a.max_nodes, cap);
+    if (a.cid) lds = std::max(lds, (size_t)cand_scratch_bytes(kWideBlock));  // (small graphs: the selection's scratch is the larger)
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_wide1: %zu bytes of LDS for graphs of %d vertices", lds, b->max_nodes);
     const char* family = residual ? "wide_residual" : "wide_solve";
     // lanes per vertex in the rounds: k_lgs's choice for 1 024-thread workgroups

@@ -187,9 +187,14 @@ def test_random_searches_with_and_without_the_tail(engine):
     rng = np.random.default_rng(6464)
     try:
         for case in range(cases):
-            layers = datagen.random_model(int(rng.choice([3, 4, 6, 20])), 32, feature_size=int(rng.choice([1, 1, 3])),
+            # (1 / 2 layers: csrc/wide.hip's residual steps on the any-size path; 3+: k_big<RESID> / k_big2<RESID>)
+            layers = datagen.random_model(int(rng.choice([1, 2, 3, 4, 6, 20])), 32, feature_size=int(rng.choice([1, 1, 3])),
                                           bias=bool(rng.integers(2)), seed=500 + case)
             ps, cs, ws = [], [], []
+            if rng.random() < 0.15:  # now and then a graph beyond k_big's 976 vertices (k_big2 on the any-size path; the fused kernel
+                n = int(rng.choice([980, 1100]))  # does not take the batch then: both "paths" are the any-size one)
+                g = datagen.er_batch(1, n, 5.0 / n, first_index=int(rng.integers(1 << 20)))
+                ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
             for _ in range(int(rng.integers(1, 10))):
                 n = int(rng.choice([0, 1, 2, 16, 40, 63, 64, 65, 66, 100, 130, 200]))
                 if n == 0:
