@@ -449,3 +449,62 @@ def test_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp
         else:
             assert np.array_equal(a[k], b[k]), k
     assert a["cit_steps"][0] > 100
+
+
+@pytest.mark.parametrize("num_layer", [1, 5])
+@pytest.mark.parametrize("beam", [1, 3, 64])
+def test_rollout_beam_edge_values_equal_the_fused_kernel(engine, golden, general_switch, num_layer, beam):
+    """The rollout's candidates are selected at the end of the step's own launch on the any-size path (cand_select.h, called by
+    k_big / k_wide1) and the instances' masks are made by k_lgs: with one candidate, with as many as the list holds (64) and
+    late in a search - fewer undecided vertices than candidates - the searches end in the same states after the same number
+    of steps as the fused kernel's.  (More than 64 candidates: refused by the entry point on both paths.)"""
+    import torch
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=num_layer), seed=4)
+    hb = golden.host_batch([2, 7, 1, 0, 12, 8])
+    db = engine.upload(hb)
+    dm = agent.model.device_model(engine)
+    from distgcn_amd._lib import DgcnError
+    results = {}
+    for path in (None, 1):
+        general_switch(path)
+        assert engine.solve_path(db, dm) == (1 if path is None else 2)
+        state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=engine.device)
+        with pytest.raises(DgcnError, match="beam"):
+            engine.solve_residual(db, dm, state, greedy=engine.GREEDY_ROLLOUT, max_rounds=1, beam=65, max_steps=1)
+        res = engine.solve_residual(db, dm, state, greedy=engine.GREEDY_ROLLOUT, max_rounds=1, beam=beam, finish_small=False)
+        engine.check_status(res["status"])
+        results[path] = (state.cpu().numpy().copy(), res["steps"])
+    assert results[None][1] == results[1][1] and results[1][1] > 3
+    assert np.array_equal(results[None][0], results[1][0])
+    assert not (results[1][0] == 0).any()
+
+
+@pytest.mark.parametrize("num_layer", [1, 5])
+def test_rollout_nan_weight_on_the_any_size_path(engine, golden, general_switch, num_layer):
+    """A NaN weight makes a NaN priority: the reference would spin on it; here the graph is reported (DGCN_FAULT_NAN_PRIORITY),
+    gets no candidates and keeps its state, and the other graphs of the batch finish their searches as without it."""
+    import torch
+    from distgcn_amd import _lib
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    agent = DQNAgent(_flags(num_layer=num_layer), seed=4)
+    hb = golden.host_batch([2, 7, 1])
+    sl = hb.graph_slices()
+    clean = engine.upload(hb)
+    dm = agent.model.device_model(engine)
+    general_switch(1)
+    hb.weights[sl[1][0] + 3] = np.nan
+    db = engine.upload(hb)
+    s0 = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=engine.device)
+    s1 = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=engine.device)
+    out0, out1 = engine.solve_buffers(clean, False), engine.solve_buffers(db, False)
+    for _ in range(70):  # (single steps: the host loop of a whole search stops at the first fault it reads back)
+        engine.solve_residual(clean, dm, s0, greedy=engine.GREEDY_ROLLOUT, max_rounds=1, beam=5, max_steps=1, out=out0)
+        engine.solve_residual(db, dm, s1, greedy=engine.GREEDY_ROLLOUT, max_rounds=1, beam=5, max_steps=1, out=out1)
+    engine.check_status(out0["status"])
+    assert int(out1["status"].cpu().numpy().ravel()[0]) & _lib.FAULT_NAN_PRIORITY
+    a, b = s0.cpu().numpy(), s1.cpu().numpy()
+    assert not (a == 0).any()
+    assert not b[sl[1][0]:sl[1][1]].any()                                 # the graph with the NaN: untouched
+    for g in (0, 2):
+        assert np.array_equal(a[sl[g][0]:sl[g][1]], b[sl[g][0]:sl[g][1]])  # the others: as without it
