@@ -35,6 +35,7 @@
 #include "lgs_rounds.h"
 #include "big_common.h"
 #include "cand_select.h"
+#include "rollout_bits.h"
 
 namespace dgcn {
 
@@ -705,6 +706,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
 #pragma unroll
                 for (int i = 0; i < kCandPer; ++i) pv[i] = 0.0;
                 pv[0] = part ? pr[tv] : 0.0;
+                if (a.roll_off) {
+                    // the whole step here: candidates (list mirrored in LDS), the completions of all of them at once, the pick.
+                    // Behind the search's state bytes: row bounds | candidates | instance words | selection scratch | 16-bit columns
+                    unsigned char* R = big_lds + a.roll_off;
+                    int* rol = reinterpret_cast<int*>(R);
+                    int32_t* cidl = rol + ((a.max_nodes + 1 + 3) & ~3);
+                    unsigned char* extra = reinterpret_cast<unsigned char*>(cidl + kCandMaxBeam);
+                    unsigned char* scratch = extra + roll_lds_bytes(a.max_nodes);
+                    uint16_t* cl = reinterpret_cast<uint16_t*>(scratch + ((cand_scratch_bytes(BLOCK) + 15) & ~(size_t)15));
+                    if (tv < ng) st[tv] = part ? 0 : 3;
+                    if (threadIdx.x < kCandMaxBeam) cidl[threadIdx.x] = -1;
+                    __syncthreads();
+                    cand_select<BLOCK>(pv, part ? 1u : 0u, 1, min(a.beam, kCandMaxBeam), cid, scratch, cidl);
+                    if (!a.by_priority && part) pr[tv] = a.weights[n0 + tv];  // (the completions go by weight: mwis_gdpg_call.py:640)
+                    for (int v = threadIdx.x; v <= ng; v += BLOCK) rol[v] = a.arow[n0 + v];
+                    const int e0 = a.arow[n0], e1 = a.arow[n0 + ng];
+                    for (int base = e0 + threadIdx.x; base < e1; base += BLOCK * 4) {  // four loads in flight per thread
+                        int c[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c[i] = (base + i * BLOCK < e1) ? a.acol[base + i * BLOCK] : n0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (base + i * BLOCK < e1) {
+                                const int u = c[i] - n0;
+                                cl[base + i * BLOCK - e0] = (uint16_t)((unsigned)u < (unsigned)ng ? u : ng);
+                            }
+                    }
+                    __syncthreads();
+                    RollArgs r;
+                    r.ng = ng; r.n0 = n0; r.e0 = e0;
+                    r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
+                    r.extra = extra;
+                    r.max_nodes = a.max_nodes;
+                    r.col_idx = a.acol; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                    rollout_bits<BLOCK>(r, g);
+                    return;
+                }
                 __syncthreads();  // (the staging tiles' space is free: the last walk is behind the barriers above)
                 cand_select<BLOCK>(pv, part ? 1u : 0u, 1, min(a.beam, kCandMaxBeam), cid, big_lds + a.lds_stage_off);
             }
@@ -1034,7 +1072,9 @@ int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, i
 int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
-                 unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s) {
+                 int32_t by_priority, int32_t* whole_step, unsigned long long* tail_word, unsigned long long tail_tag, void* bws,
+                 hipStream_t s) {
+    if (whole_step) *whole_step = 0;
     BigArgs a = {};
     a.graph_ptr = b->graph_ptr;
     a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
@@ -1060,6 +1100,22 @@ int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tabl
         block = 1024;
         lds = std::max(big_lds_bytes(a.max_nodes, block, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
                        big_lgs_lds(a.max_nodes, b->max_graph_edges));
+    }
+    a.by_priority = by_priority;
+    if (a.cid && whole_step) {
+        // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do and row bounds, instance
+        // words, the selection's scratch and the graph's 16-bit columns fit behind the search's state bytes.
+        // DGCN_ROLLOUT_BITS=0: general.hip's launches.
+        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        const size_t pad = (size_t)((a.max_nodes + 15) & ~15);
+        const size_t roll = (big_lgs_base(a.max_nodes) + (size_t)a.max_nodes * 8 + 1024 * 8 + (4 + 3 * 16) * 8 + pad + 15) & ~(size_t)15;
+        const size_t need = roll + (size_t)((a.max_nodes + 1 + 3) & ~3) * 4 + kCandMaxBeam * 4 + roll_lds_bytes(a.max_nodes) +
+                            ((cand_scratch_bytes(block) + 15) & ~(size_t)15) + (size_t)std::max(b->max_graph_edges, 0) * 2 + 16;
+        if (!bits_off && beam <= kRollBeam && weights && need <= 160 * 1024) {
+            a.roll_off = (int32_t)roll;
+            lds = std::max(lds, need);
+            *whole_step = 1;
+        }
     }
     return big_launch(a, b->num_graphs, lds, block, "big_residual", s);
 }

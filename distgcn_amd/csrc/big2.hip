@@ -27,6 +27,7 @@
 #include "lgs_rounds.h"
 #include "big_common.h"
 #include "cand_select.h"
+#include "rollout_bits.h"
 
 namespace dgcn {
 
@@ -836,6 +837,25 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                     pv[i] = 0.0;
                     if (i < per && v < ng && st[v] == 0) { pv[i] = pr[v]; have |= 1u << i; }
                 }
+                if (a.roll_off) {
+                    // the whole step here: candidates (list mirrored in LDS), the completions of all of them at once, the pick
+                    // (the host has made sure every graph's columns are in LDS: cols_lds)
+                    int32_t* cidl = reinterpret_cast<int32_t*>(b2_lds + a.roll_off);
+                    if (threadIdx.x < kCandMaxBeam) cidl[threadIdx.x] = -1;
+                    __syncthreads();
+                    cand_select<kB2Block>(pv, have, per, min(a.beam, kCandMaxBeam), cid, b2_lds + a.lds_stage_off, cidl);
+                    if (!a.by_priority)  // (the completions go by weight: mwis_gdpg_call.py:640)
+                        for (int v = threadIdx.x; v < ng; v += kB2Block) pr[v] = a.weights[n0 + v];
+                    __syncthreads();
+                    RollArgs r;
+                    r.ng = ng; r.n0 = n0; r.e0 = e0;
+                    r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
+                    r.extra = reinterpret_cast<unsigned char*>(cidl + kCandMaxBeam);
+                    r.max_nodes = a.max_nodes;
+                    r.col_idx = a.acol; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                    rollout_bits<kB2Block>(r, g);
+                    return;
+                }
                 __syncthreads();
                 cand_select<kB2Block>(pv, have, per, min(a.beam, kCandMaxBeam), cid, b2_lds + a.lds_stage_off);
             }
@@ -1130,7 +1150,9 @@ int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, 
 int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                   int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
                   double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
-                  unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s) {
+                  int32_t by_priority, int32_t* whole_step, unsigned long long* tail_word, unsigned long long tail_tag, void* bws,
+                  hipStream_t s) {
+    if (whole_step) *whole_step = 0;
     BigArgs a = {};
     a.graph_ptr = b->graph_ptr;
     a.arow = b->row_ptr; a.acol = b->col_idx; a.dinv = dinv_table; a.table_len = table_len;
@@ -1149,8 +1171,24 @@ int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     a.cid = greedy_mode == 2 ? cid : nullptr;
     a.beam = beam;
     big2_fill_model(a, m, x_const);
-    const size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
-                                b2_lgs_lds(a.max_nodes));
+    size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
+                          b2_lgs_lds(a.max_nodes));
+    a.by_priority = by_priority;
+    if (a.cid && whole_step) {
+        // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do, every graph's columns fit
+        // what the search has left of the Z1 space, and the instances' state words fit behind the selection's scratch.
+        // DGCN_ROLLOUT_BITS=0: general.hip's launches.
+        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        const size_t cl_off = b2_lgs_lds(a.max_nodes) - 16;  // (where the search puts the 16-bit columns)
+        const size_t cl_cap = (size_t)a.max_nodes * 64 > cl_off ? ((size_t)a.max_nodes * 64 - cl_off) / 2 : 0;
+        const size_t roll = ((size_t)a.lds_stage_off + cand_scratch_bytes(kB2Block) + 15) & ~(size_t)15;
+        const size_t need = roll + kCandMaxBeam * 4 + roll_lds_bytes(a.max_nodes);
+        if (!bits_off && beam <= kRollBeam && weights && (size_t)std::max(b->max_graph_edges, 0) <= cl_cap && need <= 160 * 1024) {
+            a.roll_off = (int32_t)roll;
+            lds = std::max(lds, need);
+            *whole_step = 1;
+        }
+    }
     return big2_launch(a, b->num_graphs, lds, "big_residual", s);
 }
 

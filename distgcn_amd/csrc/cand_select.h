@@ -30,9 +30,11 @@ __device__ __forceinline__ void cand_dpp_max(double& p, int& v) {
 
 // pv[i] / bit i of `have`: priority of vertex threadIdx.x + i * BLOCK and whether it takes part (undecided), i < per (uniform).
 // cid: the graph's [64] candidate slots in global memory, all -1 on entry (the caller's business); scratch: cand_scratch_bytes(BLOCK)
-// bytes of LDS, 8-byte aligned.  Every thread of the workgroup must call (barriers inside).
+// bytes of LDS, 8-byte aligned; cid_lds: null, or [64] slots in LDS that get the same list (all -1 on entry, outside `scratch`;
+// readable behind the caller's next barrier).  Every thread of the workgroup must call (barriers inside).
 template <int BLOCK>
-__device__ __forceinline__ void cand_select(const double (&pv)[kCandPer], unsigned have, int per, int beam, int32_t* cid, unsigned char* scratch) {
+__device__ __forceinline__ void cand_select(const double (&pv)[kCandPer], unsigned have, int per, int beam, int32_t* cid, unsigned char* scratch,
+                                            int32_t* cid_lds = nullptr) {
     constexpr int kW = BLOCK / 64;
     double* wl_p = reinterpret_cast<double*>(scratch);
     int* wl_v = reinterpret_cast<int*>(wl_p + kW * kCandMaxBeam);
@@ -84,7 +86,10 @@ __device__ __forceinline__ void cand_select(const double (&pv)[kCandPer], unsign
     __syncthreads();
     for (int c = threadIdx.x; c < kW * beam; c += BLOCK) {
         const int w = c / beam, k = c - w * beam;
-        if (k < wl_n[w] && rank[w * kCandMaxBeam + k] < beam) cid[rank[w * kCandMaxBeam + k]] = wl_v[w * kCandMaxBeam + k];
+        if (k < wl_n[w] && rank[w * kCandMaxBeam + k] < beam) {
+            cid[rank[w * kCandMaxBeam + k]] = wl_v[w * kCandMaxBeam + k];
+            if (cid_lds) cid_lds[rank[w * kCandMaxBeam + k]] = wl_v[w * kCandMaxBeam + k];
+        }
     }
 }
 

@@ -52,7 +52,8 @@ int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, i
 int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                  int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
                  double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
-                 unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s);
+                 int32_t by_priority, int32_t* whole_step, unsigned long long* tail_word, unsigned long long tail_tag, void* bws,
+                 hipStream_t s);
 
 // big2.hip: the same for graphs of 977 .. 1 920 vertices (Z1 a feature half at a time)
 int big2_takes(const DgcnBatch* b, const DgcnModel* m);
@@ -68,7 +69,8 @@ int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, 
 int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, float x_const, const double* weights,
                   int32_t predict_mwis, int32_t greedy_mode, int32_t max_rounds, float* scores, uint8_t* state, int32_t* rounds,
                   double* totals, int32_t* progress, int32_t* status, double* prio, int32_t* active, int32_t* cid, int32_t beam,
-                  unsigned long long* tail_word, unsigned long long tail_tag, void* bws, hipStream_t s);
+                  int32_t by_priority, int32_t* whole_step, unsigned long long* tail_word, unsigned long long tail_tag, void* bws,
+                  hipStream_t s);
 
 // wide.hip: one-layer models on graphs of any size - the plain solve, or the score / priority / greedy part of a residual step,
 // in one launch
@@ -76,8 +78,8 @@ int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t 
 int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
               int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
               int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
-              double* prio, int32_t* active, int32_t* cid, int32_t beam, unsigned long long* tail_word, unsigned long long tail_tag,
-              hipStream_t s);
+              double* prio, int32_t* active, int32_t* cid, int32_t beam, int32_t by_priority, int32_t* whole_step,
+              unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s);
 
 constexpr int kResBlock = 1024;  // (graphs of this path are large and batches of them small: 64 graphs x 256 threads left the chip idle)
 constexpr int kMaxBeam = 64;
@@ -557,7 +559,7 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
         if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
                                general_workspace(b, m), workspace_bytes);
         return wide1_run(b, m, dinv_table, table_len, X, x_const, 0, weights, predict_mwis, 0, 0, 0, 0, sc1, state, rounds, totals, nullptr,
-                         status, nullptr, nullptr, nullptr, 0, nullptr, 0, s);
+                         status, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, s);
     }
     int32_t* lrow = w.take<int32_t>(n + 1);
     int32_t* lcol = w.take<int32_t>(n + e);
@@ -636,19 +638,22 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     const dim3 gb((unsigned)b->num_graphs), tb(kResBlock);
     bool wide = wide1_takes(b, m, X, feature_mode) != 0;
     bool cand_done = false;  // the rollout's candidates were selected inside the step's own launch (cand_select.h)
+    int32_t whole_step = 0;  // ... and so were the completions and the pick (rollout_bits.h)
     if (!wide && big && big_residual_takes(b, m, X, feature_mode, options)) {
         // deep c32 stacks on graphs k_big takes, constant input features: activity test, the residual graph's support, every layer,
         // priorities and the greedy step (rounds / central pick) in ONE launch on the graph as it lies - no compaction, no k_lgs;
         // the rollout's four launches follow on the priorities it leaves
         const int rc = big_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
-                                    state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word, tail_tag, bws, s);
-        if (rc || greedy_mode != 2) return rc;
+                                    state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, a.by_priority, &whole_step,
+                                    tail_word, tail_tag, bws, s);
+        if (rc || greedy_mode != 2 || whole_step) return rc;  // (whole_step: completions and pick ran in that launch, rollout_bits.h)
         wide = true;  // (what follows is the same as behind the one-layer kernel: the rollout's launches)
         cand_done = true;  // (the candidates were selected at the end of that launch)
     } else if (!wide && big2 && big2_residual_takes(b, m, X, feature_mode, options)) {  // the same for 977 .. 1 920 vertices (k_big2)
         const int rc = big2_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
-                                     state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word, tail_tag, bws, s);
-        if (rc || greedy_mode != 2) return rc;
+                                     state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, a.by_priority, &whole_step,
+                                     tail_word, tail_tag, bws, s);
+        if (rc || greedy_mode != 2 || whole_step) return rc;
         wide = true;
         cand_done = true;
     } else
@@ -656,9 +661,9 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE
         // launch on the graph as it lies - no compaction; the rollout's four launches follow on the priorities it leaves
         const int rc = wide1_run(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, 1, given ? 1 : 0, greedy_mode,
-                                 max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, tail_word,
-                                 tail_tag, s);
-        if (rc || greedy_mode != 2) return rc;
+                                 max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, a.by_priority,
+                                 &whole_step, tail_word, tail_tag, s);
+        if (rc || greedy_mode != 2 || whole_step) return rc;  // (whole_step: completions and pick ran in that launch, rollout_bits.h)
         cand_done = true;
     }
     if (!wide) {

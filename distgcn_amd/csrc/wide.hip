@@ -32,6 +32,7 @@
 #include "common.h"
 #include "lgs_rounds.h"
 #include "cand_select.h"
+#include "rollout_bits.h"
 
 namespace dgcn {
 
@@ -67,6 +68,8 @@ struct WideArgs {
     int32_t* active;           // mode 2: [num_graphs] out
     int32_t* cid;              // mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
     int32_t beam;
+    int32_t roll_off;          // mode 2: byte offset of the LDS the completions and the pick run in (rollout_bits.h) - the whole step in
+    int32_t by_priority;       // this launch; 0: general.hip's k_lgs / k_res_pick launches follow.  by_priority: the completions' order
     unsigned long long* tail_word;
     unsigned long long tail_tag;
     int32_t max_nodes, cols_cap;
@@ -448,6 +451,26 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
                 const int v = threadIdx.x + p * kWideBlock;
                 if (v < ng && st[v] == 0) have |= 1u << p;
             }
+            if (a.roll_off) {
+                // the whole step here: candidates (list mirrored in LDS), the completions of all of them at once, the pick
+                unsigned char* tail = wide_raw + a.roll_off;
+                int32_t* cidl = reinterpret_cast<int32_t*>(tail + ((cand_scratch_bytes(kWideBlock) + 15) & ~(size_t)15));
+                if (threadIdx.x < kCandMaxBeam) cidl[threadIdx.x] = -1;
+                __syncthreads();
+                cand_select<kWideBlock>(pmine, have, (ng + kWideBlock - 1) / kWideBlock, min(a.beam, kCandMaxBeam),
+                                        a.cid + (size_t)g * kCandMaxBeam, tail, cidl);
+                if (!a.by_priority)  // (the completions go by weight: mwis_gdpg_call.py:640)
+                    for (int v = threadIdx.x; v < ng; v += kWideBlock) pr[v] = a.weights[n0 + v];
+                __syncthreads();
+                RollArgs r;
+                r.ng = ng; r.n0 = n0; r.e0 = e0;
+                r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
+                r.extra = reinterpret_cast<unsigned char*>(cidl + kCandMaxBeam);
+                r.max_nodes = a.max_nodes;
+                r.col_idx = a.col_idx; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                rollout_bits<kWideBlock>(r, g);
+                return;
+            }
             __syncthreads();  // (the selection's scratch takes the carve from its start: nothing of it is read again)
             cand_select<kWideBlock>(pmine, have, (ng + kWideBlock - 1) / kWideBlock, min(a.beam, kCandMaxBeam),
                                     a.cid + (size_t)g * kCandMaxBeam, wide_raw);
@@ -567,9 +590,10 @@ static int wide1_launch_l(const WideArgs& a, int B, size_t lds, const char* fami
 int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, int32_t table_len, const float* X, float x_const,
               int32_t feature_mode, const double* weights, int32_t predict_mwis, int32_t residual, int32_t scores_given, int32_t mode,
               int32_t max_rounds, float* sc, uint8_t* state, int32_t* rounds, double* totals, int32_t* progress, int32_t* status,
-              double* prio, int32_t* active, int32_t* cid, int32_t beam, unsigned long long* tail_word, unsigned long long tail_tag,
-              hipStream_t s) {
+              double* prio, int32_t* active, int32_t* cid, int32_t beam, int32_t by_priority, int32_t* whole_step,
+              unsigned long long* tail_word, unsigned long long tail_tag, hipStream_t s) {
     const DgcnLayer& L = m->layers_host[0];
+    if (whole_step) *whole_step = 0;
     WideArgs a = {};
     a.graph_ptr = b->graph_ptr; a.row_ptr = b->row_ptr; a.col_idx = b->col_idx;
     a.dinv = dinv_table; a.table_len = table_len;
@@ -593,6 +617,19 @@ int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     a.cols_cap = cap;
     size_t lds = wide_lds_bytes(a.max_nodes, cap);
     if (a.cid) lds = std::max(lds, (size_t)cand_scratch_bytes(kWideBlock));  // (small graphs: the selection's scratch is the larger)
+    a.by_priority = by_priority;
+    if (a.cid && whole_step) {
+        // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do and the columns, the
+        // selection's scratch and the instances' state words all fit the LDS.  DGCN_ROLLOUT_BITS=0: general.hip's launches.
+        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        const size_t base = (wide_lds_bytes(a.max_nodes, cap) + 15) & ~(size_t)15;
+        const size_t need = base + ((cand_scratch_bytes(kWideBlock) + 15) & ~(size_t)15) + kCandMaxBeam * 4 + roll_lds_bytes(a.max_nodes);
+        if (!bits_off && beam <= kRollBeam && weights && (cap > 0 || b->max_graph_edges == 0) && need <= kLdsMax) {
+            a.roll_off = (int32_t)base;
+            lds = need;
+            *whole_step = 1;
+        }
+    }
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_wide1: %zu bytes of LDS for graphs of %d vertices", lds, b->max_nodes);
     const char* family = residual ? "wide_residual" : "wide_solve";
     // lanes per vertex in the rounds: k_lgs's choice for 1 024-thread workgroups
