@@ -1815,7 +1815,71 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             // of it in the order, whatever the schedule (heuristics.py:13-35 sweeps sequentially, :77-116 in synchronous
             // rounds - same set).  (One after the other with the whole workgroup per candidate this was ~20 barriers x 16
             // candidates = 120 of a step's 300 us at N = 500.)
-            {
+            if (nc <= 16) {
+                // Up to sixteen candidates (the reference's b = 16): ALL completions at once, an instance per bit (the scheme of
+                // rollout_bits.h on this kernel's image).  S[v] = live mask | joined mask << 16 | rank << 32; a vertex looks at
+                // its neighbours of lower rank: one that has joined kills it (in the instances where it has), none of them left
+                // alive lets it join - sixteen instances with a few bit operations per neighbour, no rounds, no barriers: every
+                // wave goes over its vertices until they are decided.  Same sets as instance after instance (the set a greedy
+                // search by a total order returns does not depend on the schedule, see below); totals in a fixed order.
+                // (A wave per candidate on its own rank array, below: 49 us of a step at 500 vertices, 15 at 180.)
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                constexpr int kWaves = BLOCK / 64;
+                const unsigned short* kbase = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey : wkey;
+                unsigned long long* S = reinterpret_cast<unsigned long long*>(cid + 64);  // [ng], behind pick / cand / cid
+                volatile unsigned long long* Sv = S;
+                volatile unsigned* Slo = reinterpret_cast<volatile unsigned*>(S);  // word 2 v: the masks of vertex v
+                const unsigned full = (1u << nc) - 1u;
+                const unsigned myrank = tv < ng ? (unsigned)kbase[tv] : 0u;
+                if (tv < ng) S[tv] = ((unsigned long long)myrank << 32) | full;
+                __syncthreads();
+                for (int i = wave; i < nc; i += kWaves) {  // instance i: candidate i and its neighbours do not take part
+                    const int c = cid[i];
+                    const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
+                    for (int j = crs + lane; j < cre; j += 64)  // (diagonal entry: c itself)
+                        atomicAnd(reinterpret_cast<unsigned*>(S) + 2 * (words[j] >> 7), ~(1u << i));
+                }
+                __syncthreads();
+                {
+                    const int vrs = tv < ng ? (int)(rinfo[tv] & 0xffff) : 0, vre = tv < ng ? vrs + (int)(rinfo[tv] >> 16) : 0;
+                    bool more;
+                    do {
+                        more = false;
+                        unsigned mine = tv < ng ? Slo[2 * tv] : 0u;
+                        const unsigned live = mine & 0xffffu;
+                        if (live) {
+                            unsigned seen = 0u;
+                            int j = vrs;
+                            for (; j + 3 < vre; j += 4) {  // four word -> state chains in flight
+                                const int u0 = words[j] >> 7, u1 = words[j + 1] >> 7, u2 = words[j + 2] >> 7, u3 = words[j + 3] >> 7;
+                                const unsigned long long s0 = Sv[u0], s1 = Sv[u1], s2 = Sv[u2], s3 = Sv[u3];
+                                seen |= ((unsigned)(s0 >> 32) < myrank ? (unsigned)s0 : 0u) | ((unsigned)(s1 >> 32) < myrank ? (unsigned)s1 : 0u) |
+                                        ((unsigned)(s2 >> 32) < myrank ? (unsigned)s2 : 0u) | ((unsigned)(s3 >> 32) < myrank ? (unsigned)s3 : 0u);
+                            }
+                            for (; j < vre; ++j) {
+                                const unsigned long long s0 = Sv[words[j] >> 7];
+                                seen |= (unsigned)(s0 >> 32) < myrank ? (unsigned)s0 : 0u;
+                            }
+                            const unsigned killed = seen >> 16;
+                            const unsigned die = live & killed, win = live & ~killed & ~(seen & 0xffffu);
+                            if (die | win) {
+                                mine = (live & ~die & ~win) | (((mine >> 16) | win) << 16);
+                                Slo[2 * tv] = mine;
+                            }
+                            more = (mine & 0xffffu) != 0u;
+                        }
+                    } while (__any(more));
+                }
+                __syncthreads();
+                for (int i = wave; i < nc; i += kWaves) {  // totals: instance i on wave i, lane-strided partials + a shuffle tree
+                    double tot = 0.0;
+                    for (int v = lane; v < ng; v += 64)
+                        if ((Slo[2 * v] >> (16 + i)) & 1u) tot += wl[v];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                    if (lane == 0) cand[i] = wl[cid[i]] + tot;
+                }
+            } else {
                 const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
                 constexpr int kWaves = BLOCK / 64;
                 unsigned short* kbase = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey : wkey;
