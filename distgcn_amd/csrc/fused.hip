@@ -1793,6 +1793,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         __syncthreads();
         const int rs = mine ? (int)(rinfo[vv] & 0xffff) : 0, re = mine ? rs + (int)(rinfo[vv] >> 16) : 0;
         int rounds = 0;
+        int picked = -1;  // the rollout's pick
         if (a.greedy_mode != 2) {
             rounds = greedy_rounds<BLOCK>(key, st, 2, words, rs, re, vv, sub, lpv, mine, wflags, a.max_rounds, a.greedy_mode == 1);
         } else {
@@ -1931,20 +1932,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                // np.isclose(cand, cand.max(), rtol=1e-12, atol=0): the first candidate within tolerance wins
-                double mx = cand[0];
-                for (int i = 1; i < nc; ++i) mx = fmax(mx, cand[i]);
-                int best = 0;
-                for (int i = 0; i < nc; ++i)
-                    if (fabs(cand[i] - mx) <= 1e-12 * fabs(mx)) { best = i; break; }
-                pick[1] = best;
+            {
+                // np.isclose(cand, cand.max(), rtol=1e-12, atol=0): the first candidate within tolerance wins (none within it -
+                // totals that are not finite -: the first).  A lane per candidate, every wave for itself: no barrier, no serial
+                // walk of thread 0 over the list.
+                const int lane = threadIdx.x & 63;
+                const double cv = lane < nc ? cand[lane] : -1.0 / 0.0;
+                double mx = cv;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+                const unsigned long long tied = __ballot(lane < nc && fabs(cv - mx) <= 1e-12 * fabs(mx));
+                picked = cid[tied ? __ffsll((long long)tied) - 1 : 0];
             }
-            __syncthreads();
-            const int best = pick[1];
-            if (tv < ng && gkey[tv] == (unsigned short)best) pick[0] = tv;
-            __syncthreads();
-            const int c = pick[0];
+            const int c = picked;
             const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
             for (int j = crs + tv; j < cre; j += BLOCK) {
                 const int u = words[j] >> 7;
@@ -1956,7 +1956,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (tv < ng && was_alive) a.state[n0 + voff + tv] = st[tv];
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
         if (threadIdx.x == 0 && a.progress) atomicAdd(a.progress, 1);
-        if (a.totals) {
+        if (a.totals && picked >= 0) {  // (the rollout: one vertex joined)
+            if (threadIdx.x == 0) a.totals[g] = a.weights ? wl[picked] : pr[picked];
+        } else if (a.totals) {
             double part = 0.0;
             if (tv < ng && was_alive && st[tv] == 1) part = a.weights ? wl[tv] : pr[tv];
             const double tot = block_sum<BLOCK>(part, red);
