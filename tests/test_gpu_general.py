@@ -508,3 +508,30 @@ def test_rollout_nan_weight_on_the_any_size_path(engine, golden, general_switch,
     assert not b[sl[1][0]:sl[1][1]].any()                                 # the graph with the NaN: untouched
     for g in (0, 2):
         assert np.array_equal(a[sl[g][0]:sl[g][1]], b[sl[g][0]:sl[g][1]])  # the others: as without it
+
+
+@pytest.mark.parametrize("num_layer,nodes", [(1, 900), (2, 900), (5, 900), (5, 1500)])
+def test_rollout_in_one_launch_agrees_with_the_instance_launches(engine, tmp_path, num_layer, nodes):
+    """Witness for csrc/rollout_bits.h: complete searches on three ragged graphs (zero weights inside live graphs) by a child
+    process as built - candidates, all completions (an instance per bit) and the pick inside the step's launch of k_wide1 /
+    k_big / k_big2 - and by one with DGCN_ROLLOUT_BITS=0 - k_lgs on beam x graphs masked instances + k_res_pick: the same
+    states after the same number of steps (and every other solver's results untouched by the switch)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_wide_witness.py")
+    files = {}
+    for tag, val in (("bits", "1"), ("launches", "0")):
+        files[tag] = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ, DGCN_ROLLOUT_BITS=val)
+        subprocess.run([sys.executable, script, files[tag], str(num_layer), str(nodes)], check=True, env=env, timeout=600)
+    a, b = np.load(files["bits"]), np.load(files["launches"])
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k.endswith("_scores"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        elif k.endswith("_totals"):
+            assert np.allclose(a[k], b[k], rtol=1e-12), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+    assert a["rollout_steps"][0] > 50 and not (a["rollout_state"] == 0).any()
