@@ -696,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
         }
         if (resid && a.greedy_mode == 2) {
             // the rollout: priorities out (a decided vertex: 0, as k_res_scatter leaves it); candidates, instances, completions
-            // and the pick are general.hip's launches
+            // and the pick run right here (rollout_bits.h) or, beyond sixteen candidates, as general.hip's launches
             if (tv < ng) a.prio_out[n0 + tv] = part ? pr[tv] : 0.0;
             if (threadIdx.x == 0 && a.active) a.active[g] = 1;
             if (fault) atomicOr(a.status, fault);
@@ -1061,7 +1061,8 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
 // One step of dgcn_solve_residual_batch in ONE launch (constant input features, k_big's shapes): the residual graph's support
 // from the adjacency and the running state, every layer, priorities, and the greedy step - local rounds (solve_mwis_dit,
 // mwis_gdpg_call.py:278-318) or the central pick (solve_mwis_cit, :343-384); for the rollouts (:596-659) the priorities are
-// left in `prio` and general.hip's candidate / completion / pick launches follow.  DGCN_BIG_RESIDUAL=0: the compaction
+// left in `prio` and the candidates, all completions and the pick run at the end of the same launch (cand_select.h, rollout_bits.h; beyond sixteen
+// candidates general.hip's k_lgs / k_res_pick launches follow instead).  DGCN_BIG_RESIDUAL=0: the compaction
 // launches + k_big + k_lgs instead (tests compare the two).
 int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options) {
     static const int on = env_once("DGCN_BIG_RESIDUAL");

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
             if (a.progress) atomicAdd(a.progress, 1);
             if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)nr);
         }
-        if (resid && a.greedy_mode == 2) {  // the rollout: priorities out; candidates, instances, completions and the pick are general.hip's launches
+        if (resid && a.greedy_mode == 2) {  // the rollout: priorities out; candidates, completions and the pick below (or, beyond sixteen candidates, general.hip's launches)
             for (int v = threadIdx.x; v < ng; v += kB2Block) a.prio_out[n0 + v] = st[v] == 0 ? pr[v] : 0.0;
             if (threadIdx.x == 0 && a.active) a.active[g] = 1;
             if (fault) atomicOr(a.status, fault);

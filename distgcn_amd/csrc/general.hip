@@ -642,7 +642,7 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     if (!wide && big && big_residual_takes(b, m, X, feature_mode, options)) {
         // deep c32 stacks on graphs k_big takes, constant input features: activity test, the residual graph's support, every layer,
         // priorities and the greedy step (rounds / central pick) in ONE launch on the graph as it lies - no compaction, no k_lgs;
-        // the rollout's four launches follow on the priorities it leaves
+        // the rollout's remaining launches follow on the priorities it leaves (none when the step ran whole in that launch)
         const int rc = big_residual(b, m, dinv_table, table_len, x_const, weights, predict_mwis, greedy_mode, max_rounds, scores ? scores : sc,
                                     state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, a.by_priority, &whole_step,
                                     tail_word, tail_tag, bws, s);
@@ -659,7 +659,7 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     } else
     if (wide) {
         // one-layer models: activity test, residual degrees, scores, priorities and the greedy step (rounds / central pick) in ONE
-        // launch on the graph as it lies - no compaction; the rollout's four launches follow on the priorities it leaves
+        // launch on the graph as it lies - no compaction; a rollout's completions and pick too (rollout_bits.h) unless k_lgs / k_res_pick have to follow
         const int rc = wide1_run(b, m, dinv_table, table_len, X, x_const, feature_mode, weights, predict_mwis, 1, given ? 1 : 0, greedy_mode,
                                  max_rounds, scores ? scores : sc, state, rounds, totals, progress, status, a.prio, a.active, a.cid, beam, a.by_priority,
                                  &whole_step, tail_word, tail_tag, s);

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
         if (a.progress) atomicAdd(a.progress, 1);
         if (a.tail_word) atomicMax(a.tail_word, a.tail_tag | (unsigned long long)(unsigned)cnt);
     }
-    if (a.mode == 2) {  // the rollout's candidate / instance / completion / pick launches follow (general.hip)
+    if (a.mode == 2) {  // the rollout: candidates, completions and the pick right here, or general.hip's launches behind this one
         if (threadIdx.x == 0 && a.active) a.active[g] = 1;
         if (a.cid) {  // the candidates right here, the priorities still in registers: no k_res_cand launch
             static_assert(kCandPer * kWideBlock >= kWideMaxNodes && kCandPer == (kWideMaxNodes + kWideBlock - 1) / kWideBlock, "pmine is the selection's layout");
