@@ -59,7 +59,7 @@ def parse(argv=None):
                     help="also time the step issued alternately on two HIP streams (side figure; its overlapping launches would "
                          "blur a kernel trace of the run, so it is not part of the default command)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at N=1")
-    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5", "ER500", "MC900", "MC900-l1", "MC1500"], default=None,
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C4-share", "C5", "ER500", "MC900", "MC900-l1", "MC1500", "MC900-rollout"], default=None,
                     help="BASELINE.json configuration shortcuts: C2 = 500 ER N=100 l=1; C3 = 500 ER N=200 l=20 (the default line); "
                          "C4 = the 4 000-graph BA batch over the ranks (--layers as given, default 20); C4-share = one GPU's 500 "
                          "graphs of it; C5 = GCN-guided rollout (b=16) on 64 ER N=500 graphs; beyond the fused kernel's 512 vertices / LDS "
@@ -93,14 +93,16 @@ def parse(argv=None):
         args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 900, 0.03, 1
     elif args.config == "MC1500":
         args.family, args.graphs, args.nodes, args.p, args.layers = "mc", (args.graphs or 256), 1500, 0.03, 20
+    elif args.config == "MC900-rollout":  # C5's search on the multi-channel joint graphs: every step one launch of the any-size path
+        args.family, args.graphs, args.nodes, args.p = "mc", (args.graphs or 64), 900, 0.03
     if args.config in ("ER500", "MC900", "MC1500") and args.steps is None:
         args.steps = 400
     if args.graphs is None:
         args.graphs = 500
     if args.steps is None:
-        args.steps = 20 if args.config == "C5" else 1500
+        args.steps = 20 if args.config in ("C5", "MC900-rollout") else 1500
     if args.warmup is None:
-        args.warmup = 2 if args.config == "C5" else 20
+        args.warmup = 2 if args.config in ("C5", "MC900-rollout") else 20
     return args
 
 
@@ -335,7 +337,10 @@ class RolloutWorkload:
         self.torch, self.args = torch, args
         self.dev = "cuda:%d" % local
         torch.cuda.set_device(local)
-        self.hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
+        if args.family == "mc":  # joint K x nflows conflict graphs (wireless_dqn_test_mc.py:161, 244-289): the any-size path
+            self.hb = datagen.multichannel_batch(args.graphs, args.nodes // 3, args.p, first_index=rank * args.graphs)
+        else:
+            self.hb = datagen.er_batch(args.graphs, args.nodes, args.p, first_index=rank * args.graphs)
         self.job_graphs = world * args.graphs
         self.layers, self.weights_note = load_layers(args)
         self.eng = Engine(self.dev)
@@ -380,7 +385,7 @@ class RolloutWorkload:
 
     def kernel_times(self):
         out = {}
-        for fam in ("fused_residual", "tail_finish"):
+        for fam in ("fused_residual", "big_residual", "wide_residual", "tail_finish"):
             ms, n = self.eng.timing_read(fam)
             if n:
                 out[fam] = (ms, n)
@@ -841,9 +846,9 @@ def main(argv=None, workload_factory=None):
         os.environ.setdefault("WORLD_SIZE", "1")
         parallel.init_rank_group(args.backend)
 
-    if args.config == "C5":
+    if args.config in ("C5", "MC900-rollout"):
         args.no_gather = True  # (the searches' sets stay on their ranks: nothing of C5 is gathered per launch)
-    wl = (workload_factory or (RolloutWorkload if args.config == "C5" else GpuWorkload))(args, rank, world, local)
+    wl = (workload_factory or (RolloutWorkload if args.config in ("C5", "MC900-rollout") else GpuWorkload))(args, rank, world, local)
     hb = wl.hb
     cdev = wl.collective_device()
 
@@ -882,7 +887,7 @@ def main(argv=None, workload_factory=None):
         while pending:
             pending.pop(0)[0].wait()
 
-    if hasattr(wl, "settle") and args.config != "C5":
+    if hasattr(wl, "settle") and args.config not in ("C5", "MC900-rollout"):
         wl.settle()
     res = None
     for _ in range(args.warmup):
@@ -934,7 +939,8 @@ def main(argv=None, workload_factory=None):
 
     fam_ms = wl.kernel_times()
     if isinstance(wl, RolloutWorkload):
-        ms, n = fam_ms.get("fused_residual", (0.0, 0))
+        step_family = next((f for f in ("fused_residual", "big_residual", "wide_residual") if fam_ms.get(f, (0.0, 0))[1]), "fused_residual")
+        ms, n = fam_ms.get(step_family, (0.0, 0))
         per_step, search_steps = wl.residual_bytes() if rank == 0 else ([0.0], 1)
         # A search of `search_steps` solver steps (the untimed replay's count) is `calls` calls of dgcn_solve_residual_batch:
         # one step each, and - once every graph has at most 64 undecided vertices - the rest inside ONE launch of the tail
@@ -951,18 +957,20 @@ def main(argv=None, workload_factory=None):
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(tpath):  # FETCH_SIZE / WRITE_SIZE passes of a whole search, averaged over its k_fused launches (the empty ones included)
             c5_traffic = json.load(open(tpath)).get("fused_residual|%dx%d|l%d" % (args.graphs, args.nodes, args.layers), {}).get("hbm_bytes_per_launch")
-        roofline = {"kernel": "k_fused<residual graph> (one launch = forward on every residual graph + %d greedy completions + pick)" % args.beam,
-                    "bound": "lds+mfma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+        step_kernel = {"fused_residual": "k_fused<residual graph>", "big_residual": "k_big / k_big2<residual graph> (any-size path)",
+                       "wide_residual": "k_wide1 residual mode (any-size path, one- and two-layer models)"}[step_family]
+        roofline = {"kernel": "%s (one launch = forward on every residual graph + %d greedy completions + pick)" % (step_kernel, args.beam),
+                    "bound": "latency" if step_family == "wide_residual" else "lds+mfma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
                     "traffic": c5_traffic,
-                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE passes of tools/run_iterative.py --only rollout on this configuration (profiles/hbm_traffic.json): average over ALL k_fused launches of a search, the empty ones behind its end included", "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
+                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE passes of tools/run_iterative.py --only rollout on this configuration (profiles/hbm_traffic.json): average over ALL launches of the step kernel in a search, the empty ones behind its end included (null: no pass taken for this configuration)", "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
                     "empty_launches_per_search": n / max(args.steps, 1) - calls,
                     "algorithmic_bytes_per_launch": algo / calls,
-                    "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's k_fused launches",
+                    "formula": "SURVEY 8d: sum over layers of B_spmm on the RESIDUAL graphs of each launch (sizes from an untimed replay), averaged over a search's launches of the step kernel",
                     "tail": {"kernel": "k_tail (the last steps of every graph in one launch, from <= 64 undecided vertices on)",
                              "steps_inside": search_steps - calls, "ms_per_search": tms / max(args.steps, 1),
                              "launches_per_search": tn / max(args.steps, 1),
                              "algorithmic_bytes": float(sum(per_step[calls:]))}}
-        kernel_us = {"fused_residual": {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)},
+        kernel_us = {step_family: {"avg_us": avg_s * 1e6, "launches_per_step": n / max(args.steps, 1)},
                      "tail_finish": {"ms_per_step": tms / max(args.steps, 1), "launches_per_step": tn / max(args.steps, 1)}}
         traffic_db = {}
     else:
@@ -1026,9 +1034,15 @@ def main(argv=None, workload_factory=None):
             "kernels": kernel_us,
         }
         if isinstance(wl, RolloutWorkload):
-            out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on ER N=%d p=%g" % (args.beam, args.nodes, args.p)
-            out["config"]["workload"] = ("C5: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per step of the search, "
-                                         "~%d calls per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
+            if args.family == "mc":
+                out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on joint 3-channel conflict graphs of %d vertices" % (args.beam, args.nodes)
+                out["config"]["workload"] = ("MC900-rollout: %d joint 3 x %d-flow conflict graphs per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per "
+                                             "step of the search, every step ONE launch of the any-size path, ~%d calls per search"
+                                             % (args.graphs, args.nodes // 3, args.layers, args.hidden, args.beam, wl.launches))
+            else:
+                out["metric"] = "graphs/sec (GCN-guided rollout search, b=%d, to completion) on ER N=%d p=%g" % (args.beam, args.nodes, args.p)
+                out["config"]["workload"] = ("C5: %d ER graphs N=%d p=%g per GPU, l=%d c=%d GCN2_DQN forward + %d-candidate rollout per step of the search, "
+                                             "~%d calls per search" % (args.graphs, args.nodes, args.p, args.layers, args.hidden, args.beam, wl.launches))
         if world == 1 and args.cpu_seconds > 0 and isinstance(wl, RolloutWorkload):
             out["cpu_baseline"] = c5_cpu_baseline(wl, args.cpu_seconds)
         elif world == 1 and args.cpu_seconds > 0:
