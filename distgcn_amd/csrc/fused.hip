@@ -2325,7 +2325,11 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // N = 300 from 7 - 8 on)
     const int min_layers = (blocks >= 10 && blocks <= 16) ? 5 : 8;
     // (five to eight tiles per workgroup run - a tile per wave, two row sets per wave - but do not pay: 64 graphs of N = 500,
-    // K = 4: 183.6 against 177.1 us per residual step, 244.6 against 210.4 per rollout step; forced K only)
+    // K = 4: 183.6 against 177.1 us per residual step, 244.6 against 210.4 per rollout step in round 4.  Round 5, with the
+    // step's ranking and completions short: complete searches of those 64 graphs 10.7 -> 10.3 ms (rollout), 8.2 -> 7.7 ms (cit)
+    // with DGCN_FUSED_CLUSTER=4 - 4 .. 7 %, for a launch that needs EVERY CU of the device free at once (64 x 4 workgroups,
+    // one per CU: anything else running makes a workgroup wait for its peers until the spin bound reports a fault).
+    // Forced K only: tools/runs/r05_gpu39.sh)
     if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers || (blocks + K - 1) / K > 4)) return 0;
     return K;
 }
