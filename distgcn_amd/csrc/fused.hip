@@ -40,6 +40,7 @@
 
 #include "common.h"
 #include "tile_ops.h"
+#include "wave_reduce.h"
 #include <type_traits>
 
 namespace dgcn {
@@ -948,13 +949,16 @@ __device__ __forceinline__ double block_sum(double part, double* red) {
 // that are all different give counts that add up to ng (ng - 1) / 2, equal values share a count and the sum falls short - then
 // (and only then) every vertex adds the equal values below its index.  `cnt`: NK * cstride + NK words of LDS, cstride >= ng.
 // Barriers inside; the caller passes one before (values written) and one after (ranks written).
-template <int BLOCK, int NK>
+// PREZEROED: the caller has cleared `cnt` and passed a barrier since (saves the one here).
+template <int BLOCK, int NK, bool PREZEROED = false>
 __device__ __forceinline__ void rank_blocked(int ng, const double* val0, const double* val1, unsigned* cnt, int cstride,
                                              unsigned short* out0, unsigned short* out1) {
     constexpr int W = BLOCK / 64, KV = 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tv = threadIdx.x;
-    for (int i = threadIdx.x; i < NK * cstride + NK; i += BLOCK) cnt[i] = 0u;
-    __syncthreads();
+    if constexpr (!PREZEROED) {
+        for (int i = threadIdx.x; i < NK * cstride + NK; i += BLOCK) cnt[i] = 0u;
+        __syncthreads();
+    }
     const int VB = (ng + 64 * KV - 1) / (64 * KV);  // blocks of 256 vertices: 1 or 2
     const int WS = W / VB;                          // waves per block: each takes a share of the w range
     const int vb = wave % VB, ws = wave / VB;
@@ -1746,8 +1750,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             wl[tv] = wmine;
             st[tv] = was_alive ? 0 : a.state[n0 + tv];
         }
+        // (the rollout: the ranking's counters and the candidate list cleared here, in front of the barrier the NaN vote brings -
+        // the step's greedy part is a dozen short phases, and every barrier between two of them costs as much as a phase)
+        unsigned* rcnt = reinterpret_cast<unsigned*>(reinterpret_cast<int*>(cand + 64) + 64);  // behind pick / cand / cid
+        if (a.greedy_mode == 2) {
+            for (int i = threadIdx.x; i < 2 * a.max_nodes + 2; i += BLOCK) rcnt[i] = 0u;
+            if (threadIdx.x < 64) reinterpret_cast<int*>(cand + 64)[threadIdx.x] = -1;
+        }
         const bool any_bad = block_or<BLOCK>(bad != 0, wflags);
-        __syncthreads();
+        if (a.greedy_mode != 2) __syncthreads();  // (the vote's flag words are written again by the rounds' votes; the rollout has none)
         if (any_bad) {
             if (threadIdx.x == 0) {
                 atomicOr(a.status, fault | DGCN_FAULT_NAN_PRIORITY);
@@ -1762,10 +1773,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         const int vv = threadIdx.x >> lsh, sub = threadIdx.x & (lpv - 1);
         const bool mine = vv < ng;
         // (every vertex of the image is undecided - the renumbering in P0 - so all ng of them are ranked)
-        unsigned* rcnt = reinterpret_cast<unsigned*>(reinterpret_cast<int*>(cand + 64) + 64);  // behind pick / cand / cid: the completions' space
+        // the candidates: the first `beam` vertices in priority order = ranks 0 .. nc - 1 (every rank below ng exists)
+        const int nc = min(min(a.beam, 64), ng);
+        unsigned long long* S = reinterpret_cast<unsigned long long*>(rcnt + 2 * a.max_nodes + 2);  // [ng] the completions' state words (below)
         if (a.greedy_mode == 2) {
-            rank_blocked<BLOCK, 2>(ng, pr, wl, rcnt, a.max_nodes, gkey, wkey);
-            if (tv < ng) key[tv] = gkey[tv];
+            rank_blocked<BLOCK, 2, true>(ng, pr, wl, rcnt, a.max_nodes, gkey, wkey);
+            if (tv < ng) {  // (this thread's own ranks: written by it just now)
+                const unsigned gk = gkey[tv];
+                key[tv] = (unsigned short)gk;
+                if ((int)gk < nc) reinterpret_cast<int*>(cand + 64)[gk] = tv;  // candidate i is the vertex of rank i: one scatter
+                const unsigned kb = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gk : (unsigned)wkey[tv];
+                if (nc <= 16) S[tv] = ((unsigned long long)kb << 32) | ((1u << nc) - 1u);
+            }
         } else if (a.greedy_mode == 0) {
             rank_blocked<BLOCK, 1>(ng, pr, nullptr, rcnt, a.max_nodes, key, nullptr);
         } else {
@@ -1799,13 +1818,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         } else {
             // candidates in GCN-priority order (stable argsort of -priority = the rank keys): candidate i is the vertex of
             // rank i, so the list is one scatter
-            int* cid = reinterpret_cast<int*>(cand + 64);  // [64]
-            if (threadIdx.x < 64) cid[threadIdx.x] = -1;
-            __syncthreads();
-            if (tv < ng && gkey[tv] < (unsigned short)min(a.beam, 64)) cid[gkey[tv]] = tv;
-            __syncthreads();
-            int nc = 0;
-            while (nc < a.beam && nc < 64 && cid[nc] >= 0) ++nc;  // fewer remaining vertices than candidates: the list ends early
+            int* cid = reinterpret_cast<int*>(cand + 64);  // [64], filled with the ranks above (fewer remaining vertices than candidates: nc < beam)
             STAMP(a, g, 10, tclk);  // residual step: priorities, ranks, candidates
             // The completions - for each candidate: the residual graph minus its closed neighbourhood, searched greedily by
             // weight (or by priority), total weight of what joins - run CONCURRENTLY, one wave per candidate, each on its own
@@ -1827,13 +1840,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
                 constexpr int kWaves = BLOCK / 64;
                 const unsigned short* kbase = (a.options & DGCN_RESIDUAL_COMPLETE_BY_PRIORITY) ? gkey : wkey;
-                unsigned long long* S = reinterpret_cast<unsigned long long*>(cid + 64);  // [ng], behind pick / cand / cid
-                volatile unsigned long long* Sv = S;
+                volatile unsigned long long* Sv = S;  // (every vertex's word was written with its ranks, in front of the barrier above)
                 volatile unsigned* Slo = reinterpret_cast<volatile unsigned*>(S);  // word 2 v: the masks of vertex v
-                const unsigned full = (1u << nc) - 1u;
                 const unsigned myrank = tv < ng ? (unsigned)kbase[tv] : 0u;
-                if (tv < ng) S[tv] = ((unsigned long long)myrank << 32) | full;
-                __syncthreads();
                 for (int i = wave; i < nc; i += kWaves) {  // instance i: candidate i and its neighbours do not take part
                     const int c = cid[i];
                     const int crs = (int)(rinfo[c] & 0xffff), cre = crs + (int)(rinfo[c] >> 16);
@@ -1876,8 +1885,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     double tot = 0.0;
                     for (int v = lane; v < ng; v += 64)
                         if ((Slo[2 * v] >> (16 + i)) & 1u) tot += wl[v];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                    tot = wave_sum_f64(tot);
                     if (lane == 0) cand[i] = wl[cid[i]] + tot;
                 }
             } else {
@@ -1938,9 +1946,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 // walk of thread 0 over the list.
                 const int lane = threadIdx.x & 63;
                 const double cv = lane < nc ? cand[lane] : -1.0 / 0.0;
-                double mx = cv;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+                const double mx = wave_max_f64(cv);
                 const unsigned long long tied = __ballot(lane < nc && fabs(cv - mx) <= 1e-12 * fabs(mx));
                 picked = cid[tied ? __ffsll((long long)tied) - 1 : 0];
             }

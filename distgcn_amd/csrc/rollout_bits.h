@@ -11,10 +11,11 @@
 // other waves are seen as they happen.  The result does not depend on the schedule: the set a greedy search by a total order
 // returns is the unique independent set in which every excluded vertex has a member neighbour ahead of it (heuristics.py:13-35
 // sweeps sequentially, :77-116 in synchronous rounds - same set; tests hold this path against k_lgs's rounds and the oracle).
-// Totals: an instance per wave, lane-strided partial sums and a shuffle tree - a fixed order, equal run to run; they differ
+// Totals: an instance per wave, lane-strided partial sums, then DPP moves inside the rows and v_readlane across them - a fixed order, equal run to run; they differ
 // from k_lgs's tree by rounding only and the pick compares them with the reference's 1e-12 relative tolerance.
 #pragma once
 #include "common.h"
+#include "wave_reduce.h"
 
 namespace dgcn {
 
@@ -123,17 +124,14 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
         double part = 0.0;
         for (int v = lane; v < ng; v += 64)
             if ((S[v] >> (16 + i)) & 1u) part += r.weights[r.n0 + v];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        part = wave_sum_f64(part);  // (DPP inside the rows, v_readlane across them: a fixed order)
         if (lane == 0) tot[i] = r.weights[r.n0 + r.cidl[i]] + part;
     }
     __syncthreads();
     // ---- the pick: the largest total; totals within 1e-12 relative count as tied and the first candidate wins
     // (np.isclose(cand, cand.max(), rtol=1e-12, atol=0), as in fused.hip and k_res_pick)
     double cand = lane < nc ? tot[lane] : -1.0 / 0.0;
-    double mx = cand;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    const double mx = wave_max_f64(cand);
     const unsigned long long tied = __ballot(lane < nc && fabs(cand - mx) <= 1e-12 * fabs(mx));
     const int c = tied ? r.cidl[__ffsll((long long)tied) - 1] : -1;  // (every wave computes the same pick; none: a total that is not finite)
     if (c < 0) {
