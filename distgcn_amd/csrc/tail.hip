@@ -19,6 +19,7 @@
 // (tests/test_gpu_tail.py: every solver, final states against the per-step kernels and the oracle).
 #include "common.h"
 #include "tile_ops.h"
+#include "wave_reduce.h"
 
 namespace dgcn {
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kTailBlock) void k_tail(TailArgs a) {
     __shared__ unsigned long long adjs[kTailMax];
     __shared__ float zl[kTailMax];
     __shared__ uint8_t st[kTailMax];
-    __shared__ int wsum[kTailBlock / 64], s_pick;
+    __shared__ int wsum[kTailBlock / 64];
     // read once per launch, used by every step: d^-1/2 of the degrees a 64-vertex graph can have, the last layer's two weight
     // columns, the first layer's weights while they are few (the reference's models: one input feature)
     __shared__ double dtab[kTailMax];
@@ -476,17 +477,14 @@ __global__ __launch_bounds__(kTailBlock) void k_tail(TailArgs a) {
                 if (lane == 0) cand[i] = wc + tot;
             }
             __syncthreads();
-            if (tid == 0) {
-                // np.isclose(cand, cand.max(), rtol=1e-12, atol=0): the first candidate within tolerance wins
-                double mx = cand[0];
-                for (int i = 1; i < nc; ++i) mx = fmax(mx, cand[i]);
-                int best = 0;
-                for (int i = 0; i < nc; ++i)
-                    if (fabs(cand[i] - mx) <= 1e-12 * fabs(mx)) { best = i; break; }
-                s_pick = best;
-            }
-            __syncthreads();
-            const int c = __ffsll((long long)__ballot(al && gk == s_pick)) - 1;
+            // np.isclose(cand, cand.max(), rtol=1e-12, atol=0): the first candidate within tolerance wins (none within it - totals
+            // that are not finite -: the first).  A lane per candidate, every wave for itself (no walk of thread 0 over the list,
+            // no barrier behind it).
+            const double cvl = lane < nc ? cand[lane] : -1.0 / 0.0;
+            const double cmx = wave_max_f64(cvl);
+            const unsigned long long tied = __ballot(lane < nc && fabs(cvl - cmx) <= 1e-12 * fabs(cmx));
+            const int best = tied ? __ffsll((long long)tied) - 1 : 0;
+            const int c = __ffsll((long long)__ballot(al && gk == best)) - 1;
             const unsigned long long adjc = __shfl(myadj, c);
             if (wave == 0) {
                 if (lane == c) st[lane] = 1;
