@@ -971,7 +971,7 @@ def main(argv=None, workload_factory=None):
         c5_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(tpath):  # FETCH_SIZE / WRITE_SIZE passes of a whole search, averaged over its k_fused launches (the empty ones included)
-            c5_traffic = json.load(open(tpath)).get("fused_residual|%dx%d|l%d" % (args.graphs, args.nodes, args.layers), {}).get("hbm_bytes_per_launch")
+            c5_traffic = json.load(open(tpath)).get("%s|%dx%d|l%d" % (step_family, args.graphs, args.nodes, args.layers), {}).get("hbm_bytes_per_launch")
         step_kernel = {"fused_residual": "k_fused<residual graph>", "big_residual": "k_big / k_big2<residual graph> (any-size path)",
                        "wide_residual": "k_wide1 residual mode (any-size path, one- and two-layer models)"}[step_family]
         roofline = {"kernel": "%s (one launch = forward on every residual graph + %d greedy completions + pick)" % (step_kernel, args.beam),

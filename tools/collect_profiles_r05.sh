@@ -40,6 +40,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_mc900_$c" -- python3 $R/tools/run_general.py mc900 5 20 256 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_c3_$c" -- python3 $R/tools/run_fused.py er 5 20 500 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_c5_$c" -- python3 $R/tools/run_iterative.py --n 500 --p 0.02 --graphs 64 --layers 20 --host 0 --only rollout > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_mc900roll_$c" -- python3 $R/tools/run_iterative.py --family mc --n 900 --p 0.03 --graphs 64 --layers 20 --host 0 --only rollout > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_mc900rolll1_$c" -- python3 $R/tools/run_iterative.py --family mc --n 900 --p 0.03 --graphs 64 --layers 1 --host 0 --only rollout > /dev/null 2>&1
 done
 cd "$R"
 bash tools/collect_pmc.sh > /dev/null 2>&1

@@ -53,7 +53,8 @@ traffic = json.load(open(tpath)) if os.path.isfile(tpath) else {}
 notes = []
 for kind, match, key in (("er500", "k_big", "big_solve|256x500|l20"), ("mc900", "k_big", "big_solve|mc256x900|l20"),
                          ("mc1500", "k_big2", "big_solve|mc256x1500|l20"), ("mc900l1", "k_wide1", "wide_solve|mc256x900|l1"),
-                         ("c3", "k_fused", "fused_solve|500x200|l20"), ("c5", "k_fused", "fused_residual|64x500|l20")):
+                         ("c3", "k_fused", "fused_solve|500x200|l20"), ("c5", "k_fused", "fused_residual|64x500|l20"),
+                         ("mc900roll", "k_big", "big_residual|64x900|l20"), ("mc900rolll1", "k_wide1", "wide_residual|64x900|l1")):
     fe, wr = pmc(kind, "FETCH_SIZE", match), pmc(kind, "WRITE_SIZE", match)
     if fe is None or wr is None:
         continue
