@@ -75,6 +75,18 @@ extern "C" const char* dgcn_last_error(void) { return g_err; }
 extern "C" int dgcn_timing_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_tmu);
     g_timing = on != 0;
+    // The event pairs of the first few thousand launches exist before anything is timed: created on demand they would be
+    // created INSIDE the caller's timed region (two hipEventCreate per launch, once per slot), which is not the workload's time.
+    constexpr size_t kPrimed = 4096;
+    if (g_timing && g_slots.size() < kPrimed) {
+        g_slots.reserve(kPrimed);
+        while (g_slots.size() < kPrimed) {
+            TimingSlot t;
+            t.used = false;
+            if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) break;  // (on demand then, as before)
+            g_slots.push_back(t);
+        }
+    }
     return DGCN_OK;
 }
 
