@@ -939,6 +939,19 @@ def main(argv=None, workload_factory=None):
 
     fam_ms = wl.kernel_times()
     uninstrumented = None
+    if not isinstance(wl, RolloutWorkload) and not use_dist and world == 1:
+        # (the same K steps once more with plain launches: what the HIP event pair round every launch of the timed region costs)
+        wl.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            res_u = step()
+        drain()
+        wl.sync()
+        dt_u = time.perf_counter() - t1
+        wl.check(res_u)
+        uninstrumented = {"ms_per_step": 1e3 * dt_u / max(args.steps, 1), "graphs_per_s": wl.job_graphs * args.steps / dt_u, "steps": args.steps,
+                          "note": "the K steps of the timed region again, WITHOUT the per-launch HIP event pairs (hipExtLaunchKernelGGL) that "
+                                  "`value` / `ms_per_step` include; not `value`: the contract's figure is the instrumented one"}
     if isinstance(wl, RolloutWorkload) and not use_dist:
         # The timed region above brackets EVERY launch with a HIP event pair (the contract's live kernel times).  A search is ~140
         # launches, half of them a few microseconds long (the tail's probes, the empty launches behind the end of a search), and an

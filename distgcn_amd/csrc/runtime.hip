@@ -39,11 +39,14 @@ static std::mutex g_tmu;
 static std::vector<TimingSlot> g_slots;
 static size_t g_live = 0;  // slots [0, g_live) carry a recorded pair
 static bool g_timing = false;
+static int g_timing_every = 1;      // every N-th launch carries an event pair (dgcn_timing_enable(N)); 1 = every launch
+static unsigned long long g_timing_seq = 0;
 
 TimedLaunch::TimedLaunch(const char* family, hipStream_t s) : slot(-1), stream(s) {
     (void)hipGetLastError();  // drop any stale error so check_launch() reports this launch only
     if (!g_timing) return;
     std::lock_guard<std::mutex> lk(g_tmu);
+    if (g_timing_every > 1 && (g_timing_seq++ % (unsigned long long)g_timing_every) != 0) return;  // (a sample: this launch goes out plain)
     if (g_live == g_slots.size()) {
         TimingSlot t;
         t.used = false;
@@ -75,6 +78,8 @@ extern "C" const char* dgcn_last_error(void) { return g_err; }
 extern "C" int dgcn_timing_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_tmu);
     g_timing = on != 0;
+    g_timing_every = on > 1 ? on : 1;
+    g_timing_seq = 0;
     // The event pairs of the first few thousand launches exist before anything is timed: created on demand they would be
     // created INSIDE the caller's timed region (two hipEventCreate per launch, once per slot), which is not the workload's time.
     constexpr size_t kPrimed = 4096;

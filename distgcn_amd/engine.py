@@ -7,6 +7,7 @@ return host data.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -500,7 +501,8 @@ class Engine:
         """on=True clears earlier records and starts recording; on=False stops (records stay readable)."""
         if on:
             self.lib.dgcn_timing_reset()
-        self.lib.dgcn_timing_enable(1 if on else 0)
+        # (DGCN_TIMING_EVERY=N: an event pair round every N-th launch only - an A/B switch for what the instrumentation costs)
+        self.lib.dgcn_timing_enable(int(os.environ.get("DGCN_TIMING_EVERY", "1")) if on else 0)
 
     def timing_read(self, family: str):
         ms = C.c_double(0.0)
