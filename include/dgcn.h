@@ -397,7 +397,8 @@ int dgcn_host_solver_result(DgcnHostSolver* solver, int32_t slot, const uint8_t*
                             int32_t* status_bits, int32_t* num_nodes, int32_t* num_graphs);
 
 /* ---- per-kernel timing for bench.py's roofline line (HIP events on the launch stream) ---------
- * enable(1) makes every launch of the named kernel families record an event pair;
+ * enable(1) makes every launch of the named kernel families record an event pair (enable(N), N > 1: every N-th launch only -
+ * an A/B switch for what the instrumentation costs; 0: off);
  * read() synchronises those events and returns the summed milliseconds and launch count. */
 int dgcn_timing_enable(int32_t on);
 int dgcn_timing_reset(void);
