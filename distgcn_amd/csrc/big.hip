@@ -739,7 +739,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void
                     r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
                     r.extra = extra;
                     r.max_nodes = a.max_nodes;
-                    r.col_idx = a.acol; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                    r.wl = a.by_priority ? nullptr : pr; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
                     rollout_bits<BLOCK>(r, g);
                     return;
                 }

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                     r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
                     r.extra = reinterpret_cast<unsigned char*>(cidl + kCandMaxBeam);
                     r.max_nodes = a.max_nodes;
-                    r.col_idx = a.acol; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                    r.wl = a.by_priority ? nullptr : pr; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
                     rollout_bits<kB2Block>(r, g);
                     return;
                 }

@@ -1,8 +1,9 @@
 // The rollout's candidates: the first `beam` undecided vertices of a graph under (priority desc, index asc) - the stable argsort of
 // -gcn_wts (mwis_gdpg_call.py:624-626) - selected by ONE workgroup that holds the graph's priorities in registers.  Shared by
 // general.hip (k_res_cand: a launch of its own), big.hip and wide.hip (the end of a residual step's launch).
-// Every wave selects ITS first `beam` (`beam` rounds of: best of my vertices not taken yet, wave-wide argmax - inside a row of
-// sixteen lanes by DPP moves, across the four rows by v_readlane -, its owner marks it taken); the waves' lists - sorted, and
+// Every wave selects ITS first `beam` (a vertex per lane: each lane counts the wave's vertices ahead of it, one v_readlane pass;
+// several vertices per lane: `beam` rounds of: best of my vertices not taken yet, wave-wide argmax - inside a row of sixteen
+// lanes by DPP moves, across the four rows by v_readlane -, its owner marks it taken); the waves' lists - sorted, and
 // together they contain the graph's first `beam` - are ranked against each other: a candidate's rank is the sum over the lists of
 // the entries ahead of it, a binary search per list, all threads on (candidate, list) pairs.
 #pragma once
@@ -43,6 +44,22 @@ __device__ __forceinline__ void cand_select(const double (&pv)[kCandPer], unsign
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < kW * kCandMaxBeam; c += BLOCK) rank[c] = 0;
     int mine_n = 0;
+    if (per == 1) {
+        // A vertex per lane (graphs of up to BLOCK vertices): a lane's place in its wave's list is the number of the wave's
+        // undecided vertices ahead of it - one pass over them with v_readlane, ~7 instructions each - instead of `beam` rounds
+        // of a wave-wide argmax (~120 instructions each; sixteen waves on four SIMDs: 13 of a one-layer rollout step's 47 us).
+        const bool on = (have & 1u) != 0u;
+        const double p = pv[0];
+        const unsigned long long onmask = __ballot(on);
+        int ahead = 0;
+        for (unsigned long long m = onmask; m; m &= m - 1ull) {  // (uniform)
+            const int l = __ffsll((long long)m) - 1;
+            const double op = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(p), l), __builtin_amdgcn_readlane(__double2loint(p), l));
+            ahead += (op > p) || (op == p && l < lane);
+        }
+        if (on && ahead < beam) { wl_p[wave * kCandMaxBeam + ahead] = p; wl_v[wave * kCandMaxBeam + ahead] = (int)threadIdx.x; }
+        mine_n = min(__popcll(onmask), beam);
+    } else
     for (int it = 0; it < beam; ++it) {
         double bp = 0.0;
         int bv = -1;

@@ -21,9 +21,9 @@ namespace dgcn {
 
 constexpr int kRollBeam = 16;  // instances per state word: rollouts with more candidates take general.hip's launches
 
-// LDS the caller sets aside: S u32[max_nodes] | ahead counts u16[max_nodes] | totals f64[16]
+// LDS the caller sets aside: S u32[max_nodes] | ahead counts u16[max_nodes] | start masks u16[max_nodes] | totals f64[16]
 __host__ __device__ constexpr size_t roll_lds_bytes(int max_nodes) {
-    return (((size_t)max_nodes * 4 + 15) & ~(size_t)15) + (((size_t)max_nodes * 2 + 15) & ~(size_t)15) + kRollBeam * 8;
+    return (((size_t)max_nodes * 4 + 15) & ~(size_t)15) + 2 * (((size_t)max_nodes * 2 + 15) & ~(size_t)15) + kRollBeam * 8;
 }
 
 struct RollArgs {
@@ -31,12 +31,12 @@ struct RollArgs {
     const double* key;        // LDS [ng]: the completions' order key of every undecided vertex (weight, or priority)
     const uint8_t* st;        // LDS [ng]: the running state, 0 = undecided
     const int* rol;           // LDS [ng + 1]: row bounds as entry numbers of the batch
-    uint16_t* cl;             // LDS: the graph's local column ids, entry j at cl[j - e0]; REWRITTEN (ahead lists at the row fronts)
+    uint16_t* cl;             // LDS: the graph's local column ids (>= ng: not a vertex), entry j at cl[j - e0]; REWRITTEN (ahead lists at the row fronts)
     const int32_t* cidl;      // LDS [>= beam]: the candidates, the list ends at the first negative entry
     int beam;                 // <= kRollBeam
     unsigned char* extra;     // LDS, roll_lds_bytes(max_nodes), 16-byte aligned
     int max_nodes;
-    const int32_t* col_idx;   // global: the batch's columns (a candidate's whole neighbourhood is read from here)
+    const double* wl;         // LDS [ng] or null: the vertices' weights when the caller has them there (key, when the order is by weight)
     const double* weights;    // global, never null (the entry point refuses a rollout without weights)
     uint8_t* state;           // global, in / out
     int32_t* rounds;          // global [num_graphs] or null
@@ -49,7 +49,7 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
     constexpr int kW = BLOCK / 64;
     unsigned* S = reinterpret_cast<unsigned*>(r.extra);
     uint16_t* acnt = reinterpret_cast<uint16_t*>(r.extra + (((size_t)r.max_nodes * 4 + 15) & ~(size_t)15));
-    double* tot = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(acnt) + (((size_t)r.max_nodes * 2 + 15) & ~(size_t)15));
+    double* tot = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(acnt) + 2 * (((size_t)r.max_nodes * 2 + 15) & ~(size_t)15));
     volatile unsigned* Sv = S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ng = r.ng, e0 = r.e0;
@@ -63,11 +63,26 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
         return;
     }
     const unsigned full = (1u << nc) - 1u;
-    // ---- every undecided vertex: alive in every instance; its neighbours ahead of it, compacted to the front of its row
+    uint16_t* m0 = acnt + (((size_t)r.max_nodes * 2 + 15) & ~(size_t)15) / 2;  // [ng] who is alive in which instance when the instances start
+    // (no global memory from here to the state bytes at the end: a candidate's neighbourhood is read from the column lists in LDS
+    // while they are still whole, the picked candidate's is recovered from the start masks)
+    // ---- every undecided vertex: alive in every instance
+    for (int v = threadIdx.x; v < ng; v += BLOCK) S[v] = r.st[v] == 0 ? full : 0u;
+    __syncthreads();
+    // ---- instance i: candidate i and its neighbours do not take part
+    for (int i = wave; i < nc; i += kW) {
+        const int c = r.cidl[i];
+        for (int j = r.rol[c] - e0 + lane; j < r.rol[c + 1] - e0; j += 64) {
+            const int u = r.cl[j];
+            if (u < ng) atomicAnd(&S[u], ~(1u << i));
+        }
+        if (lane == 0) atomicAnd(&S[c], ~(1u << i));
+    }
+    __syncthreads();
+    // ---- the start masks; every undecided vertex's neighbours ahead of it, compacted to the front of its row
     for (int v = threadIdx.x; v < ng; v += BLOCK) {
         int cnt = 0;
-        const bool on = r.st[v] == 0;
-        if (on) {
+        if (r.st[v] == 0) {
             const double kv = r.key[v];
             const int rs = r.rol[v] - e0, re = r.rol[v + 1] - e0;
             for (int j = rs; j < re; ++j) {
@@ -79,17 +94,7 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
             }
         }
         acnt[v] = (uint16_t)cnt;
-        S[v] = on ? full : 0u;
-    }
-    __syncthreads();
-    // ---- instance i: candidate i and its neighbours do not take part
-    for (int i = wave; i < nc; i += kW) {
-        const int c = r.cidl[i];
-        for (int j = r.rol[c] + lane; j < r.rol[c + 1]; j += 64) {
-            const int u = r.col_idx[j] - r.n0;
-            if ((unsigned)u < (unsigned)ng) atomicAnd(&S[u], ~(1u << i));
-        }
-        if (lane == 0) atomicAnd(&S[c], ~(1u << i));
+        m0[v] = (uint16_t)S[v];
     }
     __syncthreads();
     // ---- the instances: a vertex dies where an ahead-neighbour has joined, joins where none of them is alive any more
@@ -122,10 +127,18 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
     // ---- totals: instance i on wave i, a fixed order
     for (int i = wave; i < nc; i += kW) {
         double part = 0.0;
-        for (int v = lane; v < ng; v += 64)
-            if ((S[v] >> (16 + i)) & 1u) part += r.weights[r.n0 + v];
+        if (r.wl) {
+            for (int v = lane; v < ng; v += 64)
+                if ((S[v] >> (16 + i)) & 1u) part += r.wl[v];
+        } else {
+            // (every weight asked for, joined or not: a load inside the branch is a global round trip per pass of the loop)
+            for (int v = lane; v < ng; v += 64) {
+                const double w = r.weights[r.n0 + v];
+                part += ((S[v] >> (16 + i)) & 1u) ? w : 0.0;
+            }
+        }
         part = wave_sum_f64(part);  // (DPP inside the rows, v_readlane across them: a fixed order)
-        if (lane == 0) tot[i] = r.weights[r.n0 + r.cidl[i]] + part;
+        if (lane == 0) tot[i] = (r.wl ? r.wl[r.cidl[i]] : r.weights[r.n0 + r.cidl[i]]) + part;
     }
     __syncthreads();
     // ---- the pick: the largest total; totals within 1e-12 relative count as tied and the first candidate wins
@@ -133,22 +146,21 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
     double cand = lane < nc ? tot[lane] : -1.0 / 0.0;
     const double mx = wave_max_f64(cand);
     const unsigned long long tied = __ballot(lane < nc && fabs(cand - mx) <= 1e-12 * fabs(mx));
-    const int c = tied ? r.cidl[__ffsll((long long)tied) - 1] : -1;  // (every wave computes the same pick; none: a total that is not finite)
-    if (c < 0) {
+    const int best = tied ? __ffsll((long long)tied) - 1 : -1;  // (every wave computes the same pick; none: a total that is not finite)
+    if (best < 0) {
         if (threadIdx.x == 0) {
             if (r.rounds) r.rounds[g] = 0;
             if (r.totals) r.totals[g] = 0.0;
         }
         return;
     }
-    for (int j = r.rol[c] + (int)threadIdx.x; j < r.rol[c + 1]; j += BLOCK) {
-        const int u = r.col_idx[j] - r.n0;
-        if ((unsigned)u < (unsigned)ng && u != c && r.st[u] == 0) r.state[r.n0 + u] = 2;
-    }
+    // the picked candidate joins, its undecided neighbours leave: exactly the vertices instance `best` started without
+    const int c = r.cidl[best];
+    for (int v = threadIdx.x; v < ng; v += BLOCK)
+        if (r.st[v] == 0 && !((m0[v] >> best) & 1u)) r.state[r.n0 + v] = v == c ? 1 : 2;
     if (threadIdx.x == 0) {
-        r.state[r.n0 + c] = 1;
         if (r.rounds) r.rounds[g] = 1;
-        if (r.totals) r.totals[g] = r.weights[r.n0 + c];
+        if (r.totals) r.totals[g] = r.wl ? r.wl[c] : r.weights[r.n0 + c];
     }
 }
 

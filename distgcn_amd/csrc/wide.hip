@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
                 r.key = pr; r.st = st; r.rol = rol; r.cl = cl; r.cidl = cidl; r.beam = a.beam;
                 r.extra = reinterpret_cast<unsigned char*>(cidl + kCandMaxBeam);
                 r.max_nodes = a.max_nodes;
-                r.col_idx = a.col_idx; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
+                r.wl = a.by_priority ? nullptr : pr; r.weights = a.weights; r.state = a.state; r.rounds = a.rounds; r.totals = a.totals;
                 rollout_bits<kWideBlock>(r, g);
                 return;
             }
