@@ -905,6 +905,13 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         la.rounds = a.rounds;
         la.max_rounds = resid ? a.max_rounds : 0;
         la.init_state = resid ? a.state : nullptr;  // (only its being there matters: the rounds count who takes part from `st`)
+        if (cols_lds && la.max_rounds <= 0 && a.ahead_rounds) {
+            // a whole search: the rounds on ahead lists (lgs_rounds.h; the counts in the reduction array's space, free until the totals)
+            static_assert(kB2Block * 4 >= kB2MaxNodes, "a 16-bit count per vertex in the reduction array");
+            const int rounds = lgs_rounds_ahead<kB2Block, true>(ng, e0, pr, st, nw, cl, rol, reinterpret_cast<uint16_t*>(red), acc64);
+            if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+            __syncthreads();
+        } else
         if (cols_lds) lgs_rounds<1, false, true, kB2Block, true>(la, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
         else lgs_rounds<1, false, false, kB2Block, true>(la, g, n0, ng, e0, pr, st, nw, nullptr, acc64, rol);
         {
@@ -984,6 +991,11 @@ static size_t b2_lds_bytes(int max_nodes, int* cnt_off, int* perm_off, int* stag
     *tab_off = (int)off;
     off += kB2MaxTiles * 8;
     return off;
+}
+
+static int b2_ahead_rounds() {  // DGCN_WIDE_AHEAD=0: lgs_rounds.h's three-phase rounds (the tests' witness)
+    static const bool off = [] { const char* e = getenv("DGCN_WIDE_AHEAD"); return e && atoi(e) == 0; }();
+    return off ? 0 : 1;
 }
 
 static size_t b2_lgs_lds(int max_nodes) {
@@ -1131,7 +1143,7 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
     a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
     a.front = 1;
     a.scores = scores;
-    a.do_lgs = 1; a.predict_mwis = predict_mwis;
+    a.do_lgs = 1; a.predict_mwis = predict_mwis; a.ahead_rounds = b2_ahead_rounds();
     a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
     big2_fill_model(a, m, x_const);
     const size_t lds = std::max(b2_lds_bytes(a.max_nodes, &a.lds_cnt_off, &a.lds_perm_off, &a.lds_stage_off, &a.lds_tab_off),
@@ -1162,7 +1174,7 @@ int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     a.max_nodes = (std::max(b->max_nodes, 16) + 15) & ~15;
     a.front = 1;
     a.scores = scores;
-    a.do_lgs = 1; a.predict_mwis = predict_mwis;
+    a.do_lgs = 1; a.predict_mwis = predict_mwis; a.ahead_rounds = b2_ahead_rounds();
     a.weights = weights; a.state = state; a.rounds = rounds; a.totals = totals;
     a.residual = 1; a.greedy_mode = greedy_mode; a.max_rounds = max_rounds;
     a.progress = progress; a.tail_word = tail_word; a.tail_tag = tail_tag;

@@ -101,6 +101,13 @@ __global__ __launch_bounds__(BLOCK) void k_lgs(LgsArgs a) {
         for (int v = threadIdx.x; v < ng; v += BLOCK) a.state[n0 + v] = a.init_state ? a.init_state[n0 + v] : (uint8_t)0;
         return;
     }
+    if (!STATS && cols_lds && a.max_rounds <= 0 && ng <= 4096 && a.ahead_rounds) {
+        // a whole search without statistics: the rounds on ahead lists (lgs_rounds.h: two walks over state / flag bytes per round;
+        // the 16-bit counts in the reduction array's space, free until the totals)
+        const int rounds = lgs_rounds_ahead<BLOCK, false>(ng, e0, pr, st, nw, cl, rol, reinterpret_cast<uint16_t*>(red), acc64);
+        if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
+        __syncthreads();
+    } else
     if (cols_lds) lgs_rounds<LPV, STATS, true, BLOCK>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
     else lgs_rounds<LPV, STATS, false, BLOCK>(a, g, n0, ng, e0, pr, st, nw, cl, acc64, rol);
 
@@ -268,6 +275,10 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     a.prio_stride = prio_stride;
     a.active = active;
     a.cand = cand;
+    {
+        static const bool ahead_off = [] { const char* e = getenv("DGCN_WIDE_AHEAD"); return e && atoi(e) == 0; }();
+        a.ahead_rounds = ahead_off ? 0 : 1;
+    }
     // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
     // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
     int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;

@@ -35,6 +35,7 @@ struct LgsArgs {
     // (mwis_gdpg_call.py:629-643; a negative entry: no such candidate, the instance has nothing to search) - the mask is made in
     // LDS, no launch writes it out first
     const int32_t* cand;
+    int ahead_rounds;           // whole searches without statistics: lgs_rounds_ahead below (0: lgs_rounds; DGCN_WIDE_AHEAD=0)
 };
 
 template <bool COLS_LDS>
@@ -273,5 +274,91 @@ __device__ __forceinline__ int lgs_mask_rounds(int tv, bool my, const unsigned l
     __syncthreads();  // every state byte is written
     return rounds;
 }
+
+// The local greedy search's synchronous rounds (heuristics.py:77-116) on AHEAD lists: every undecided vertex's neighbours ahead of
+// it in the order (priority desc, index asc) are compacted once to the front of its row of the 16-bit column lists in LDS; a round
+// is then two walks over those - who has no undecided vertex ahead wins; who has a winner ahead (a winner beats all its undecided
+// neighbours, so it is ahead of each of them) leaves - on state / flag BYTES only, half the entries, two barriers (lgs_rounds.h
+// walks every neighbour with a float64 compare in the first phase, lets the winners push to all theirs in a second, updates in a
+// third: three).  Same winners in the same rounds, hence the same states and the same round count.  A whole search only
+// (max_rounds <= 0): a single round does not pay for the lists.  acnt: [ng] 16-bit counts; cl: WRITABLE column lists in LDS.
+// No statistics (the _count / _stats / _overhead variants keep lgs_rounds).
+// FLAG_OR: the votes through acc64[3] and acc64[2] in turn instead of __syncthreads_count (see lgs_rounds).
+template <int BLOCK, bool FLAG_OR>
+__device__ __forceinline__ int lgs_vote(bool mine, unsigned long long* acc64, int which) {
+    if constexpr (FLAG_OR) {
+        // (two words in turn: a thread may set this vote's word while a slower one still reads the last vote's)
+        unsigned long long* word = acc64 + 2 + (which & 1);
+        if (threadIdx.x == 0) acc64[2 + ((which + 1) & 1)] = 0;  // (the other word: everybody has read it - it decided to come here)
+        if (mine) *word = 1;
+        __syncthreads();
+        return *word != 0 ? 1 : 0;
+    } else {
+        return __syncthreads_count(mine) ? 1 : 0;
+    }
+}
+template <int BLOCK, bool FLAG_OR>
+__device__ __forceinline__ int lgs_rounds_ahead(int ng, int e0, const double* pr, uint8_t* st, uint8_t* nw, uint16_t* cl, const int* rol,
+                                                uint16_t* acnt, unsigned long long* acc64) {
+    if (FLAG_OR) {
+        if (threadIdx.x == 0) { acc64[2] = 0; acc64[3] = 0; }
+        __syncthreads();
+    }
+    int votes = 0;
+    int mine = 0;
+    for (int v = threadIdx.x; v < ng; v += BLOCK) {
+        int cnt = 0;
+        if (st[v] == 0) {
+            ++mine;
+            const double pv = pr[v];
+            const int rs = rol[v] - e0, re = rol[v + 1] - e0;
+            for (int j = rs; j < re; ++j) {
+                const int u = cl[j];
+                if (u < ng && u != v && st[u] == 0) {
+                    const double pu = pr[u];
+                    if (pu > pv || (pu == pv && u < v)) cl[rs + cnt++] = (uint16_t)u;  // (behind the read position: same thread, in order)
+                }
+            }
+        }
+        acnt[v] = (uint16_t)cnt;
+        nw[v] = 0;
+    }
+    int remaining = lgs_vote<BLOCK, FLAG_OR>(mine > 0, acc64, votes++);
+    int rounds = 0;
+    while (remaining) {
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {  // who wins this round: nobody undecided ahead
+            if (st[v] != 0) continue;
+            const int rs = rol[v] - e0, n = acnt[v];
+            bool lost = false;
+            int k = 0;
+            for (; k + 3 < n; k += 4) {
+                const int u0 = cl[rs + k], u1 = cl[rs + k + 1], u2 = cl[rs + k + 2], u3 = cl[rs + k + 3];
+                lost |= (st[u0] == 0) | (st[u1] == 0) | (st[u2] == 0) | (st[u3] == 0);
+            }
+            for (; k < n; ++k) lost |= st[cl[rs + k]] == 0;
+            nw[v] = lost ? 0 : 1;
+        }
+        __syncthreads();
+        mine = 0;
+        for (int v = threadIdx.x; v < ng; v += BLOCK) {  // winners join; who has a winner ahead leaves
+            if (st[v] != 0) continue;
+            if (nw[v]) { st[v] = 1; continue; }
+            const int rs = rol[v] - e0, n = acnt[v];
+            bool killed = false;
+            int k = 0;
+            for (; k + 3 < n; k += 4) {
+                const int u0 = cl[rs + k], u1 = cl[rs + k + 1], u2 = cl[rs + k + 2], u3 = cl[rs + k + 3];
+                killed |= (nw[u0] | nw[u1] | nw[u2] | nw[u3]) != 0;
+            }
+            for (; k < n; ++k) killed |= nw[cl[rs + k]] != 0;
+            // (a flag left from an earlier round belongs to a member: whoever is adjacent to one has left in that round)
+            if (killed) st[v] = 2; else ++mine;
+        }
+        remaining = lgs_vote<BLOCK, FLAG_OR>(mine > 0, acc64, votes++);
+        ++rounds;
+    }
+    return rounds;
+}
+
 
 }  // namespace dgcn

@@ -68,7 +68,7 @@ struct WideArgs {
     int32_t* active;           // mode 2: [num_graphs] out
     int32_t* cid;              // mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
     int32_t beam;
-    int32_t ahead_rounds;      // mode 0, whole searches: the rounds on ahead lists (wide_rounds_ahead); 0: lgs_rounds.h's (DGCN_WIDE_AHEAD=0)
+    int32_t ahead_rounds;      // mode 0, whole searches: the rounds on ahead lists (lgs_rounds_ahead, lgs_rounds.h); 0: lgs_rounds.h's (DGCN_WIDE_AHEAD=0)
     int32_t roll_off;          // mode 2: byte offset of the LDS the completions and the pick run in (rollout_bits.h) - the whole step in
     int32_t by_priority;       // this launch; 0: general.hip's k_lgs / k_res_pick launches follow.  by_priority: the completions' order
     unsigned long long* tail_word;
@@ -303,71 +303,6 @@ __device__ __forceinline__ void wide_scores2(const WideArgs& a, int n0, int ng, 
     }
 }
 
-// The local greedy search's synchronous rounds (heuristics.py:77-116) on AHEAD lists: every undecided vertex's neighbours ahead of
-// it in the order (priority desc, index asc) are compacted once to the front of its row of the 16-bit column lists in LDS; a round
-// is then two walks over those - who has no undecided vertex ahead wins; who has a winner ahead (a winner beats all its undecided
-// neighbours, so it is ahead of each of them) leaves - on state / flag BYTES only, half the entries, two barriers (lgs_rounds.h
-// walks every neighbour with a float64 compare in the first phase, lets the winners push to all theirs in a second, updates in a
-// third: three).  Same winners in the same rounds, hence the same states and the same round count.  A whole search only
-// (max_rounds <= 0): a single round does not pay for the lists.  acnt: [ng] 16-bit counts.
-template <int BLOCK>
-__device__ __forceinline__ int wide_rounds_ahead(int ng, int e0, const double* pr, uint8_t* st, uint8_t* nw, uint16_t* cl, const int* rol,
-                                                 uint16_t* acnt) {
-    int mine = 0;
-    for (int v = threadIdx.x; v < ng; v += BLOCK) {
-        int cnt = 0;
-        if (st[v] == 0) {
-            ++mine;
-            const double pv = pr[v];
-            const int rs = rol[v] - e0, re = rol[v + 1] - e0;
-            for (int j = rs; j < re; ++j) {
-                const int u = cl[j];
-                if (u < ng && u != v && st[u] == 0) {
-                    const double pu = pr[u];
-                    if (pu > pv || (pu == pv && u < v)) cl[rs + cnt++] = (uint16_t)u;  // (behind the read position: same thread, in order)
-                }
-            }
-        }
-        acnt[v] = (uint16_t)cnt;
-        nw[v] = 0;
-    }
-    int remaining = __syncthreads_count(mine > 0);
-    int rounds = 0;
-    while (remaining) {
-        for (int v = threadIdx.x; v < ng; v += BLOCK) {  // who wins this round: nobody undecided ahead
-            if (st[v] != 0) continue;
-            const int rs = rol[v] - e0, n = acnt[v];
-            bool lost = false;
-            int k = 0;
-            for (; k + 3 < n; k += 4) {
-                const int u0 = cl[rs + k], u1 = cl[rs + k + 1], u2 = cl[rs + k + 2], u3 = cl[rs + k + 3];
-                lost |= (st[u0] == 0) | (st[u1] == 0) | (st[u2] == 0) | (st[u3] == 0);
-            }
-            for (; k < n; ++k) lost |= st[cl[rs + k]] == 0;
-            nw[v] = lost ? 0 : 1;
-        }
-        __syncthreads();
-        mine = 0;
-        for (int v = threadIdx.x; v < ng; v += BLOCK) {  // winners join; who has a winner ahead leaves
-            if (st[v] != 0) continue;
-            if (nw[v]) { st[v] = 1; continue; }
-            const int rs = rol[v] - e0, n = acnt[v];
-            bool killed = false;
-            int k = 0;
-            for (; k + 3 < n; k += 4) {
-                const int u0 = cl[rs + k], u1 = cl[rs + k + 1], u2 = cl[rs + k + 2], u3 = cl[rs + k + 3];
-                killed |= (nw[u0] | nw[u1] | nw[u2] | nw[u3]) != 0;
-            }
-            for (; k < n; ++k) killed |= nw[cl[rs + k]] != 0;
-            // (a flag left from an earlier round belongs to a member: whoever is adjacent to one has left in that round)
-            if (killed) st[v] = 2; else ++mine;
-        }
-        remaining = __syncthreads_count(mine > 0);
-        ++rounds;
-    }
-    return rounds;
-}
-
 template <int LPV>
 __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_raw[];
@@ -588,7 +523,7 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
     la.init_state = a.residual ? a.state : nullptr;
     if (cols_lds && a.max_rounds <= 0 && ng <= 4096 && a.ahead_rounds) {
         // (a whole search on graphs whose ahead counts fit the reduction array's space, free until the totals)
-        const int rounds = wide_rounds_ahead<kWideBlock>(ng, e0, pr, st, nw, cl, rol, reinterpret_cast<uint16_t*>(red));
+        const int rounds = lgs_rounds_ahead<kWideBlock, false>(ng, e0, pr, st, nw, cl, rol, reinterpret_cast<uint16_t*>(red), acc64);
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
         __syncthreads();
     } else
