@@ -535,3 +535,29 @@ def test_rollout_in_one_launch_agrees_with_the_instance_launches(engine, tmp_pat
         else:
             assert np.array_equal(a[k], b[k]), k
     assert a["rollout_steps"][0] > 50 and not (a["rollout_state"] == 0).any()
+
+
+@pytest.mark.parametrize("num_layer,nodes", [(1, 900), (2, 900), (5, 1500)])
+def test_rounds_on_ahead_lists_agree_with_the_three_phase_rounds(engine, tmp_path, num_layer, nodes):
+    """Witness for lgs_rounds_ahead (lgs_rounds.h): the plain solve (states, round counts, totals, score bits) and complete
+    searches of k_wide1 / k_big2 by a child process as built - a whole search's rounds as two walks over every vertex's AHEAD
+    list - and by one with DGCN_WIDE_AHEAD=0 - lgs_rounds' three phases over all neighbours: the same bytes."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_wide_witness.py")
+    files = {}
+    for tag, val in (("ahead", "1"), ("rounds", "0")):
+        files[tag] = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ, DGCN_WIDE_AHEAD=val)
+        subprocess.run([sys.executable, script, files[tag], str(num_layer), str(nodes)], check=True, env=env, timeout=600)
+    a, b = np.load(files["ahead"]), np.load(files["rounds"])
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k.endswith("_scores"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        elif k.endswith("_totals"):
+            assert np.allclose(a[k], b[k], rtol=1e-12), k
+        else:
+            assert np.array_equal(a[k], b[k]), k
+    assert a["plain_rounds"].min() >= 2
