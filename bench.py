@@ -683,14 +683,14 @@ def e2e_probe(args, wl, reference_state):
     import ctypes
     from distgcn_amd import _lib
     ci = _lib.DgcnCompactInfo()
-    compact = os.environ.get("DGCN_HOST_COMPACT", "1") != "0" and _lib.load().dgcn_pack_compact_layout(ctypes.byref(info), ctypes.byref(ci)) == 0
+    compact = _lib.get_option("host_compact") != 0 and _lib.load().dgcn_pack_compact_layout(ctypes.byref(info), ctypes.byref(ci)) == 0
     h2d = int(ci.total_bytes) if compact else int(info.total_bytes)
     return {"value": hb.num_graphs * batches / dt, "unit": "graphs/s", "ms_per_batch": dt / batches * 1e3, "batches": batches,
             "path": "dgcn_host_solver_submit / _result: per-graph CSR arrays in host memory -> native packing into pinned memory (%s) -> "
                     "1 H2D copy (%.1f MB) -> %sdgcn_solve_batch -> 1 D2H copy (%.0f KB) -> membership + totals + rounds in host memory; "
                     "3 batches in flight"
                     % ("compact transfer format: 16-bit local column ids + degrees" if compact else "block-diagonal int32 CSR", h2d / 1e6,
-                       ("(one-layer models: k_expand_compact -> ) " if args.layers == 1 or os.environ.get("DGCN_HOST_COMPACT_DIRECT", "1") == "0"
+                       ("(one-layer models: k_expand_compact -> ) " if args.layers == 1 or _lib.get_option("host_compact_direct") == 0
                         else "(read as it is by the fused kernel's image build) ") if compact else "", (hb.num_nodes + 12 * hb.num_graphs) / 1e3),
             "h2d_bytes_per_batch": h2d, "pack_ms_per_batch_ordinary_format": pack_ms, "results_equal_resident_step": same,
             "runs_graphs_per_s": [round(hb.num_graphs * batches / t) for t in runs]}

@@ -28,7 +28,8 @@ SYMBOLS = (
     "dgcn_version", "dgcn_last_error", "dgcn_pack_measure", "dgcn_pack_batch", "dgcn_pack_compact_layout", "dgcn_pack_compact_batch", "dgcn_expand_compact_batch", "dgcn_supports_batch", "dgcn_supports2_count_batch", "dgcn_supports2_fill_batch", "dgcn_spmm_split", "dgcn_set_cluster", "dgcn_get_cluster", "dgcn_spmm_batch", "dgcn_spmm_f64acc_batch", "dgcn_transform_batch", "dgcn_transform_f64acc_batch",
     "dgcn_gcn_forward_workspace", "dgcn_gcn_forward_batch", "dgcn_gcn_forward_poly_batch", "dgcn_head_dual_batch", "dgcn_head_skip_batch", "dgcn_argmax_batch", "dgcn_lgs_batch", "dgcn_margin_risk_batch", "dgcn_lgs_masked_batch", "dgcn_solve_supported", "dgcn_solve_path", "dgcn_set_general", "dgcn_get_general", "dgcn_solve_workspace", "dgcn_solve_batch", "dgcn_solve_residual_batch",
     "dgcn_host_solver_create", "dgcn_host_solver_destroy", "dgcn_host_solver_submit", "dgcn_host_solver_result",
-    "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read",
+    "dgcn_timing_enable", "dgcn_timing_reset", "dgcn_timing_read", "dgcn_timing_sampling",
+    "dgcn_set_option", "dgcn_get_option", "dgcn_option_count", "dgcn_option_name",
 )
 
 
@@ -174,8 +175,62 @@ def load():
     lib.dgcn_timing_reset.restype = C.c_int
     lib.dgcn_timing_read.restype = C.c_int
     lib.dgcn_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.dgcn_timing_sampling.restype = i32
+    lib.dgcn_timing_sampling.argtypes = []
+    lib.dgcn_set_option.restype = C.c_int
+    lib.dgcn_set_option.argtypes = [C.c_char_p, C.c_int64]
+    lib.dgcn_get_option.restype = C.c_int
+    lib.dgcn_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+    lib.dgcn_option_count.restype = C.c_int
+    lib.dgcn_option_count.argtypes = []
+    lib.dgcn_option_name.restype = C.c_char_p
+    lib.dgcn_option_name.argtypes = [i32, C.POINTER(C.c_int64)]
     _lib = lib
+    # DGCN_OPTIONS="key=value,key=value": the library itself reads no environment variable (include/dgcn.h "Options");
+    # this is the host layer's convenience for child processes of tests and A/B scripts.
+    for kv in filter(None, (os.environ.get("DGCN_OPTIONS") or "").split(",")):
+        key, _, val = kv.partition("=")
+        set_option(key.strip(), int(val, 0))
     return lib
+
+
+def set_option(key: str, value: int) -> None:
+    """dgcn_set_option: one of the library's process-wide path switches (include/dgcn.h "Options")."""
+    check(load().dgcn_set_option(key.encode(), int(value)), "dgcn_set_option(%s)" % key)
+
+
+def get_option(key: str) -> int:
+    out = C.c_int64(0)
+    check(load().dgcn_get_option(key.encode(), C.byref(out)), "dgcn_get_option(%s)" % key)
+    return int(out.value)
+
+
+def option_defaults() -> dict:
+    """{key: default} of every option the library knows."""
+    lib, out = load(), {}
+    for i in range(lib.dgcn_option_count()):
+        d = C.c_int64(0)
+        name = lib.dgcn_option_name(i, C.byref(d))
+        out[name.decode()] = int(d.value)
+    return out
+
+
+class options:
+    """Context manager: set options for a block, put the previous values back afterwards (tests, A/B scripts)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc: int, what: str = "libdgcn") -> None:

@@ -39,7 +39,7 @@
 
 namespace dgcn {
 
-// (DGCN_DIAG builds, DGCN_BIG_DIAG_REC=1: every walk reads its tile's FIRST record group again and again - wrong results, a timing
+// (DGCN_DIAG builds, option "diag_flags" bit 0: every walk reads its tile's FIRST record group again and again - wrong results, a timing
 // experiment: what would the launch cost if the support's records did not have to stream from the L2 / MALL?)
 #ifdef DGCN_DIAG
 #define BIG_DIAG_SAME_GROUP (a.lgs_cols_lds == 2)
@@ -843,21 +843,16 @@ int transform_f64acc_dispatch(const float* H, int ldh, float h_const, int rows, 
 
 static size_t b256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// tuning / A-B switches of this file, read from the environment ONCE per process (never per launch: getenv next to the
-// packer's worker threads is a data race in glibc): DGCN_BIG=0 (no k_big: layer by layer), DGCN_BIG_SOLVE=0 (supports and
-// greedy search in launches of their own), DGCN_BIG_BLOCK=512|1024, DGCN_BIG_TILES=4
-static int env_once(const char* name) {  // the value, or -1 when the variable is not set
-    const char* e = getenv(name);
-    return e ? atoi(e) : -1;
-}
-static int big_env_enabled() { static const int v = env_once("DGCN_BIG"); return v; }
-static int big_env_solve() { static const int v = env_once("DGCN_BIG_SOLVE"); return v; }
-static int big_env_block() { static const int v = env_once("DGCN_BIG_BLOCK"); return v; }
-static int big_env_tiles() { static const int v = env_once("DGCN_BIG_TILES"); return v; }
+// tuning / A-B switches of this file (dgcn_set_option, options.h): "big" = 0 (no k_big: layer by layer), "big_solve" = 0
+// (supports and greedy search in launches of their own), "big_block" = 512 | 1024, "big_tiles" = 4
+static int big_env_enabled() { return opt(OPT_BIG); }
+static int big_env_solve() { return opt(OPT_BIG_SOLVE); }
+static int big_env_block() { return opt(OPT_BIG_BLOCK); }
+static int big_env_tiles() { return opt(OPT_BIG_TILES); }
 
 // threads per workgroup: a wave keeps at most kBigTilesPerWave tiles in registers, so 512 threads reach 512 vertices - and two
 // such workgroups share a CU (the recipe of fused.hip's C3 launch: one's barriers and round trips under the other's work);
-// larger graphs get the CU to themselves.  DGCN_BIG_BLOCK=512|1024 overrides (tuning / tests).
+// larger graphs get the CU to themselves.  option "big_block" = 512 | 1024 overrides (tuning / tests).
 static int big_block(int max_nodes) {
     int block = max_nodes <= 16 * kBigTilesPerWave * 8 ? 512 : 1024;
     const int want = big_env_block();
@@ -1016,9 +1011,9 @@ static int big_launch_b(BigArgs& a, int B, size_t lds, const char* family, hipSt
 static int big_launch(BigArgs& a, int B, size_t lds, int block, const char* family, hipStream_t s) {
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big: %zu bytes of LDS", lds);
 #ifdef DGCN_DIAG
-    a.stamps = getenv("DGCN_BIG_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_BIG_STAMPS"), nullptr, 0) : nullptr;
+    a.stamps = reinterpret_cast<unsigned long long*>(static_cast<uintptr_t>(opt64(OPT_DIAG_STAMPS)));
     a.num_graphs_diag = B;
-    if (getenv("DGCN_BIG_DIAG_REC") && atoi(getenv("DGCN_BIG_DIAG_REC"))) a.lgs_cols_lds = 2;
+    if (opt(OPT_DIAG_FLAGS) & 1) a.lgs_cols_lds = 2;
 #endif
     // two tiles per wave where that covers the largest graph: the freed registers keep a second group of records in flight
     const bool two = a.max_nodes <= 16 * 2 * (block / 64) && big_env_tiles() != 4;
@@ -1062,10 +1057,10 @@ int big_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
 // from the adjacency and the running state, every layer, priorities, and the greedy step - local rounds (solve_mwis_dit,
 // mwis_gdpg_call.py:278-318) or the central pick (solve_mwis_cit, :343-384); for the rollouts (:596-659) the priorities are
 // left in `prio` and the candidates, all completions and the pick run at the end of the same launch (cand_select.h, rollout_bits.h; beyond sixteen
-// candidates general.hip's k_lgs / k_res_pick launches follow instead).  DGCN_BIG_RESIDUAL=0: the compaction
+// candidates general.hip's k_lgs / k_res_pick launches follow instead).  option "big_residual" = 0: the compaction
 // launches + k_big + k_lgs instead (tests compare the two).
 int big_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options) {
-    static const int on = env_once("DGCN_BIG_RESIDUAL");
+    const int on = opt(OPT_BIG_RESIDUAL);
     if (on == 0 || feature_mode != 0 || (options & DGCN_RESIDUAL_SCORES_GIVEN)) return 0;
     return big_solve_takes(b, m, X);
 }
@@ -1106,8 +1101,8 @@ int big_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tabl
     if (a.cid && whole_step) {
         // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do and row bounds, instance
         // words, the selection's scratch and the graph's 16-bit columns fit behind the search's state bytes.
-        // DGCN_ROLLOUT_BITS=0: general.hip's launches.
-        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        // option "rollout_bits" = 0: general.hip's launches.
+        const bool bits_off = opt(OPT_ROLLOUT_BITS) == 0;
         const size_t pad = (size_t)((a.max_nodes + 15) & ~15);
         const size_t roll = (big_lgs_base(a.max_nodes) + (size_t)a.max_nodes * 8 + 1024 * 8 + (4 + 3 * 16) * 8 + pad + 15) & ~(size_t)15;
         const size_t need = roll + (size_t)((a.max_nodes + 1 + 3) & ~3) * 4 + kCandMaxBeam * 4 + roll_lds_bytes(a.max_nodes) +

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + kB2Block);  // [4]
         int* rol = reinterpret_cast<int*>(acc64 + 4);                                   // [max_nodes + 1]
         uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
-        uint8_t* nw = st + ((a.max_nodes + 15) & ~15);
+        uint8_t* nw = st + ((a.max_nodes + 16) & ~15);  // (st has a slot [ng]: where a column outside the graph points, state 3)
         // the graph's columns as 16-bit local ids in what is left of the Z1h space, when they fit: the rounds then read LDS only
         uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
         const int cl_cap = (int)(((size_t)a.max_nodes * 64 - (size_t)(reinterpret_cast<unsigned char*>(cl) - b2_lds)) / 2);
@@ -799,10 +799,13 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
                 for (int i = 0; i < 4; ++i) c[i] = (base + i * kB2Block < e1) ? a.acol[base + i * kB2Block] : n0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (base + i * kB2Block < e1) cl[base + i * kB2Block - e0] = (uint16_t)(c[i] - n0);
+                    if (base + i * kB2Block < e1) {  // (a column outside the graph - BAD_COLUMN is reported with the batch - reads the sentinel)
+                        const int u = c[i] - n0;
+                        cl[base + i * kB2Block - e0] = (uint16_t)((unsigned)u < (unsigned)ng ? u : ng);
+                    }
             }
         }
-        if (threadIdx.x == 0) acc64[3] = 0;
+        if (threadIdx.x == 0) { acc64[3] = 0; st[ng] = 3; nw[ng] = 0; }
         __syncthreads();
         if (bad) acc64[3] = 1;
         __syncthreads();
@@ -973,8 +976,8 @@ int transform_dispatch(const float* H, int ldh, float h_const, int rows, int cin
 
 static size_t b2_256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// DGCN_BIG2 (read once per process): 0 = no k_big2 (layer by layer), 1 = also for graphs k_big / k_fused would take (tests)
-static int b2_env() { static const int v = [] { const char* e = getenv("DGCN_BIG2"); return e ? atoi(e) : -1; }(); return v; }
+// option "big2": 0 = no k_big2 (layer by layer), 1 = also for graphs k_big / k_fused would take (tests)
+static int b2_env() { return opt(OPT_BIG2); }
 
 static int b2_rec_cap(const DgcnBatch* b) {
     return ((b->max_graph_edges + b->max_nodes + 2 + 16 + 15) & ~15) + ((20 * b->max_nodes + 448 + 15) & ~15);
@@ -993,8 +996,8 @@ static size_t b2_lds_bytes(int max_nodes, int* cnt_off, int* perm_off, int* stag
     return off;
 }
 
-static int b2_ahead_rounds() {  // DGCN_WIDE_AHEAD=0: lgs_rounds.h's three-phase rounds (the tests' witness)
-    static const bool off = [] { const char* e = getenv("DGCN_WIDE_AHEAD"); return e && atoi(e) == 0; }();
+static int b2_ahead_rounds() {  // option "wide_ahead" = 0: lgs_rounds.h's three-phase rounds (the tests' witness)
+    const bool off = opt(OPT_WIDE_AHEAD) == 0;
     return off ? 0 : 1;
 }
 
@@ -1060,7 +1063,7 @@ static int big2_launch_t(BigArgs& a, int B, size_t lds, const char* family, hipS
 static int big2_launch(BigArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 160 * 1024) return fail(DGCN_ERR_UNSUPPORTED, "k_big2: %zu bytes of LDS", lds);
 #ifdef DGCN_DIAG
-    a.stamps = getenv("DGCN_BIG_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_BIG_STAMPS"), nullptr, 0) : nullptr;
+    a.stamps = reinterpret_cast<unsigned long long*>(static_cast<uintptr_t>(opt64(OPT_DIAG_STAMPS)));
 #endif
     const int per_wave = (a.max_nodes / 16 + kB2Waves - 1) / kB2Waves;  // tiles a wave owns at most
     if (a.residual) {
@@ -1126,7 +1129,7 @@ int big2_forward(const DgcnBatch* b, const DgcnCsr* lap, const DgcnModel* m, con
 
 // 1 = dgcn_solve_batch's whole path in ONE launch: adjacency in, set out (constant input features, k_big2's shapes)
 int big2_solve_takes(const DgcnBatch* b, const DgcnModel* m, const float* X) {
-    static const int solve = [] { const char* e = getenv("DGCN_BIG_SOLVE"); return e ? atoi(e) : -1; }();
+    const int solve = opt(OPT_BIG_SOLVE);
     if (solve == 0) return 0;
     return !X && big2_takes(b, m) && m->layers_host[0].in_dim <= 64;
 }
@@ -1152,9 +1155,9 @@ int big2_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table,
 }
 
 // One step of dgcn_solve_residual_batch in ONE launch on k_big2's shapes (constant input features): big.hip's big_residual for
-// graphs of 977 .. 1 920 vertices.  DGCN_BIG_RESIDUAL=0: the compaction launches + k_big2 + k_lgs instead.
+// graphs of 977 .. 1 920 vertices.  option "big_residual" = 0: the compaction launches + k_big2 + k_lgs instead.
 int big2_residual_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode, int32_t options) {
-    static const int on = [] { const char* e = getenv("DGCN_BIG_RESIDUAL"); return e ? atoi(e) : -1; }();
+    const int on = opt(OPT_BIG_RESIDUAL);
     if (on == 0 || feature_mode != 0 || (options & DGCN_RESIDUAL_SCORES_GIVEN)) return 0;
     return big2_solve_takes(b, m, X);
 }
@@ -1189,8 +1192,8 @@ int big2_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     if (a.cid && whole_step) {
         // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do, every graph's columns fit
         // what the search has left of the Z1 space, and the instances' state words fit behind the selection's scratch.
-        // DGCN_ROLLOUT_BITS=0: general.hip's launches.
-        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        // option "rollout_bits" = 0: general.hip's launches.
+        const bool bits_off = opt(OPT_ROLLOUT_BITS) == 0;
         const size_t cl_off = b2_lgs_lds(a.max_nodes) - 16;  // (where the search puts the 16-bit columns)
         const size_t cl_cap = (size_t)a.max_nodes * 64 > cl_off ? ((size_t)a.max_nodes * 64 - cl_off) / 2 : 0;
         const size_t roll = ((size_t)a.lds_stage_off + cand_scratch_bytes(kB2Block) + 15) & ~(size_t)15;

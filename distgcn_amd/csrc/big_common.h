@@ -56,7 +56,7 @@ struct BigArgs {
     double* prio_out;      // greedy_mode 2: [num_nodes] out
     int32_t* cid;          // greedy_mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
     int32_t beam;
-    int32_t ahead_rounds;  // whole searches of k_big2: the rounds on ahead lists (lgs_rounds_ahead); 0: lgs_rounds (DGCN_WIDE_AHEAD=0)
+    int32_t ahead_rounds;  // whole searches of k_big2: the rounds on ahead lists (lgs_rounds_ahead); 0: lgs_rounds (option "wide_ahead" = 0)
     int32_t roll_off;      // greedy_mode 2: byte offset of the LDS the completions and the pick run in (rollout_bits.h: the whole
     int32_t by_priority;   // step in this launch); 0: general.hip's k_lgs / k_res_pick launches follow.  by_priority: their order
     unsigned long long* tail_word;

@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "../../include/dgcn.h"
+#include "options.h"
 
 namespace dgcn {
 
@@ -27,6 +28,7 @@ struct TimedLaunch {
     hipEvent_t start_ev() const;
     hipEvent_t stop_ev() const;
     int slot;
+    int device;  // whose slot table the pair belongs to (runtime.hip)
     hipStream_t stream;
 };
 

@@ -81,7 +81,6 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
-    int32_t stagger;           // tuning experiment (DGCN_FUSED_STAGGER, units of 1 024 cycles): the second workgroup of a CU starts this much later
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
@@ -104,7 +103,7 @@ struct FusedArgs {
     uint32_t done_target;
     // cluster variant (k_fused<false, *, 512, true>): `cluster` workgroups per graph, see cluster_pull_rows()
     int32_t cluster;
-    int32_t cluster_inject;  // test hook (DGCN_FUSED_CLUSTER_INJECT_FAULT=1): report a placement fault although there is none
+    int32_t cluster_inject;  // test hook (option "test_cluster_fault"): report a placement fault although there is none
     unsigned long long nonce;  // this launch's value of the progress words ("my exchange rows are marked unwritten")
     int32_t num_graphs;
     float* xz;          // [num_graphs][3][max_nodes][32] Z1 rows on their way between the workgroups of a graph (slice l % 3)
@@ -1108,12 +1107,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     // 4 955 vs 4 182 hundred cycles per graph), and the launch ends with the slower one.
     const bool second = (blockIdx.x >> 8) & 1;
     if (a.prio_second && second) __builtin_amdgcn_s_setprio(1);
-    // (round-4 review: start the second co-resident workgroup half a layer late, so that one's MFMA phase meets the other's
-    // LDS phase by construction rather than by drift.  Measured in round 5, DESIGN 9: no gain - off unless the variable is set.
-    // The stricter form - the two workgroups taking turns in the aggregation phase through a word in global memory - costs 23 %:
-    // profiles/r05_fused_turns.txt.)
-    if (a.stagger > 0 && second)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    // (Measured in round 5, DESIGN_HISTORY: starting the second co-resident workgroup half a layer late gains nothing; the two
+    // workgroups taking turns in the aggregation phase through a word in global memory costs 23 %: profiles/r05_fused_turns.txt.)
     unsigned long long tclk = 0;
 #ifdef DGCN_DIAG
     tclk = __builtin_amdgcn_s_memtime();
@@ -1947,7 +1942,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 const int lane = threadIdx.x & 63;
                 const double cv = lane < nc ? cand[lane] : -1.0 / 0.0;
                 const double mx = wave_max_f64(cv);
-                const unsigned long long tied = __ballot(lane < nc && fabs(cv - mx) <= 1e-12 * fabs(mx));
+                // (cv == mx: equal infinities are close for np.isclose, fabs(inf - inf) is NaN; nobody close - NaN totals -: the first)
+                const unsigned long long tied = __ballot(lane < nc && (cv == mx || fabs(cv - mx) <= 1e-12 * fabs(mx)));
                 picked = cid[tied ? __ffsll((long long)tied) - 1 : 0];
             }
             const int c = picked;
@@ -2281,29 +2277,15 @@ static int fused_order_bits(const DgcnBatch* b) {
 // worth it?  only the host-side shape is known here: more graphs than CUs (several rounds) and a largest graph well above the mean
 static bool fused_wants_order(const DgcnBatch* b) {
     if (fused_order_bits(b) < 0) return false;
-    if (const char* e = getenv("DGCN_FUSED_ORDER")) return atoi(e) != 0 && b->num_graphs > 1;
+    if (const int want = opt(OPT_FUSED_ORDER); want >= 0) return want != 0 && b->num_graphs > 1;
     if (b->num_graphs <= device_cus()) return false;
     return (double)b->max_nodes * b->num_graphs > 1.25 * (double)b->num_nodes ||
            (double)b->max_graph_edges * b->num_graphs > 1.25 * (double)b->num_edges;
 }
 
-// The variant's switch: the environment variable DGCN_FUSED_CLUSTER read ONCE (first use), afterwards only
-// dgcn_set_cluster() - called by the fault path of host_solver.hip and by the Python engine when a launch reports
-// DGCN_FAULT_CLUSTER - changes it.  (It used to be setenv() + getenv() per launch: a data race in glibc next to the
-// packing threads, and a mutation every child process inherited.)
-static std::atomic<int> g_cluster_setting{-2};  // -2: not read yet
-int cluster_setting() {
-    int v = g_cluster_setting.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("DGCN_FUSED_CLUSTER");
-        int fresh = e ? atoi(e) : -1;
-        if (fresh < -1) fresh = -1;
-        int expect = -2;
-        g_cluster_setting.compare_exchange_strong(expect, fresh, std::memory_order_relaxed);
-        v = g_cluster_setting.load(std::memory_order_relaxed);
-    }
-    return v;
-}
+// The variant's switch: option "fused_cluster" (dgcn_set_option; dgcn_set_cluster is the older name of the same word) - set by
+// the fault path of host_solver.hip and by the Python engine when a launch reports DGCN_FAULT_CLUSTER.
+int cluster_setting() { return max(opt(OPT_FUSED_CLUSTER), -1); }
 
 // How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
 // Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
@@ -2333,7 +2315,7 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // (five to eight tiles per workgroup run - a tile per wave, two row sets per wave - but do not pay: 64 graphs of N = 500,
     // K = 4: 183.6 against 177.1 us per residual step, 244.6 against 210.4 per rollout step in round 4.  Round 5, with the
     // step's ranking and completions short: complete searches of those 64 graphs 10.7 -> 10.3 ms (rollout), 8.2 -> 7.7 ms (cit)
-    // with DGCN_FUSED_CLUSTER=4 - 4 .. 7 %, for a launch that needs EVERY CU of the device free at once (64 x 4 workgroups,
+    // with option "fused_cluster" = 4 - 4 .. 7 %, for a launch that needs EVERY CU of the device free at once (64 x 4 workgroups,
     // one per CU: anything else running makes a workgroup wait for its peers until the spin bound reports a fault).
     // Forced K only: tools/runs/r05_gpu39.sh)
     if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers || (blocks + K - 1) / K > 4)) return 0;
@@ -2441,7 +2423,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     }
     a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
     if (a->cluster > 1) a->order = nullptr;
-    a->cluster_inject = getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT") ? atoi(getenv("DGCN_FUSED_CLUSTER_INJECT_FAULT")) : 0;
+    a->cluster_inject = opt(OPT_TEST_CLUSTER_FAULT);
     if (a->cluster > 1) {
         const size_t need = fused_cluster_bytes(b, a->cluster);
         if (!workspace || workspace_bytes < need)
@@ -2494,14 +2476,14 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
 }
 
 // An image above half the LDS leaves its graph alone on a CU: 16 waves instead of 8 then work on it
-// (at 128 VGPRs both fit the register file exactly).  DGCN_FUSED_BLOCK=512|1024 overrides (tuning / tests).
+// (at 128 VGPRs both fit the register file exactly).  Option "fused_block" = 512 | 1024 overrides (tuning / tests).
 template <bool MASKED, bool GVALS, bool COMPACT = false>
 static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     // ... and so does every graph of a batch that has no more graphs than the device has CUs
     const int ncu = device_cus();
     bool big = ((lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
-    if (const char* e = getenv("DGCN_FUSED_BLOCK"))
-        big = (atoi(e) == kFusedBlockBig && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
+    if (const int want = opt(OPT_FUSED_BLOCK); want > 0)
+        big = (want == kFusedBlockBig && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
     return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig, COMPACT>(a, B, lds, family, s)
                : fused_launch_b<MASKED, GVALS, kFusedBlock, COMPACT>(a, B, lds, family, s);
 }
@@ -2525,15 +2507,11 @@ static int fused_launch_cluster(FusedArgs& a, int B, size_t lds, const char* fam
 }
 
 static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s, bool masked, bool gvals) {
-    a.prio_gather = getenv("DGCN_FUSED_PRIOG") ? atoi(getenv("DGCN_FUSED_PRIOG")) : 1;
-    a.prio_second = getenv("DGCN_FUSED_PRIO") ? atoi(getenv("DGCN_FUSED_PRIO")) : 5;
-    a.stagger = getenv("DGCN_FUSED_STAGGER") ? atoi(getenv("DGCN_FUSED_STAGGER")) : 0;
+    a.prio_gather = 1;  // (rounds 2 - 5 swept both: 1 / 5 of every 8 layers; the knobs are gone)
+    a.prio_second = 5;
 #ifdef DGCN_DIAG
-    if (getenv("DGCN_FUSED_LDS_PAD")) lds += (size_t)atoi(getenv("DGCN_FUSED_LDS_PAD"));  // force 1 workgroup per CU
-#endif
-#ifdef DGCN_DIAG
-    a.diag = getenv("DGCN_FUSED_DIAG") ? atoi(getenv("DGCN_FUSED_DIAG")) : 0;
-    a.stamps = getenv("DGCN_FUSED_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_FUSED_STAMPS"), nullptr, 0) : nullptr;
+    a.diag = opt(OPT_DIAG_FLAGS);
+    a.stamps = reinterpret_cast<unsigned long long*>(static_cast<uintptr_t>(opt64(OPT_DIAG_STAMPS)));
 #endif
     const bool compact = a.ccol != nullptr;
     if (compact && masked) return fail(DGCN_ERR_ARG, "k_fused: the residual-graph variant takes expanded batches only");
@@ -2611,7 +2589,7 @@ constexpr size_t kTailWordBytes = 512;  // what dgcn_solve_workspace adds behind
 
 using namespace dgcn;
 
-extern "C" void dgcn_set_cluster(int32_t setting) { g_cluster_setting.store(setting < -1 ? -1 : setting, std::memory_order_relaxed); }
+extern "C" void dgcn_set_cluster(int32_t setting) { opt_store(OPT_FUSED_CLUSTER, setting < -1 ? -1 : setting); }
 extern "C" int32_t dgcn_get_cluster(void) { return cluster_setting(); }
 
 extern "C" int dgcn_solve_supported(const DgcnBatch* b, const DgcnModel* m) {

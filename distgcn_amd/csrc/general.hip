@@ -475,9 +475,11 @@ __global__ __launch_bounds__(64) void k_res_pick(ResArgs a) {
         double mx = counts ? cand : -1.0 / 0.0;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
-        const unsigned long long tied = __ballot(counts && fabs(cand - mx) <= 1e-12 * fabs(mx));
+        // (cand == mx: equal infinities are close for np.isclose; nobody close - NaN totals -: the first candidate, as in
+        // fused.hip / tail.hip / rollout_bits.h: a step that picks nobody would leave the graph active for ever)
+        const unsigned long long tied = __ballot(counts && (cand == mx || fabs(cand - mx) <= 1e-12 * fabs(mx)));
         int c = -1;
-        if (nc > 0 && tied) c = __shfl(my, __ffsll((long long)tied) - 1);
+        if (nc > 0) c = __shfl(my, tied ? __ffsll((long long)tied) - 1 : 0);
         if (threadIdx.x == 0) {
             s_c = c;
             if (a.rounds) a.rounds[g] = c < 0 ? 0 : 1;
@@ -567,7 +569,7 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     float* sc = scores ? scores : w.take<float>(n);
     const size_t fbytes = layered_bytes(b, m);
     char* fws = w.take<char>(fbytes);
-    const bool big2 = big2_takes(b, m) != 0;  // (977 .. 1 920 vertices; with DGCN_BIG2=1 every shape k_big takes too)
+    const bool big2 = big2_takes(b, m) != 0;  // (977 .. 1 920 vertices; with option "big2" = 1 every shape k_big takes too)
     const bool big = !big2 && big_takes(b, m) != 0;
     char* bws = big ? w.take<char>(big_workspace(b, m)) : big2 ? w.take<char>(big2_workspace(b, m)) : nullptr;
     if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
@@ -721,20 +723,10 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
 }
 
 // -1 = automatic (the fused kernels where a graph's image fits, this path otherwise), 1 = always this path (tests, A/B runs)
-static std::atomic<int> g_general_setting{-2};
-int general_setting() {
-    int v = g_general_setting.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* env = getenv("DGCN_GENERAL");
-        int fresh = env ? (atoi(env) > 0 ? 1 : -1) : -1;
-        int expect = -2;
-        g_general_setting.compare_exchange_strong(expect, fresh, std::memory_order_relaxed);
-        v = g_general_setting.load(std::memory_order_relaxed);
-    }
-    return v;
-}
+// (option "general"; dgcn_set_general is the older name of the same word)
+int general_setting() { return opt(OPT_GENERAL) > 0 ? 1 : -1; }
 
 }  // namespace dgcn
 
-extern "C" void dgcn_set_general(int32_t setting) { dgcn::g_general_setting.store(setting > 0 ? 1 : -1, std::memory_order_relaxed); }
+extern "C" void dgcn_set_general(int32_t setting) { dgcn::opt_store(dgcn::OPT_GENERAL, setting > 0 ? 1 : -1); }
 extern "C" int32_t dgcn_get_general(void) { return dgcn::general_setting(); }

@@ -280,15 +280,14 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
     // A batch of up to a few dozen graphs: the kernel reads it where the packer left it and writes its results where the
     // caller reads them (pinned memory is device-addressable) - two copy commands and the gaps around them cost more
     // than PCIe round trips inside the kernel (tools/direct_probe.py: 101 vs 110 us for one N = 200 graph, 150 vs 170 us
-    // for 63 of them = 1.1 MB; DGCN_HOST_DIRECT_BYTES: largest batch handled this way, default 2 MB).
-    const char* direct_env = getenv("DGCN_HOST_DIRECT_BYTES");
-    const size_t direct_bytes = direct_env ? (size_t)atol(direct_env) : (size_t)(2 << 20);
+    // for 63 of them = 1.1 MB; option "host_direct_bytes": largest batch handled this way, default 2 MB).
+    const int64_t direct_opt = opt64(OPT_HOST_DIRECT_BYTES);
+    const size_t direct_bytes = direct_opt >= 0 ? (size_t)direct_opt : (size_t)(2 << 20);
     const bool direct = (size_t)info.total_bytes <= direct_bytes;
     // Larger batches cross PCIe in the compact form (16-bit local column ids, 16-bit degrees: about half the bytes, and
     // half the bytes for the packer to write) and are expanded on the device (expand.hip); graphs beyond 65 535 vertices,
-    // and every batch when DGCN_HOST_COMPACT=0, go as the ordinary block-diagonal CSR.
-    const char* compact_env = getenv("DGCN_HOST_COMPACT");
-    const bool compact_ok = !compact_env || atoi(compact_env) != 0;
+    // and every batch when option "host_compact" is 0, go as the ordinary block-diagonal CSR.
+    const bool compact_ok = opt(OPT_HOST_COMPACT) != 0;
     DgcnCompactInfo ci = {};
     bool compact = false;
     if (!direct && compact_ok && info.num_nodes > 0 && compact_layout(&info, &ci) == 0) {
@@ -322,8 +321,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
         b.graph_ptr = reinterpret_cast<const int32_t*>(base + ci.off_graph_ptr);
         b.row_ptr = nullptr;
         b.col_idx = nullptr;
-        const char* direct_env = getenv("DGCN_HOST_COMPACT_DIRECT");  // (per call, like DGCN_HOST_COMPACT: tests switch it)
-        const bool direct_ok = !direct_env || atoi(direct_env) != 0;
+        const bool direct_ok = opt(OPT_HOST_COMPACT_DIRECT) != 0;  // (tests switch it)
         s.compact_direct = direct_ok && !h->lgs_only && dgcn_solve_path(&b, &h->model) == 1 && !shallow_takes(&b, &h->model);
         if (s.compact_direct) {
             s.c_edge = reinterpret_cast<const int32_t*>(base + ci.off_edge_ptr);
@@ -359,7 +357,7 @@ int dgcn_host_solver_submit(DgcnHostSolver* h, const void* const* indptr_host, c
             int32_t* st = reinterpret_cast<int32_t*>(static_cast<char*>(s.out_host) + s.off_status);
             st[0] = 0;
             // the latency path (one slot, nothing else to do meanwhile): a completion word written by the kernel itself
-            static const bool word_ok = [] { const char* e = getenv("DGCN_HOST_DONE_WORD"); return !e || atoi(e) != 0; }();
+            const bool word_ok = opt(OPT_HOST_DONE_WORD) != 0;
             if (word_ok && h->slots.size() == 1 && !h->lgs_only && s.done_count && dgcn_solve_path(&b, &h->model) == 1) {
                 s.done_base += (uint32_t)info.num_graphs;
                 s.done_total = s.done_base;

@@ -186,7 +186,7 @@ int layer32_dispatch(const DgcnCsr* S, const int32_t* graph_ptr, int B, int max_
     if (!graph_ptr || B <= 0 || max_nodes <= 0 || max_nodes > 512) return 0;
     if (ctot_next != 64 && ctot_next != 2) return 0;
     if (spmm_split_for(kLC) != 1) return 0;  // a tuning override of the summation order: keep the plain kernels
-    if (getenv("DGCN_LAYER_FUSE") && atoi(getenv("DGCN_LAYER_FUSE")) == 0) return 0;
+    if (opt(OPT_LAYER_FUSE) == 0) return 0;
     if (((uintptr_t)Z | (uintptr_t)Zn | (uintptr_t)(bias ? bias : Z)) % 16) return 0;
     constexpr size_t kLdsMax = 150 * 1024;
     const int rows32 = (max_nodes + 31) & ~31;

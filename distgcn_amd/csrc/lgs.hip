@@ -275,10 +275,7 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     a.prio_stride = prio_stride;
     a.active = active;
     a.cand = cand;
-    {
-        static const bool ahead_off = [] { const char* e = getenv("DGCN_WIDE_AHEAD"); return e && atoi(e) == 0; }();
-        a.ahead_rounds = ahead_off ? 0 : 1;
-    }
+    a.ahead_rounds = opt(OPT_WIDE_AHEAD) == 0 ? 0 : 1;
     // column ids in LDS when the largest graph's adjacency fits next to the state (prefer <= 48 KB
     // per workgroup so several graphs share a CU; allow up to the whole LDS for big graphs)
     int cap = b->max_graph_edges > 0 ? b->max_graph_edges : 0;
@@ -287,13 +284,12 @@ int dgcn::lgs_launch_common(const DgcnBatch* b, const double* prio, long prio_st
     const size_t lds = lgs_lds_bytes(b->max_nodes, cap);
     hipStream_t s = (hipStream_t)stream;
     const bool want_stats = stats != nullptr || overhead != nullptr;
-    const char* lpv_s = getenv("DGCN_LGS_LPV");  // tuning / test knob
-    const int lpv_env = lpv_s ? atoi(lpv_s) : 0;
+    const int lpv_env = opt(OPT_LGS_LPV);  // tuning / test knob
     int lpv = lpv_env > 0 ? lpv_env : (b->max_nodes <= 512 ? 4 : 1);  // measured: 4 lanes per vertex wins at N ~ 200
     // graphs beyond the fused kernel's sizes (the any-size path, general.hip): 1 024 threads per graph - a vertex's lanes in
     // every pass instead of a quarter of the graph per pass (ER(500, 0.1), 256 graphs: 118 us with 256 threads; the search is a chain
     // of LDS round trips, more waves hide more of them).  Same decisions, same totals (the reduction tree is fixed).
-    static const int blk_env = [] { const char* e = getenv("DGCN_LGS_BLOCK"); return e ? atoi(e) : -1; }();  // (read once per process)
+    const int blk_env = opt(OPT_LGS_BLOCK);
     // (the 1 024-thread kernels are built without the statistics: a caller that wants them never gets the wide launch)
     const bool wide = !want_stats && (blk_env >= 0 ? blk_env == 1024 : b->max_nodes > 384);
     if (wide && lpv_env <= 0) lpv = b->max_nodes <= 256 ? 4 : (b->max_nodes <= 512 ? 2 : 1);

@@ -35,7 +35,7 @@ struct LgsArgs {
     // (mwis_gdpg_call.py:629-643; a negative entry: no such candidate, the instance has nothing to search) - the mask is made in
     // LDS, no launch writes it out first
     const int32_t* cand;
-    int ahead_rounds;           // whole searches without statistics: lgs_rounds_ahead below (0: lgs_rounds; DGCN_WIDE_AHEAD=0)
+    int ahead_rounds;           // whole searches without statistics: lgs_rounds_ahead below (0: lgs_rounds; option "wide_ahead" = 0)
 };
 
 template <bool COLS_LDS>

@@ -145,8 +145,10 @@ __device__ __forceinline__ void rollout_bits(const RollArgs& r, int g) {
     // (np.isclose(cand, cand.max(), rtol=1e-12, atol=0), as in fused.hip and k_res_pick)
     double cand = lane < nc ? tot[lane] : -1.0 / 0.0;
     const double mx = wave_max_f64(cand);
-    const unsigned long long tied = __ballot(lane < nc && fabs(cand - mx) <= 1e-12 * fabs(mx));
-    const int best = tied ? __ffsll((long long)tied) - 1 : -1;  // (every wave computes the same pick; none: a total that is not finite)
+    // (cand == mx: equal infinities are close for np.isclose; nobody close - NaN totals -: the first candidate, as in fused.hip /
+    // tail.hip / k_res_pick: a step that picks nobody would leave the graph active for ever.  Every wave computes the same pick.)
+    const unsigned long long tied = __ballot(lane < nc && (cand == mx || fabs(cand - mx) <= 1e-12 * fabs(mx)));
+    const int best = nc > 0 ? (tied ? __ffsll((long long)tied) - 1 : 0) : -1;
     if (best < 0) {
         if (threadIdx.x == 0) {
             if (r.rounds) r.rounds[g] = 0;

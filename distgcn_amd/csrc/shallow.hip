@@ -482,9 +482,9 @@ static size_t shallow_lds(int max_nodes, int cap) {
 }
 
 // does this (batch, model) go through k_shallow?  One layer F -> 1 with two supports, graphs of <= 512 vertices whose
-// neighbour lists fit the LDS.  DGCN_SHALLOW=0 sends everything to k_fused (tests compare the two).
+// neighbour lists fit the LDS.  Option "shallow" = 0 sends everything to k_fused (tests compare the two).
 bool shallow_takes(const DgcnBatch* b, const DgcnModel* m) {
-    if (const char* e = getenv("DGCN_SHALLOW")) if (atoi(e) == 0) return false;
+    if (opt(OPT_SHALLOW) == 0) return false;
     if (!m->layers_host || m->num_layers != 1 || m->num_supports != 2) return false;
     const DgcnLayer& L = m->layers_host[0];
     if (L.out_dim != 1 || L.in_dim < 1 || L.in_dim > 64) return false;
@@ -522,7 +522,7 @@ template <int BLOCK>
 static int shallow_launch_b(ShallowArgs& a, int B, size_t lds, hipStream_t s) {
     if constexpr (BLOCK >= 512) {
         bool lng = (long)a.cap >= 24L * a.max_nodes;
-        if (const char* e = getenv("DGCN_SHALLOW_LONG")) lng = atoi(e) != 0;  // tuning / tests
+        if (const int want = opt(OPT_SHALLOW_LONG); want >= 0) lng = want != 0;  // tuning / tests
         if (lng) return shallow_launch_bl<BLOCK, true>(a, B, lds, s);
     }
     return shallow_launch_bl<BLOCK, false>(a, B, lds, s);
@@ -557,7 +557,7 @@ int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     a.done_count = hook.count;
     a.done_target = hook.target;
 #ifdef DGCN_DIAG
-    a.stamps = getenv("DGCN_SHALLOW_STAMPS") ? (unsigned long long*)strtoull(getenv("DGCN_SHALLOW_STAMPS"), nullptr, 0) : nullptr;
+    a.stamps = reinterpret_cast<unsigned long long*>(static_cast<uintptr_t>(opt64(OPT_DIAG_STAMPS)));
 #endif
     const size_t lds = shallow_lds(a.max_nodes, a.cap);
     // threads: a vertex per thread at least; small graphs get several lanes per vertex (<= 8) out of a 64..256-thread block
@@ -565,8 +565,7 @@ int shallow_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     // measured (tools/runs/r03_gpu9.sh, 500 graphs per launch): ER N=100: 17.9 / 12.3 / 13.3 / 24.4 us with 128 / 256 / 512 / 1024
     // threads; ER N=200: 22.8 (512) / 27.8 (1024); BA mix up to N=300 (hub rows): 53.0 (512) / 44.8 (1024)
     int block = mn <= 16 ? 64 : mn <= 64 ? 128 : mn <= 128 ? 256 : mn <= 256 ? 512 : 1024;
-    if (const char* e = getenv("DGCN_SHALLOW_BLOCK")) {  // tuning: any of 64 / 128 / 256 / 512 / 1024 that holds a vertex per thread
-        const int want = atoi(e);
+    if (const int want = opt(OPT_SHALLOW_BLOCK); want > 0) {  // tuning: any of 64 / 128 / 256 / 512 / 1024 that holds a vertex per thread
         if ((want == 64 || want == 128 || want == 256 || want == 512 || want == 1024) && want >= mn) block = want;
     }
     if (block == 64) return shallow_launch_b<64>(a, b->num_graphs, lds, s);

@@ -332,11 +332,6 @@ static int spmm_f64acc_plain(const DgcnCsr* S, const float* Z, int ldz, int C, c
     return check_launch("k_spmm_f64acc");
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    if (!e || !*e) return dflt;
-    return atoi(e);
-}
 
 
 
@@ -363,19 +358,19 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
     // LDS row stride of the staged Z slice = C + pad floats.  Measured on working sets beyond the Infinity Cache
     // (tools/tune_spmm_hbm.py, 4 000 ER graphs per launch): no padding 103.3 us, one vector 107.9 us, two 107.4 us -
     // the denser slice (25.6 instead of 28.8 KB per graph) is worth more than the staggered banks.
-    const int pad = env_int("DGCN_SPMM_PAD", 0);
+    const int pad = opt(OPT_SPMM_PAD);
     const int zs = (C == 1) ? 1 : C + (pad / VEC) * VEC;
     const size_t zbytes = (size_t)((max_nodes * zs + 3) & ~3) * sizeof(float);
-    const int force_global = env_int("DGCN_SPMM_GLOBAL", 0);
+    const int force_global = opt(OPT_SPMM_GLOBAL);
     if (graph_ptr && B > 0 && max_nodes > 0 && zbytes + 4096 <= kLdsMax && !force_global && (!f64 || (G == 1 && VEC == 4))) {
         // Tile = the whole graph unless the batch is too small to fill the chip; threads per
         // workgroup chosen so that every row group has about two rows.
-        const int rows_env = env_int("DGCN_SPMM_ROWS", 0);
+        const int rows_env = opt(OPT_SPMM_ROWS);
         int rows_per_tile = rows_env > 0 ? rows_env : max_nodes;
         if (rows_env <= 0)
             while ((long)B * ceil_div(max_nodes, rows_per_tile) < 256 && rows_per_tile > 64)
                 rows_per_tile = (rows_per_tile + 1) / 2;
-        int block = env_int("DGCN_SPMM_BLOCK", 0);
+        int block = opt(OPT_SPMM_BLOCK);
         if (block != 256 && block != 512 && block != 1024) {
             const int want_slots = (rows_per_tile + 1) / 2;  // about two passes per row slot
             block = want_slots * LPR * G <= 256 ? 256 : (want_slots * LPR * G <= 512 ? 512 : 1024);
@@ -388,7 +383,7 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
         const double avg_row = (double)S->nnz / (double)max(S->num_rows, 1);
         long cap = (long)(avg_row * rows_per_tile * 1.15) + 128;
         if (S->max_graph_nnz > 0 && tiles == 1) cap = S->max_graph_nnz;  // exact bound known
-        const int cap_env = env_int("DGCN_SPMM_CSRCAP", -1);
+        const int cap_env = opt(OPT_SPMM_CSRCAP);
         if (cap_env >= 0) cap = cap_env;
         // prefer two workgroups per CU (<= 78 KB each) when the average tile still fits
         const long two_per_cu = ((long)78 * 1024 - (long)zbytes) / 8;
@@ -422,7 +417,7 @@ static int launch_spmm(const DgcnCsr* S, const int32_t* graph_ptr, int B, int ma
 // The split factor G is part of the arithmetic (it fixes the summation order), so it depends on
 // the feature width only - never on the data.  DGCN_SPMM_SPLIT overrides it for tuning.
 int spmm_split_for(int C) {
-    const int env = env_int("DGCN_SPMM_SPLIT", 0);
+    const int env = opt(OPT_SPMM_SPLIT);
     int g = env > 0 ? env : 1;  // measured on MI355X (C=32, ER and BA batches): the plain chain is fastest
     const bool vec = (C % 4 == 0);
     int lpr = 1;

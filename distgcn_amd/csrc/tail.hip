@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kTailBlock) void k_tail(TailArgs a) {
             // no barrier behind it).
             const double cvl = lane < nc ? cand[lane] : -1.0 / 0.0;
             const double cmx = wave_max_f64(cvl);
-            const unsigned long long tied = __ballot(lane < nc && fabs(cvl - cmx) <= 1e-12 * fabs(cmx));
+            const unsigned long long tied = __ballot(lane < nc && (cvl == cmx || fabs(cvl - cmx) <= 1e-12 * fabs(cmx)));  // (equal infinities are close)
             const int best = tied ? __ffsll((long long)tied) - 1 : 0;
             const int c = __ffsll((long long)__ballot(al && gk == best)) - 1;
             const unsigned long long adjc = __shfl(myadj, c);
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kTailBlock) void k_tail(TailArgs a) {
 // Which (model, call) pairs the tail takes: [I, L] stacks F -> 32 -> ... -> 32 -> 1 of at least three layers (the shapes k_big
 // takes), constant or weight-derived input features, scores computed here.
 int tail_takes(const DgcnModel* m, const float* X, int32_t options) {
-    static const bool off = [] { const char* e = getenv("DGCN_TAIL"); return e && atoi(e) == 0; }();  // (read once per process)
+    const bool off = opt(OPT_TAIL) == 0;
     if (off || !m || !m->layers_host || m->num_supports != 2 || X || (options & DGCN_RESIDUAL_SCORES_GIVEN)) return 0;
     const int L = m->num_layers;
     if (L < 3 || L > kTailMaxLayers) return 0;
@@ -551,7 +551,7 @@ int tail_finish(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table
         a.layers[l].act = Ly.act; a.layers[l].pad = 0;
     }
 #ifdef DGCN_DIAG
-    a.diag = getenv("DGCN_TAIL_DIAG") ? atoi(getenv("DGCN_TAIL_DIAG")) : 0;
+    a.diag = opt(OPT_DIAG_FLAGS);
 #endif
     TimedLaunch t("tail_finish", s);
     DGCN_LAUNCH(t, k_tail, dim3((unsigned)b->num_graphs), dim3(kTailBlock), 0, s, a);

@@ -68,7 +68,7 @@ struct WideArgs {
     int32_t* active;           // mode 2: [num_graphs] out
     int32_t* cid;              // mode 2: [num_graphs][64] the rollout's candidates (cand_select.h), or null (k_res_cand follows)
     int32_t beam;
-    int32_t ahead_rounds;      // mode 0, whole searches: the rounds on ahead lists (lgs_rounds_ahead, lgs_rounds.h); 0: lgs_rounds.h's (DGCN_WIDE_AHEAD=0)
+    int32_t ahead_rounds;      // mode 0, whole searches: the rounds on ahead lists (lgs_rounds_ahead, lgs_rounds.h); 0: lgs_rounds.h's (option "wide_ahead" = 0)
     int32_t roll_off;          // mode 2: byte offset of the LDS the completions and the pick run in (rollout_bits.h) - the whole step in
     int32_t by_priority;       // this launch; 0: general.hip's k_lgs / k_res_pick launches follow.  by_priority: the completions' order
     unsigned long long* tail_word;
@@ -557,17 +557,17 @@ __global__ __launch_bounds__(kWideBlock) void k_wide1(WideArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// which (batch, model) pairs: one layer F -> 1 over [I, L], F <= 64, graphs of at most 9 600 vertices.  DGCN_WIDE1=0 (read
-// once per process) sends them layer by layer instead (tests compare the two).
+// which (batch, model) pairs: one layer F -> 1 over [I, L], F <= 64, graphs of at most 9 600 vertices.  Option "wide1" = 0
+// sends them layer by layer instead (tests compare the two).
 int wide1_takes(const DgcnBatch* b, const DgcnModel* m, const float* X, int32_t feature_mode) {
-    static const bool off = [] { const char* e = getenv("DGCN_WIDE1"); return e && atoi(e) == 0; }();
+    const bool off = opt(OPT_WIDE1) == 0;
     if (off || !b || !m || !m->layers_host || m->num_supports != 2) return 0;
     if (b->max_nodes <= 0 || b->max_nodes > kWideMaxNodes) return 0;
     const DgcnLayer& L = m->layers_host[0];
     if (!L.weights || L.in_dim < 1 || L.in_dim > 64) return 0;
     if (m->num_layers == 1) return L.out_dim == 1;
     // two layers F -> C -> 1, C <= 64, on constant input features (per-vertex features would need the neighbours' C-wide rows)
-    static const bool off2 = [] { const char* e = getenv("DGCN_WIDE2"); return e && atoi(e) == 0; }();
+    const bool off2 = opt(OPT_WIDE2) == 0;
     if (m->num_layers != 2 || off2 || X || feature_mode != 0) return 0;
     const DgcnLayer& L1 = m->layers_host[1];
     return L.out_dim >= 1 && L.out_dim <= 64 && L1.weights && L1.in_dim == L.out_dim && L1.out_dim == 1;
@@ -625,14 +625,11 @@ int wide1_run(const DgcnBatch* b, const DgcnModel* m, const double* dinv_table, 
     size_t lds = wide_lds_bytes(a.max_nodes, cap);
     if (a.cid) lds = std::max(lds, (size_t)cand_scratch_bytes(kWideBlock));  // (small graphs: the selection's scratch is the larger)
     a.by_priority = by_priority;
-    {
-        static const bool ahead_off = [] { const char* e = getenv("DGCN_WIDE_AHEAD"); return e && atoi(e) == 0; }();
-        a.ahead_rounds = ahead_off ? 0 : 1;
-    }
+    a.ahead_rounds = opt(OPT_WIDE_AHEAD) == 0 ? 0 : 1;
     if (a.cid && whole_step) {
         // the completions and the pick in this launch too (rollout_bits.h) when sixteen candidates do and the columns, the
-        // selection's scratch and the instances' state words all fit the LDS.  DGCN_ROLLOUT_BITS=0: general.hip's launches.
-        static const bool bits_off = [] { const char* e = getenv("DGCN_ROLLOUT_BITS"); return e && atoi(e) == 0; }();
+        // selection's scratch and the instances' state words all fit the LDS.  Option "rollout_bits" = 0: general.hip's launches.
+        const bool bits_off = opt(OPT_ROLLOUT_BITS) == 0;
         const size_t base = (wide_lds_bytes(a.max_nodes, cap) + 15) & ~(size_t)15;
         const size_t need = base + ((cand_scratch_bytes(kWideBlock) + 15) & ~(size_t)15) + kCandMaxBeam * 4 + roll_lds_bytes(a.max_nodes);
         if (!bits_off && beam <= kRollBeam && weights && (cap > 0 || b->max_graph_edges == 0) && need <= kLdsMax) {

@@ -465,6 +465,9 @@ class Engine:
         group = 4
         issued = 0
         done = n == 0
+        # (the status word is sticky - kernels OR into it, nobody clears it: only bits set DURING this search end it, a fault
+        # an earlier call left in a re-used `out` is the caller's to read, not a reason to cut this search short)
+        status_at_entry = out["status"].reshape(-1)[:1].to(t.int32).clone()
         while not done and steps < limit:
             k = min(group, limit - steps)
             progress = t.zeros(k, dtype=t.int32, device=self.device)
@@ -484,13 +487,13 @@ class Engine:
                 break
             # (the status word rides along: a fault such as a NaN priority leaves its graph undecided - "active" - for ever,
             # and the any-size path counts active graphs as progress; the caller's check_status reports it)
-            words = t.cat([progress, out["status"].reshape(-1)[:1].to(t.int32)]).cpu().tolist()
+            words = t.cat([progress, out["status"].reshape(-1)[:1].to(t.int32), status_at_entry]).cpu().tolist()
             for v in words[:k]:
                 if v == 0:
                     done = True
                     break
                 steps += 1
-            if words[k] != 0:
+            if words[k] & ~words[k + 1]:
                 done = True
             group = min(2 * group, 32)  # (a search of ~100 steps: 6 read-backs instead of 14; at most 31 empty launches at its end)
         return {"state": state, "steps": steps, "status": out["status"],
@@ -501,11 +504,15 @@ class Engine:
         """on=True clears earlier records and starts recording; on=False stops (records stay readable)."""
         if on:
             self.lib.dgcn_timing_reset()
-        # (DGCN_TIMING_EVERY=N: an event pair round every N-th launch only - an A/B switch for what the instrumentation costs)
-        self.lib.dgcn_timing_enable(int(os.environ.get("DGCN_TIMING_EVERY", "1")) if on else 0)
+        # (DGCN_TIMING_EVERY=N: an event pair round every N-th launch only - an A/B switch for what the instrumentation costs;
+        # anything below 1 means 1: "on" never silently turns the recording off)
+        self.lib.dgcn_timing_enable(max(1, int(os.environ.get("DGCN_TIMING_EVERY", "1"))) if on else 0)
 
     def timing_read(self, family: str):
+        """(milliseconds, launches) of a kernel family since timing(True).  With every N-th launch sampled both are scaled by N
+        (estimates of the whole region: the average per launch is unchanged, per-step figures stay per step)."""
         ms = C.c_double(0.0)
         n = C.c_int64(0)
         _lib.check(self.lib.dgcn_timing_read(family.encode(), C.byref(ms), C.byref(n)), "dgcn_timing_read")
-        return ms.value, n.value
+        every = max(1, int(self.lib.dgcn_timing_sampling()))
+        return ms.value * every, n.value * every

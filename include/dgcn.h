@@ -44,8 +44,8 @@ enum {
     DGCN_FAULT_DEGREE_RANGE = 4, /* vertex degree >= dinv_table length, or a row with (many) more entries than its graph has vertices */
     DGCN_FAULT_BAD_COLUMN = 8,   /* column id outside the owning graph's node range */
     DGCN_FAULT_CLUSTER = 16      /* small batches only (one graph on several workgroups): the workgroups of a graph did not
-                                    end up on one XCD, or one of them never arrived - results are not valid; rerun with the
-                                    environment variable DGCN_FUSED_CLUSTER=0 */
+                                    end up on one XCD, or one of them never arrived - results are not valid; rerun after
+                                    dgcn_set_option("fused_cluster", 0) */
 };
 
 /* Block-diagonal adjacency of a batch (host struct holding device pointers). */
@@ -91,6 +91,25 @@ typedef struct DgcnModel {
 
 int dgcn_version(void);
 const char* dgcn_last_error(void);
+
+/* ---- Options: the library's only process-wide state ------------------------------------------------------
+ * The library reads NO environment variable.  Every switch between code paths (all of which give the same results: they
+ * exist for A/B measurements, for the tests' witnesses - "the same batch down the other path, bit for bit" - and for the
+ * fault recovery of the small-batch launch) is one word of this table: set / get are atomic, take effect with the next call
+ * of any thread, and cost a launch nothing.  -1 = automatic (the default of every path switch).  Keys (csrc/options.h has
+ * the full list with defaults; dgcn_option_name enumerates it):
+ *   "fused_cluster" (-1 | 0 | K), "fused_block" (512 | 1024), "fused_order", "fused_pipe" (0 lock-step layer loop | 1 transforms
+ *   pulled by free waves), "general" (1: every shape down the any-size path), "shallow", "shallow_long", "shallow_block",
+ *   "wide1", "wide2", "wide_ahead", "rollout_bits", "big", "big_solve", "big_block", "big_tiles", "big_residual", "big2",
+ *   "tail", "layer_fuse", "lgs_lpv", "lgs_block", "spmm_*" (tuning of the stand-alone SpMM), "host_direct_bytes",
+ *   "host_compact", "host_compact_direct", "host_done_word", "test_cluster_fault" (test hook: the small-batch launch reports
+ *   DGCN_FAULT_CLUSTER although there is none), "diag_flags" / "diag_stamps" (read by -DDGCN_DIAG builds only).
+ * Unknown key: DGCN_ERR_ARG.  The Python package applies DGCN_OPTIONS="key=value,key=value" from ITS environment once at
+ * load (distgcn_amd/_lib.py) - a convenience of the host layer, not of this library. */
+int dgcn_set_option(const char* key, int64_t value);
+int dgcn_get_option(const char* key, int64_t* value);
+int dgcn_option_count(void);
+const char* dgcn_option_name(int32_t index, int64_t* default_value /* or NULL */); /* NULL past the end */
 
 /* ---- batch ingestion (host side): what mwis_dqn_test.py:304-321 does one .mat file at a time ------------
  * Packs num_graphs per-graph CSR adjacencies (SciPy's indptr / indices arrays as they are, int32 or int64:
@@ -309,13 +328,13 @@ int dgcn_solve_supported(const DgcnBatch* batch, const DgcnModel* model);
  * (renumbered, with its own support), the forward pass runs layer by layer (mode 0's kernels: same bits), the greedy step in
  * kernels of its own.  Nothing returns to the host, nothing changes in the results.  dgcn_solve_path: 1 = fused kernels, 2 = any-size path (graphs
  * up to 9 600 vertices, [I, L] models with one output per vertex), 0 = neither (DGCN_ERR_UNSUPPORTED).
- * dgcn_set_general(1) sends every shape down the any-size path (tests, A/B runs); -1 = automatic (default; initialised
- * once from the environment variable DGCN_GENERAL). */
+ * dgcn_set_general(1) sends every shape down the any-size path (tests, A/B runs); -1 = automatic (default).
+ * Same word as dgcn_set_option("general", ..). */
 int dgcn_solve_path(const DgcnBatch* batch, const DgcnModel* model);
 void dgcn_set_general(int32_t setting);
 int32_t dgcn_get_general(void);
 /* The several-workgroups-per-graph launch variant (small batches): -1 = chosen automatically (default), 0 = off,
- * K >= 2 = forced.  Process-wide, atomic; initialised once from the environment variable DGCN_FUSED_CLUSTER.  The
+ * K >= 2 = forced.  Process-wide, atomic; same word as dgcn_set_option("fused_cluster", ..).  The
  * library's own recovery from DGCN_FAULT_CLUSTER calls dgcn_set_cluster(0). */
 void dgcn_set_cluster(int32_t setting);
 int32_t dgcn_get_cluster(void);
@@ -373,7 +392,7 @@ int dgcn_solve_residual_batch(const DgcnBatch* batch, const DgcnModel* model, co
  * directory.  A DgcnHostSolver keeps `depth` slots of pinned staging memory, device buffers, a stream and an event:
  *   submit: dgcn_pack_batch into the slot's pinned memory -> one host-to-device copy -> dgcn_solve_batch -> one
  *           device-to-host copy, all asynchronous; returns the slot index (>= 0) or a DGCN_ERR_* code (< 0)
- *           (a packed batch of at most DGCN_HOST_DIRECT_BYTES, default 2 MB, is not copied: the kernel reads the pinned
+ *           (a packed batch of at most option "host_direct_bytes", default 2 MB, is not copied: the kernel reads the pinned
  *           staging memory and writes the pinned result memory itself)
  *   result: waits for that slot; hands out pointers into its pinned result memory (valid until the slot's next submit):
  *           state[num_nodes] (0 undecided / 1 in the set / 2 excluded), totals[num_graphs], rounds[num_graphs],
@@ -403,6 +422,10 @@ int dgcn_host_solver_result(DgcnHostSolver* solver, int32_t slot, const uint8_t*
 int dgcn_timing_enable(int32_t on);
 int dgcn_timing_reset(void);
 int dgcn_timing_read(const char* kernel, double* total_ms, int64_t* launches);
+/* N = every N-th launch carries (carried, once timing is off again) an event pair: read()'s totals cover the sampled launches
+ * only, a caller that wants per-step figures multiplies both by N.  Event pairs are kept per device: a launch takes its pair
+ * from the device that is current when it is issued. */
+int32_t dgcn_timing_sampling(void);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_wide.py / test_gpu_general.py: complete dit / cit / rollout searches and a plain solve on
 three ragged ~900-vertex graphs (or ~`nodes`), results to an .npz: python _wide_witness.py out.npz [num_layer=1] [nodes=900].  Run twice - as built
-and with a switch of the library set in the environment (DGCN_WIDE1=0: one-layer models layer by layer instead of
-csrc/wide.hip; DGCN_BIG_RESIDUAL=0: the residual steps of deep models through the compaction launches + k_big + k_lgs
+and with a switch of the library set (DGCN_OPTIONS="wide1=0", applied by distgcn_amd/_lib.py through dgcn_set_option: one-layer
+models layer by layer instead of csrc/wide.hip; "big_residual=0": the residual steps of deep models through the compaction launches + k_big + k_lgs
 instead of one launch of k_big) - the two files must hold the same bytes / bits."""
 import os
 import sys

@@ -94,3 +94,72 @@ def test_python_option_bits_equal_the_header():
     assert defs["DGCN_RESIDUAL_FINISH_SMALL"] == engine.Engine.FINISH_SMALL
     bits = [defs[k] for k in ("DGCN_RESIDUAL_SCORES_GIVEN", "DGCN_RESIDUAL_COMPLETE_BY_PRIORITY", "DGCN_RESIDUAL_FINISH_SMALL")]
     assert len(set(bits)) == 3 and all(b & (b - 1) == 0 for b in bits)  # distinct single bits
+
+
+def test_options_are_the_only_process_state_and_no_environment_is_read():
+    """dgcn_set_option / dgcn_get_option (include/dgcn.h "Options"): every key of csrc/options.h is listed by the library with
+    its default, a set is seen by the next get, unknown keys are refused, the older setters are names of the same words - and
+    no source of the library calls getenv (a stateless, re-entrant library; round-5 review item 6)."""
+    lib = _lib.load()
+    table = open(os.path.join(ROOT, "distgcn_amd", "csrc", "options.h")).read()
+    declared = {m.group(1): int(m.group(2)) for m in re.finditer(r'X\(OPT_[A-Z0-9_]+,\s*"([a-z0-9_]+)",\s*(-?\d+)\)', table)}
+    defaults = _lib.option_defaults()
+    assert defaults == declared and len(defaults) == lib.dgcn_option_count() >= 30
+    assert lib.dgcn_option_name(lib.dgcn_option_count(), None) is None and lib.dgcn_option_name(-1, None) is None
+    before = {k: _lib.get_option(k) for k in defaults}
+    try:
+        for i, k in enumerate(defaults):
+            _lib.set_option(k, 1000 + i)
+        assert [_lib.get_option(k) for k in defaults] == [1000 + i for i in range(len(defaults))]
+        _lib.set_option("diag_stamps", 0x7fff12345678)  # 64-bit values (a device address in the -DDGCN_DIAG builds)
+        assert _lib.get_option("diag_stamps") == 0x7fff12345678
+        lib.dgcn_set_cluster(4)
+        assert _lib.get_option("fused_cluster") == 4 and lib.dgcn_get_cluster() == 4
+        lib.dgcn_set_general(1)
+        assert _lib.get_option("general") == 1 and lib.dgcn_get_general() == 1
+        with _lib.options(wide1=0, tail=0):
+            assert _lib.get_option("wide1") == 0 and _lib.get_option("tail") == 0
+        assert _lib.get_option("wide1") == 1000 + list(defaults).index("wide1")  # (put back by the context manager)
+    finally:
+        for k, v in before.items():
+            _lib.set_option(k, v)
+    assert lib.dgcn_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.dgcn_last_error()
+    assert lib.dgcn_get_option(b"fused_pipe", None) == -1
+    assert lib.dgcn_set_option(None, 1) == -1
+    csrc = os.path.join(ROOT, "distgcn_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".c")):
+            code = re.sub(r"//.*?$|/\*.*?\*/", "", open(os.path.join(csrc, f)).read(), flags=re.S | re.M)
+            assert "getenv" not in code, f
+
+
+def test_options_from_many_threads():
+    """Set / get from eight threads at once: every read returns a value some thread wrote (atomic words, no torn state)."""
+    import threading
+    _lib.load()
+    seen, stop = [], []
+
+    def worker(i):
+        for r in range(2000):
+            _lib.set_option("lgs_lpv", i)
+            v = _lib.get_option("lgs_lpv")
+            if not 0 <= v < 8:
+                seen.append(v)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    _lib.set_option("lgs_lpv", -1)
+    assert not seen and not stop
+
+
+def test_dgcn_options_environment_is_applied_by_the_python_layer():
+    """DGCN_OPTIONS="key=value,..." is read by distgcn_amd/_lib.py at load (not by the library): a child process sees it."""
+    import subprocess
+    import sys
+    code = "from distgcn_amd import _lib; _lib.load(); print(_lib.get_option('wide1'), _lib.get_option('fused_cluster'), _lib.get_option('tail'))"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DGCN_OPTIONS="wide1=0, fused_cluster=4"), cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["0", "4", "-1"], r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DGCN_OPTIONS="nonsense=1"), cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unknown option" in r.stderr

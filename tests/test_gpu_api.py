@@ -971,13 +971,11 @@ def test_native_host_solver(engine, golden):
     with pytest.raises(TypeError):
         hs.solve([batches[1][0][0].astype(np.float32)], [batches[1][1][0]], [batches[1][2][0]])
     # small batches are read in place from the pinned staging memory and write their results there; larger ones (or
-    # DGCN_HOST_DIRECT_BYTES=0) take the two copies: same answers, through both the one-call and the two-call path
+    # option host_direct_bytes = 0) take the two copies: same answers, through both the one-call and the two-call path
     import os
-    for direct in ("0", None):
-        if direct is None:
-            os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
-        else:
-            os.environ["DGCN_HOST_DIRECT_BYTES"] = direct
+    from distgcn_amd import _lib
+    for direct in (0, -1):
+        _lib.set_option("host_direct_bytes", direct)
         for b, r in zip(batches, refs):
             for g in (hs.solve(*b), hs.result(hs.submit(*b))):
                 assert np.array_equal(g["state"], r["state"]) and np.array_equal(g["rounds"], r["rounds"])
@@ -985,7 +983,7 @@ def test_native_host_solver(engine, golden):
                 assert np.array_equal(g["scores"].view(np.uint32), np.asarray(r["scores"], np.float32).ravel().view(np.uint32))
     hs.close()
     # The one-slot object's kernel tells the host itself when a batch is through (a word in pinned memory, written after the
-    # outputs have been written back; DGCN_HOST_DONE_WORD=0 = wait for the event only): 400 single-graph calls in a row,
+    # outputs have been written back; option host_done_word = 0 = wait for the event only): 400 single-graph calls in a row,
     # every result complete when it is handed out.
     one = HostSolver(engine, dm, depth=1, want_scores=True)
     ps, cs, ws = batches[0]
@@ -1007,18 +1005,14 @@ def test_native_host_solver(engine, golden):
         g = one.solve([ps[k]], [cs[k]], [ws[k]])
         assert np.array_equal(g["state"], refs[0]["state"][gp[k]:gp[k + 1]])
     one.close()
-    # A placement fault of the several-workgroups-per-graph kernel (injected: DGCN_FUSED_CLUSTER_INJECT_FAULT) is not the
+    # A placement fault of the several-workgroups-per-graph kernel (injected: option test_cluster_fault) is not the
     # caller's problem: the object switches the variant off for the process, solves the batch again and hands out that.
-    from distgcn_amd import _lib
     lib = _lib.load()
     initial = int(lib.dgcn_get_cluster())
-    os.environ["DGCN_FUSED_CLUSTER_INJECT_FAULT"] = "1"
+    _lib.set_option("test_cluster_fault", 1)
     try:
-        for direct in ("0", None):
-            if direct is None:
-                os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
-            else:
-                os.environ["DGCN_HOST_DIRECT_BYTES"] = direct
+        for direct in (0, -1):
+            _lib.set_option("host_direct_bytes", direct)
             lib.dgcn_set_cluster(-1)
             one = HostSolver(engine, dm, depth=1, want_scores=True)
             g = one.solve(*batches[1])  # one N = 200 graph, 20 layers: the cluster variant's case
@@ -1027,8 +1021,8 @@ def test_native_host_solver(engine, golden):
             assert np.array_equal(g["scores"].view(np.uint32), np.asarray(refs[1]["scores"], np.float32).ravel().view(np.uint32))
             one.close()
     finally:
-        os.environ.pop("DGCN_FUSED_CLUSTER_INJECT_FAULT", None)
-        os.environ.pop("DGCN_HOST_DIRECT_BYTES", None)
+        _lib.set_option("test_cluster_fault", 0)
+        _lib.set_option("host_direct_bytes", -1)
         lib.dgcn_set_cluster(initial)
 
 
@@ -1240,7 +1234,7 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
 def test_host_solver_compact_transfer(engine, monkeypatch):
     """Batches above the in-place threshold cross PCIe in the compact form (16-bit local column ids + degrees: include/dgcn.h
     DgcnCompactInfo) and are expanded on the device (csrc/expand.hip): same sets / rounds / totals / scores as the ordinary
-    transfer (DGCN_HOST_COMPACT=0), as the expanded-on-the-device form (DGCN_HOST_COMPACT_DIRECT=0) and as the twin, on the BA mix (hubs, 100..300 vertices), an ER batch, and a batch with an
+    transfer (option host_compact = 0), as the expanded-on-the-device form (host_compact_direct = 0) and as the twin, on the BA mix (hubs, 100..300 vertices), an ER batch, and a batch with an
     unsorted row (entry order is the caller's, in both forms); the plain greedy search (no model) goes the same way."""
     from distgcn_amd import datagen
     from distgcn_amd.batch import HostBatch
@@ -1249,7 +1243,8 @@ def test_host_solver_compact_transfer(engine, monkeypatch):
     from oracle import ctwin
     layers = datagen.random_model(3, 32, seed=21)
     dm = DeviceModel(layers, engine.device)
-    monkeypatch.setenv("DGCN_HOST_DIRECT_BYTES", "0")
+    from distgcn_amd import _lib
+    _lib.set_option("host_direct_bytes", 0)  # (conftest puts the table back after the test)
 
     def lists(hb, scramble=None):
         ps, cs, ws = [], [], []
@@ -1269,19 +1264,19 @@ def test_host_solver_compact_transfer(engine, monkeypatch):
         ref = ctwin.solve(hb, layers)
         # compact + read by the fused kernel as it is (the default), compact + expanded on the device first, ordinary transfer
         for mode, direct in (("1", "1"), ("1", "0"), ("0", "1")):
-            monkeypatch.setenv("DGCN_HOST_COMPACT", mode)
-            monkeypatch.setenv("DGCN_HOST_COMPACT_DIRECT", direct)
+            _lib.set_option("host_compact", int(mode))
+            _lib.set_option("host_compact_direct", int(direct))
             hs = HostSolver(engine, dm, depth=2, want_scores=True)
             g = [hs.solve(ps, cs, ws) for _ in range(2)][-1]
             hs.close()
             assert np.array_equal(g["state"], ref["state"]) and np.array_equal(g["rounds"], ref["rounds"]), (mode, direct)
             assert np.allclose(g["totals"], ref["totals"], rtol=1e-12, atol=0)
             assert np.array_equal(g["scores"].view(np.uint32), ref["scores"][:, 0].view(np.uint32)), (mode, direct)
-        monkeypatch.delenv("DGCN_HOST_COMPACT_DIRECT")
+        _lib.set_option("host_compact_direct", -1)
     ps, cs, ws = cases[0]
     hb = HostBatch.from_csr_lists(ps, cs, ws)
     want = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, hb.weights, sum_weights=hb.weights, want_stats=False)
-    monkeypatch.setenv("DGCN_HOST_COMPACT", "1")
+    _lib.set_option("host_compact", 1)
     hs = HostSolver(engine, None, depth=2)
     g = hs.solve(ps, cs, ws)
     hs.close()

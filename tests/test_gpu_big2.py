@@ -4,7 +4,7 @@ two walks.  Chains per (row, feature) are untouched, so everything must equal th
 
 (1) plain solves from 977 to 1 920 vertices - sparse, dense, hubs, ragged batches, biases - against the twin; (2) explicit
 input features (the layer-by-layer prelude + k_big2) against the twin's forward; (3) complete iterative searches at 1 500
-vertices against the oracle's solvers; (4) the existing any-size suite re-run in a child process with DGCN_BIG2=1, which
+vertices against the oracle's solvers; (4) the existing any-size suite re-run in a child process with option big2 = 1, which
 sends every shape k_big takes down k_big2 instead: each residual step of nine solver variants against the fused kernel,
 plain solves against the fused kernel and the twin, hub graphs, 600 .. 976-vertex graphs."""
 import os
@@ -130,11 +130,11 @@ def test_big2_iterative_solvers_vs_oracle(engine, which):
 
 
 def test_any_size_suite_through_big2(engine):
-    """DGCN_BIG2=1 (read once per process, hence a child): every shape k_big takes goes down k_big2 - eight tiles per wave, the
+    """option "big2" = 1 (DGCN_OPTIONS in a child process): every shape k_big takes goes down k_big2 - eight tiles per wave, the
     same code as at 1 500 vertices.  The any-size suite's bit-for-bit checks run unchanged: nine solver variants step by step
     against the fused residual kernel, plain solves against the fused kernel and the twin, graphs of 600 .. 976 vertices, rows
     of 575+ entries."""
-    env = dict(os.environ, DGCN_BIG2="1")
+    env = dict(os.environ, DGCN_OPTIONS="big2=1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_general.py"), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "plain_solve_equals or residual_steps_equal or big_graphs_plain or beyond_575"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
@@ -145,13 +145,13 @@ def test_any_size_suite_through_big2(engine):
 def test_big2_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp_path):
     """A residual step on 977 .. 1 920-vertex graphs is one launch of k_big2<.., RESID> too (the residual graph's support from the
     adjacency and the running state).  Complete dit / cit / rollout searches on three ragged ~1 500-vertex graphs (zero weights
-    inside live graphs, biases, leaky last layer) by a child process as built and by one with DGCN_BIG_RESIDUAL=0 - the compaction
+    inside live graphs, biases, leaky last layer) by a child process as built and by one with option big_residual = 0 - the compaction
     launches + k_big2 + k_lgs: same states, step counts, score bits."""
     script = os.path.join(ROOT, "tests", "_wide_witness.py")
     files = {}
     for tag, val in (("one_launch", "1"), ("compaction", "0")):
         files[tag] = str(tmp_path / (tag + ".npz"))
-        subprocess.run([sys.executable, script, files[tag], "4", "1500"], check=True, env=dict(os.environ, DGCN_BIG_RESIDUAL=val), timeout=900)
+        subprocess.run([sys.executable, script, files[tag], "4", "1500"], check=True, env=dict(os.environ, DGCN_OPTIONS="big_residual=" + val), timeout=900)
     a, b = np.load(files["one_launch"]), np.load(files["compaction"])
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:

@@ -429,7 +429,7 @@ def test_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp
     """A residual step of a deep model on graphs k_big takes is ONE launch (big.hip: the residual graph's support from the
     adjacency and the running state, every layer, the greedy step).  Second witness besides the fused kernel (the step-by-step
     test above, on fixture graphs): complete dit / cit / rollout searches on three ragged ~900-vertex graphs - zero weights
-    inside live graphs, biases, a leaky last layer - by a child process as built and by one with DGCN_BIG_RESIDUAL=0, the
+    inside live graphs, biases, a leaky last layer - by a child process as built and by one with option big_residual = 0, the
     compaction launches + k_big + k_lgs that ran before: same states, step counts, score bits."""
     import os
     import subprocess
@@ -438,7 +438,7 @@ def test_residual_step_in_one_launch_agrees_with_the_compaction_path(engine, tmp
     files = {}
     for tag, val in (("one_launch", "1"), ("compaction", "0")):
         files[tag] = str(tmp_path / (tag + ".npz"))
-        subprocess.run([sys.executable, script, files[tag], "5"], check=True, env=dict(os.environ, DGCN_BIG_RESIDUAL=val), timeout=900)
+        subprocess.run([sys.executable, script, files[tag], "5"], check=True, env=dict(os.environ, DGCN_OPTIONS="big_residual=" + val), timeout=900)
     a, b = np.load(files["one_launch"]), np.load(files["compaction"])
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
@@ -514,7 +514,7 @@ def test_rollout_nan_weight_on_the_any_size_path(engine, golden, general_switch,
 def test_rollout_in_one_launch_agrees_with_the_instance_launches(engine, tmp_path, num_layer, nodes):
     """Witness for csrc/rollout_bits.h: complete searches on three ragged graphs (zero weights inside live graphs) by a child
     process as built - candidates, all completions (an instance per bit) and the pick inside the step's launch of k_wide1 /
-    k_big / k_big2 - and by one with DGCN_ROLLOUT_BITS=0 - k_lgs on beam x graphs masked instances + k_res_pick: the same
+    k_big / k_big2 - and by one with option rollout_bits = 0 - k_lgs on beam x graphs masked instances + k_res_pick: the same
     states after the same number of steps (and every other solver's results untouched by the switch)."""
     import os
     import subprocess
@@ -523,7 +523,7 @@ def test_rollout_in_one_launch_agrees_with_the_instance_launches(engine, tmp_pat
     files = {}
     for tag, val in (("bits", "1"), ("launches", "0")):
         files[tag] = str(tmp_path / (tag + ".npz"))
-        env = dict(os.environ, DGCN_ROLLOUT_BITS=val)
+        env = dict(os.environ, DGCN_OPTIONS="rollout_bits=" + val)
         subprocess.run([sys.executable, script, files[tag], str(num_layer), str(nodes)], check=True, env=env, timeout=600)
     a, b = np.load(files["bits"]), np.load(files["launches"])
     assert sorted(a.files) == sorted(b.files)
@@ -541,7 +541,7 @@ def test_rollout_in_one_launch_agrees_with_the_instance_launches(engine, tmp_pat
 def test_rounds_on_ahead_lists_agree_with_the_three_phase_rounds(engine, tmp_path, num_layer, nodes):
     """Witness for lgs_rounds_ahead (lgs_rounds.h): the plain solve (states, round counts, totals, score bits) and complete
     searches of k_wide1 / k_big2 by a child process as built - a whole search's rounds as two walks over every vertex's AHEAD
-    list - and by one with DGCN_WIDE_AHEAD=0 - lgs_rounds' three phases over all neighbours: the same bytes."""
+    list - and by one with option wide_ahead = 0 - lgs_rounds' three phases over all neighbours: the same bytes."""
     import os
     import subprocess
     import sys
@@ -549,7 +549,7 @@ def test_rounds_on_ahead_lists_agree_with_the_three_phase_rounds(engine, tmp_pat
     files = {}
     for tag, val in (("ahead", "1"), ("rounds", "0")):
         files[tag] = str(tmp_path / (tag + ".npz"))
-        env = dict(os.environ, DGCN_WIDE_AHEAD=val)
+        env = dict(os.environ, DGCN_OPTIONS="wide_ahead=" + val)
         subprocess.run([sys.executable, script, files[tag], str(num_layer), str(nodes)], check=True, env=env, timeout=600)
     a, b = np.load(files["ahead"]), np.load(files["rounds"])
     assert sorted(a.files) == sorted(b.files)

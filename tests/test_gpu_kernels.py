@@ -13,6 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from conftest import TOL, check_scores
+from distgcn_amd import _lib
 
 
 def _dev(engine, a):
@@ -352,9 +353,8 @@ def test_lgs_reference_goldens(engine, golden, variant, lpv, monkeypatch):
     hb = golden.host_batch(ids)
     db = engine.upload(hb)
     prio = np.concatenate([golden.lgs["g%02d_%s_prio" % (i, variant)] for i in ids])
-    if lpv:
-        monkeypatch.setenv("DGCN_LGS_LPV", str(lpv))  # lanes per vertex: 0 = library default
-    res = engine.lgs(db, prio=_dev(engine, prio), want_stats=True, want_overhead=True)
+    with _lib.options(lgs_lpv=lpv if lpv else -1):  # lanes per vertex: -1 = library default
+        res = engine.lgs(db, prio=_dev(engine, prio), want_stats=True, want_overhead=True)
     engine.check_status(res["status"])
     _lgs_check(res, hb, golden, variant, ids)
     stats = res["stats"].cpu().numpy()
@@ -667,7 +667,7 @@ def test_margin_risk_counts_and_guarantee(engine, golden):
 
 def test_layer_fused_with_next_transform(engine, golden):
     """Layer-by-layer path at hidden width 32: the aggregation of layer l and the transform of layer l + 1 run as one
-    launch (csrc/layer.hip).  Same bits as the two separate kernels (DGCN_LAYER_FUSE=0) and as the twin, for deep stacks
+    launch (csrc/layer.hip).  Same bits as the two separate kernels (option layer_fuse = 0) and as the twin, for deep stacks
     with and without bias, explicit features, the BA mix, and a batch whose largest graph (700 vertices) sends it back
     to the separate kernels."""
     import os
@@ -688,11 +688,8 @@ def test_layer_fused_with_next_transform(engine, golden):
         X = None if fs is None else np.random.default_rng(0).random((hb.num_nodes, fs)).astype(np.float32)
         Xd = None if X is None else _dev(engine, X)
         got = engine.forward(db, dm, X=Xd, mode=0).cpu().numpy()
-        os.environ["DGCN_LAYER_FUSE"] = "0"
-        try:
+        with _lib.options(layer_fuse=0):
             plain = engine.forward(db, dm, X=Xd, mode=0).cpu().numpy()
-        finally:
-            del os.environ["DGCN_LAYER_FUSE"]
         lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
         twin = ctwin.forward(lap, layers, hb.num_nodes, X=X)
         assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
@@ -813,13 +810,10 @@ def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatc
         db = engine.upload(hb)
         got = {}
         for order in ("0", "1", None):
-            if order is None:
-                monkeypatch.delenv("DGCN_FUSED_ORDER", raising=False)
-            else:
-                monkeypatch.setenv("DGCN_FUSED_ORDER", order)
-            out = engine.solve_buffers(db, True)
-            engine.solve_fused(db, model, out=out, want_scores=True)
-            torch.cuda.synchronize()
+            with _lib.options(fused_order=-1 if order is None else int(order)):
+                out = engine.solve_buffers(db, True)
+                engine.solve_fused(db, model, out=out, want_scores=True)
+                torch.cuda.synchronize()
             got[order] = {k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")}
             assert int(got[order]["status"][0]) == 0
         for order in ("1", None):
@@ -831,7 +825,7 @@ def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatc
 def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     """One-layer models go through the small dedicated kernel (csrc/shallow.hip: no 32-wide image, greedy rounds on the
     float64 priorities themselves instead of on ranks).  Against the twin bit for bit, and against k_fused forced on the
-    same batch (DGCN_SHALLOW=0): ties everywhere (weights from a handful of values), isolated vertices, 1-vertex and
+    same batch (option shallow = 0): ties everywhere (weights from a handful of values), isolated vertices, 1-vertex and
     empty graphs, explicit features with a bias and an activation (GCN2_DQN's last layer), the BA mix with hubs, dense
     graphs whose every row is long (with ties), 512-vertex graphs, and the C2 batch itself with the trained weights."""
     import scipy.sparse as sp
@@ -890,19 +884,17 @@ def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     engine.torch.cuda.synchronize()
     engine.timing(False)
     engine.check_status(got["status"])
-    monkeypatch.setenv("DGCN_SHALLOW", "0")
-    old = engine.solve(db, dm, mode=1, X=Xd)
-    engine.check_status(old["status"])
-    monkeypatch.delenv("DGCN_SHALLOW")
+    with _lib.options(shallow=0):
+        old = engine.solve(db, dm, mode=1, X=Xd)
+        engine.check_status(old["status"])
     # graphs above 128 vertices have two shallow kernels - with and without the entry-parallel treatment of long rows (hubs) -
     # and the host picks by the batch's density: both, forced, on every case (the "ba" and "dense" cases have such rows)
     forced = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("DGCN_SHALLOW_LONG", flag)
-        out = engine.solve(db, dm, mode=1, X=Xd)
-        engine.check_status(out["status"])
-        forced.append(("shallow, DGCN_SHALLOW_LONG=" + flag, out))
-    monkeypatch.delenv("DGCN_SHALLOW_LONG")
+        with _lib.options(shallow_long=int(flag)):
+            out = engine.solve(db, dm, mode=1, X=Xd)
+            engine.check_status(out["status"])
+        forced.append(("shallow, option shallow_long=" + flag, out))
     for name, out in [("shallow", got), ("fused", old)] + forced:
         assert np.array_equal(out["scores"].cpu().numpy().reshape(-1).view(np.uint32), ref["scores"][:, 0].view(np.uint32)), name
         assert np.array_equal(out["state"].cpu().numpy(), ref["state"]), name

@@ -6,7 +6,7 @@ Checks: (1) plain solves against the twin, bit for bit, from 16 to 9 600 vertice
 not), with bias / explicit features / F = 16 input features; (2) forced onto shapes the fused residual kernel takes too,
 every step of every solver variant must leave the same bytes / bits; (3) complete searches at 900 / 1 500 / 3 000
 vertices against the oracle's solvers (oracle/ref_numpy.py, pinned by the executed reference) fed with the twin's scores;
-(4) the layer-by-layer any-size path (what ran before) as a second witness via a child process with DGCN_WIDE1=0."""
+(4) the layer-by-layer any-size path (what ran before) as a second witness via a child process with option wide1 = 0 (DGCN_OPTIONS)."""
 import numpy as np
 import pytest
 
@@ -291,7 +291,7 @@ def test_wireless_joint_graph_900_one_layer(engine):
 def test_one_layer_paths_agree_with_the_layer_by_layer_path(engine, tmp_path):
     """Second witness: the same plain solve and complete dit / cit / rollout searches (three ragged ~900-vertex graphs, zero
     weights inside live graphs, GCN2_DQN-style bias + leaky last layer) run by a child process as built and by one with
-    DGCN_WIDE1=0 - the compaction + layer-by-layer + k_lgs chain that served one-layer models beyond 512 vertices before
+    option wide1 = 0 - the compaction + layer-by-layer + k_lgs chain that served one-layer models beyond 512 vertices before
     wide.hip existed: same states, step counts and score bits."""
     import os
     import subprocess
@@ -300,7 +300,7 @@ def test_one_layer_paths_agree_with_the_layer_by_layer_path(engine, tmp_path):
     files = {}
     for tag, val in (("wide", "1"), ("layered", "0")):
         files[tag] = str(tmp_path / (tag + ".npz"))
-        env = dict(os.environ, DGCN_WIDE1=val)
+        env = dict(os.environ, DGCN_OPTIONS="wide1=" + val)
         subprocess.run([sys.executable, script, files[tag]], check=True, env=env, timeout=600)
     a, b = np.load(files["wide"]), np.load(files["layered"])
     assert sorted(a.files) == sorted(b.files)

@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""A/B of k_fused launch options in ONE process, interleaved rounds (cdna guide rule 24):
-   python tools/ab_fused.py "K=V,K=V" "K=V" ...   (each argument is one variant; "" = defaults)"""
+"""A/B of k_fused launch options (dgcn_set_option keys) in ONE process, interleaved rounds (cdna guide rule 24):
+   python tools/ab_fused.py "fused_pipe=0" "fused_pipe=1" ...   (each argument is one variant: key=value,key=value; "" = defaults)
+   DGCN_AB_GRAPHS / DGCN_AB_KIND=er|ba pick the batch (default 500 ER(200, 0.1))"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
 
 variants = [dict(kv.split("=") for kv in a.split(",") if kv) for a in (sys.argv[1:] or [""])]
 keys = sorted({k for v in variants for k in v})
-hb = datagen.er_batch(500, 200, 0.1)
+nB = int(os.environ.get("DGCN_AB_GRAPHS", "500"))
+hb = datagen.ba_test2_batch(nB) if os.environ.get("DGCN_AB_KIND", "er") == "ba" else datagen.er_batch(nB, 200, 0.1)
+defaults = _lib.option_defaults()
 eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_model(20, 32), "cuda:0")
 out = eng.solve_buffers(db, True)
 ref = None
@@ -20,8 +23,9 @@ torch.cuda.synchronize()
 for rnd in range(7):
     for i, v in enumerate(variants):
         for k in keys:
-            os.environ.pop(k, None)
-        os.environ.update(v)
+            _lib.set_option(k, defaults[k])
+        for k, val in v.items():
+            _lib.set_option(k, int(val))
         for _ in range(20):
             eng.solve_fused(db, model, out=out)
         torch.cuda.synchronize()

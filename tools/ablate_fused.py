@@ -6,7 +6,7 @@ meaningless; only their duration is read.
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.engine import Engine, DeviceModel
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 500
@@ -19,11 +19,10 @@ torch.cuda.synchronize()
 rows = [("everything", 0), ("no aggregation (hidden layers)", 1), ("no transform (hidden layers)", 2), ("neither", 3),
         ("neither, no weight fetch", 11), ("no greedy rounds", 4), ("layers only: neither + no greedy", 7),
         ("neighbour parities forced conflict-free", 16), ("... and no transform", 18)]
-for pad in ("0", "40000"):
-    os.environ["DGCN_FUSED_LDS_PAD"] = pad
-    print("workgroups per CU: %s" % ("2" if pad == "0" else "1 (LDS padded)"))
+# (until round 5 the diag build could also pad the LDS to force one workgroup per CU: profiles/r03_fused_ablation.txt has that table)
+if True:
     for name, bits in rows:
-        os.environ["DGCN_FUSED_DIAG"] = str(bits)
+        _lib.set_option("diag_flags", bits)
         for _ in range(20):
             eng.solve_fused(db, model, out=out)
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from distgcn_amd import datagen
+from distgcn_amd import _lib
 from distgcn_amd.engine import Engine, DeviceModel
 from distgcn_amd.serving import HostSolver
 eng = Engine("cuda:0"); dm = DeviceModel(datagen.random_model(20, 32), "cuda:0")
@@ -18,7 +19,7 @@ for B in (1, 4, 8, 16, 32, 63):
         ws.append(np.ascontiguousarray(hb.weights[n0:n1]))
     line = "B=%2d (%4d KB packed):" % (B, (hb.num_edges * 4 + hb.num_nodes * 12) // 1024)
     for name, val in (("copied", "0"), ("in place", str(64 << 20))):
-        os.environ["DGCN_HOST_DIRECT_BYTES"] = val
+        _lib.set_option("host_direct_bytes", int(val))
         for _ in range(30): hs.solve(ps, cs, ws)
         t0 = time.perf_counter()
         for _ in range(300): hs.solve(ps, cs, ws)

@@ -6,6 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from distgcn_amd import datagen
+from distgcn_amd import _lib
 from distgcn_amd.engine import Engine, DeviceModel
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -18,10 +19,10 @@ for n in (16, 64, 128, 256, 500):
     db = eng.upload(hb)
     out = eng.solve_buffers(db, True)
     for block in ("512", "1024"):
-        os.environ["DGCN_FUSED_BLOCK"] = block
+        _lib.set_option("fused_block", int(block))
         line = []
         for name, bits in rows:
-            os.environ["DGCN_FUSED_DIAG"] = str(bits)
+            _lib.set_option("diag_flags", bits)
             for _ in range(30):
                 eng.solve_fused(db, model, out=out)
             torch.cuda.synchronize()

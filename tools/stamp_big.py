@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.engine import Engine, DeviceModel
 kind = sys.argv[1] if len(sys.argv) > 1 else "er500"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -17,9 +17,9 @@ out = eng.solve_buffers(db, False)
 for _ in range(20): eng.solve_fused(db, model, want_scores=False, out=out)
 torch.cuda.synchronize()
 st = torch.zeros(hb.num_graphs * 32, dtype=torch.int64, device="cuda")  # [graphs][16] phases, then [graphs][16] per-wave aggregation sums
-os.environ["DGCN_BIG_STAMPS"] = str(st.data_ptr())
+_lib.set_option("diag_stamps", st.data_ptr())
 eng.solve_fused(db, model, want_scores=False, out=out); torch.cuda.synchronize()
-os.environ.pop("DGCN_BIG_STAMPS")
+_lib.set_option("diag_stamps", 0)
 allst = st.cpu().numpy().astype(np.float64)
 raw = allst[:hb.num_graphs * 16].reshape(-1, 16)
 waves = allst[hb.num_graphs * 16:].reshape(-1, 16)

@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
 kind = sys.argv[1] if len(sys.argv) > 1 else "er"
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -13,9 +13,9 @@ eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_
 for _ in range(3): eng.solve(db, model, mode=MODE_FUSED)
 torch.cuda.synchronize()
 st = torch.zeros(hb.num_graphs * 64, dtype=torch.int64, device="cuda")
-os.environ["DGCN_FUSED_STAMPS"] = str(st.data_ptr())
+_lib.set_option("diag_stamps", st.data_ptr())
 eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
-os.environ.pop("DGCN_FUSED_STAMPS")
+_lib.set_option("diag_stamps", 0)
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 2400.0  # s_memtime ticks at the shader clock (2.4 GHz under load: tools/stamp_residual.py) -> us
 names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
          "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]

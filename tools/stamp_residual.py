@@ -4,7 +4,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.api_common import get_engine
 from distgcn_amd.mwis_gdpg_call import DQNAgent
 from distgcn_amd.runtime_config import FLAGS
@@ -29,10 +29,10 @@ if before > 0:
 torch.cuda.synchronize()
 left = (state.cpu().numpy() == 0).reshape(graphs, n).sum(1)
 st = torch.zeros(graphs * 64, dtype=torch.int64, device="cuda")
-os.environ["DGCN_FUSED_STAMPS"] = str(st.data_ptr())
+_lib.set_option("diag_stamps", st.data_ptr())
 eng.solve_residual(db, dm, state, greedy=greedy, max_rounds=1, beam=16, max_steps=1)
 torch.cuda.synchronize()
-os.environ.pop("DGCN_FUSED_STAMPS")
+_lib.set_option("diag_stamps", 0)
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 100.0
 names = ["P0 states, anything left, renumbering", "P0 row bounds, columns, counts, slots", "P0 entries, row order, records", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
          "hidden A (sum)", "barrier after A (sum)", "last layer", "priorities, ranks, candidates", "rounds / completions, pick, output"]

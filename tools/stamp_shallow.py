@@ -4,7 +4,7 @@ python tools/stamp_shallow.py [er100|er200|ba] [graphs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from distgcn_amd import datagen
+from distgcn_amd import datagen, _lib
 from distgcn_amd.engine import Engine, DeviceModel, MODE_FUSED
 kind = sys.argv[1] if len(sys.argv) > 1 else "er100"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 500
@@ -13,9 +13,9 @@ eng = Engine("cuda:0"); db = eng.upload(hb); model = DeviceModel(datagen.random_
 for _ in range(5): eng.solve(db, model, mode=MODE_FUSED)
 torch.cuda.synchronize()
 st = torch.zeros(hb.num_graphs * 8, dtype=torch.int64, device="cuda")
-os.environ["DGCN_SHALLOW_STAMPS"] = str(st.data_ptr())
+_lib.set_option("diag_stamps", st.data_ptr())
 eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
-os.environ.pop("DGCN_SHALLOW_STAMPS")
+_lib.set_option("diag_stamps", 0)
 s = st.cpu().numpy().reshape(-1, 8).astype(np.float64)
 names = ["row pointers, weights (round trip 1)", "columns + degree table issued -> ids in LDS", "barrier after the LDS image",
          "entry values, chain, priority (+ NaN vote, barrier)", "greedy rounds", "outputs, totals"]

@@ -7,6 +7,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distgcn_amd import datagen
+from distgcn_amd import _lib
 from distgcn_amd.api_common import get_engine
 from distgcn_amd.mwis_gdpg_call import DQNAgent
 from distgcn_amd.runtime_config import FLAGS
@@ -34,7 +35,7 @@ for layers in (3, 8, 20):
         print("layers %2d %-8s step by step: %3d steps %.3f ms (%.1f us per step) | with the tail: %d calls %.3f ms"
               % (layers, which, s_full, line[False][0] * 1e3, line[False][0] * 1e6 / max(s_full, 1), line[True][1], line[True][0] * 1e3), flush=True)
         for bits, name in ((0, "everything"), (1, "no aggregation"), (2, "no transform"), (4, "no weight fetch"), (7, "none of the three")) if diag else ((0, "everything"),):
-            os.environ["DGCN_TAIL_DIAG"] = str(bits)
+            _lib.set_option("diag_flags", bits)
             out = eng.solve_buffers(db, False)
             best = None
             for rep in range(4):
@@ -48,4 +49,4 @@ for layers in (3, 8, 20):
                     best = (ms / steps, steps, ms)
             if best:
                 print("      tail launch, %-20s %6.1f us per step of the longest graph (%d steps, %.3f ms)" % (name + ":", best[0] * 1e3, best[1], best[2]), flush=True)
-        os.environ.pop("DGCN_TAIL_DIAG", None)
+        _lib.set_option("diag_flags", 0)

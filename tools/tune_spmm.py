@@ -4,6 +4,7 @@ import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distgcn_amd import datagen
+from distgcn_amd import _lib
 from distgcn_amd.engine import Engine
 
 def main():
@@ -22,8 +23,8 @@ def main():
     for rnd in range(5):
         for i, v in enumerate(variants):
             for k in ("DGCN_SPMM_GLOBAL", "DGCN_SPMM_ROWS", "DGCN_SPMM_BLOCK", "DGCN_SPMM_CSRCAP", "DGCN_SPMM_PAD", "DGCN_SPMM_SPLIT"):
-                os.environ.pop(k, None)
-            os.environ.update(v)
+                _lib.set_option(k[5:].lower(), {'DGCN_SPMM_CSRCAP': -1}.get(k, 0))
+            [_lib.set_option(k[5:].lower(), int(val)) for k, val in v.items()]
             eng.timing(True)
             for _ in range(20):
                 eng.spmm(lap, Z[:, 32:], 32, ldz=64, graph_ptr=db.graph_ptr, num_graphs=hb.num_graphs,

@@ -7,9 +7,10 @@ import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distgcn_amd import datagen
+from distgcn_amd import _lib
 from distgcn_amd.engine import Engine
 
-KEYS = ("DGCN_SPMM_GLOBAL", "DGCN_SPMM_ROWS", "DGCN_SPMM_BLOCK", "DGCN_SPMM_CSRCAP", "DGCN_SPMM_PAD", "DGCN_SPMM_SPLIT", "DGCN_SPMM_XCD", "DGCN_SPMM_PERSIST")
+KEYS = ("DGCN_SPMM_GLOBAL", "DGCN_SPMM_ROWS", "DGCN_SPMM_BLOCK", "DGCN_SPMM_CSRCAP", "DGCN_SPMM_PAD", "DGCN_SPMM_SPLIT")
 
 
 def make(eng, hb):
@@ -42,8 +43,8 @@ def main():
     for rnd in range(3):
         for i, v in enumerate(variants):
             for k in KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(v)
+                _lib.set_option(k[5:].lower(), {'DGCN_SPMM_CSRCAP': -1}.get(k, 0))
+            [_lib.set_option(k[5:].lower(), int(val)) for k, val in v.items()]
             for w, sets, reps in (("one4000", [big], 6), ("rot8", rot, 3)):
                 for st in sets:
                     launch(eng, st)
