@@ -561,3 +561,80 @@ def test_rounds_on_ahead_lists_agree_with_the_three_phase_rounds(engine, tmp_pat
         else:
             assert np.array_equal(a[k], b[k]), k
     assert a["plain_rounds"].min() >= 2
+
+
+@pytest.mark.parametrize("hidden,num_layer,n,p", [(16, 20, 600, 0.012), (16, 4, 900, 0.01), (4, 4, 900, 0.01), (3, 3, 700, 0.02), (2, 3, 520, 0.05),
+                                                  (16, 5, 1500, 0.006), (5, 3, 1200, 0.01)])
+def test_narrow_deep_stacks_take_the_one_launch_kernels(engine, hidden, num_layer, n, p):
+    """Round-5 review item 4a.  The reference ships deep stacks narrower than 32 (model/result_IS4SAT_deep_ld1_c16_l20.., c16_l4,
+    c4_l4, c3_l3, c2_l3: widths from --hidden1, gcn/models.py:550-573) and runs them on any conflict graph it gets
+    (wireless_dqn_test_mc.py:161).  Beyond the fused kernel's 512 vertices they ran layer by layer (a 20-launch chain); now as
+    their 32-wide zero-padded copy on k_big / k_big2: ONE launch for the plain solve, bit-equal to the twin (which computes at
+    the model's own width) - scores, sets, rounds, totals - on 520 .. 1 500 vertices, biases and a leaky last layer included."""
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    layers = datagen.random_model(num_layer, hidden, bias=True, last_act="leaky_relu", seed=31 + hidden)
+    hb = datagen.er_batch(3, n, p, first_index=70 + hidden)
+    sl = hb.graph_slices()
+    hb.weights[sl[1][0]:sl[1][0] + 7] = 0.0
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    assert engine.solve_path(db, dm) == 2
+    ref = ctwin.solve(hb, layers)
+    engine.timing(True)
+    r = engine.solve_fused(db, dm)
+    engine.torch.cuda.synchronize()
+    engine.timing(False)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), ref["scores"].ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), ref["state"])
+    assert np.array_equal(r["rounds"].cpu().numpy(), ref["rounds"])
+    assert np.allclose(r["totals"].cpu().numpy(), ref["totals"], rtol=1e-12)
+    assert engine.timing_read("big_solve")[1] == 1  # the whole path in one launch of k_big / k_big2 ...
+    assert engine.timing_read("fused_pad")[1] == 1  # ... behind the one that writes the padded copy
+    assert engine.timing_read("spmm")[1] == 0 and engine.timing_read("transform")[1] == 0  # ... and no layer-by-layer kernel
+
+
+@pytest.mark.parametrize("hidden,num_layer,n", [(16, 4, 900), (4, 4, 600), (16, 5, 1200)])
+def test_narrow_deep_stacks_iterative_solvers_agree_with_the_layer_by_layer_path(engine, hidden, num_layer, n):
+    """... and their residual steps: complete dit / cit / rollout searches (b = 16) on three ragged graphs as built - padded,
+    every step one launch of k_big<RESID> / k_big2<RESID>, the tail of the search in k_tail - and with k_big / k_big2 switched
+    off (options big = 0, big2 = 0: the model's own width through the compaction launches and the layer-by-layer kernels, what
+    ran before): same final states and totals; and against the oracle's solvers fed with the twin's scores."""
+    import torch
+    from distgcn_amd import datagen, _lib
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    import scipy.sparse as sp
+    from oracle import ref_numpy as orc
+    layers = datagen.random_model(num_layer, hidden, bias=True, last_act="leaky_relu", seed=5 + hidden)
+    rng = np.random.default_rng(123 + n)
+    mats, ws = [], []
+    for nn in (n, n - 37, n - 210):
+        ip, ix = datagen.er_graph(nn, 9.0 / nn, rng)
+        mats.append(sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(nn, nn)))
+        w = rng.random(nn)
+        w[rng.random(nn) < 0.04] = 0.0
+        ws.append(w)
+    hb = HostBatch.from_scipy(mats, ws)
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    assert engine.solve_path(db, dm) == 2
+    fn = _twin_scores_fn(layers)
+    for name, kw in (("dit", dict(greedy=engine.GREEDY_ROUNDS, max_rounds=1)), ("cit", dict(greedy=engine.GREEDY_CENTRAL)),
+                     ("rollout", dict(greedy=engine.GREEDY_ROLLOUT, beam=16))):
+        got = {}
+        for tag, opts in (("padded", {}), ("layered", dict(big=0, big2=0))):
+            with _lib.options(**opts):
+                state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=engine.device)
+                res = engine.solve_residual(db, dm, state, **kw)
+                engine.check_status(res["status"])
+                got[tag] = state.cpu().numpy().copy()
+        assert np.array_equal(got["padded"], got["layered"]), name
+        assert (got["padded"] == 1).sum() > 50  # (a search happened; zero-weight vertices may stay undecided: np.sum(wts_nn) <= 0 -> break)
+        g = 2  # the smallest graph against the oracle's solver (pure Python: seconds)
+        n0, n1 = hb.graph_slices()[g]
+        solver = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit, "rollout": orc.solve_mwis_rollout}[name]
+        want, _ = solver(fn, mats[g], ws[g], 16) if name == "rollout" else solver(fn, mats[g], ws[g])
+        assert set(np.flatnonzero(got["padded"][n0:n1] == 1).tolist()) == set(int(v) for v in want), name
