@@ -81,7 +81,6 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
-    int32_t pipe_own;          // k_fused<.., PIPE>: 1 = every wave transforms the tiles of its OWN row blocks (no ready queue)
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
@@ -525,12 +524,9 @@ template <> struct RowAcc<true> {
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-// `pq` (pulled layer loop, below): the wave reports every block it has finished - H' of the block's sixteen rows is in bufA -
-// in the workgroup's ready queue: pq[1] counts the reports, pq[4 + i] = tag << 8 | block is the i-th of this layer.
 template <int BLOCK, int ACT, bool BIAS, bool F64 = false>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
-                                                 const uint2* rec, const unsigned* rinfo_lds, unsigned long long* st, bool const_rows = false,
-                                                 unsigned* pq = nullptr, unsigned ptag = 0u) {
+                                                 const uint2* rec, const unsigned* rinfo_lds, unsigned long long* st, bool const_rows = false) {
     (void)st;
     (void)rinfo_lds;
 #ifdef DGCN_DIAG
@@ -685,15 +681,6 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
         bacc[4] += 1;
         bacc[5] += (unsigned long long)trips;
 #endif
-        if (pq) {
-            // (a wave's LDS operations complete in order; the count says the rows are written before anybody is told)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
-                const unsigned pos = atomicAdd(&pq[1], 1u);
-                __hip_atomic_store(&pq[4 + pos], (ptag << 8) | (unsigned)blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
     };
     one_block(std::integral_constant<int, 0>{});
     one_block(std::integral_constant<int, 1>{});
@@ -835,8 +822,7 @@ __device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bu
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
 template <int BLOCK>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
-                                                 const unsigned* rinfo, bool precise, unsigned long long* st = nullptr, bool const_rows = false,
-                                                 unsigned* pq = nullptr, unsigned ptag = 0u) {
+                                                 const unsigned* rinfo, bool precise, unsigned long long* st = nullptr, bool const_rows = false) {
     const float* bias = L.bias;
     const int act = L.act;
     if (precise) {  // layer index 0: chains in double (once per launch: not worth twelve instantiations, the bias is a runtime test there)
@@ -852,91 +838,14 @@ __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* buf
         return;
     }
     if (bias) {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, rinfo, st);
     } else {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, rinfo, st, false, pq, ptag);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, rinfo, st);
     }
-}
-
-// ---- the pulled layer loop (round 6) ---------------------------------------------------------------------------------------
-// Until round 5 a hidden layer was transform | barrier | aggregate | barrier with tiles and row blocks dealt statically and
-// separately: wave 0 of a C3 workgroup spent 50 of 194 us behind the second barrier, waiting for the waves with the long
-// row blocks, while the next layer's transforms - which need nothing but H' of their own sixteen rows - could not start.
-// Here a tile IS a row block (rows perm[16 t .. 16 t + 15]): the wave that finishes aggregating block t reports it in a
-// ready queue in LDS (aggregate_rows16), and a wave that has finished ITS blocks takes a ticket, waits for the ticket's
-// report and transforms that tile for the next layer - Z0 goes straight into the tile's rows of bufA (nobody else reads
-// them), Z1 stays in registers until every aggregation of this layer has read the old Z1 (barrier X), is written, and is
-// seen by everybody (barrier Y).  Still two barriers, but back to back, with nothing but eight ds_write_b128 between them:
-// what the waves used to wait for behind the aggregation now runs inside it.  Chains per row / per output element are
-// untouched (same MFMA sequence per element, same entry order per row): the bits do not change.
-// A wave takes at most two tickets (its registers hold two tiles' Z1): with at most two row blocks per wave (kMaxRowBlocks)
-// there are never more tiles than that, so every ticket below `tiles` is taken and every taken ticket is served - the
-// aggregations never wait for anything.
-struct HeldTile {
-    f32x4 za, zb;  // Z1 chunks kq and 4 + kq of the lane's row
-    int row;       // -1: nothing held
-};
-
-template <int BLOCK>
-__device__ __forceinline__ void pull_transforms(const float (&b)[8][4], int ng, int tiles, float* bufA, const unsigned short* perm,
-                                                unsigned* pq, unsigned ptag, HeldTile& h0, HeldTile& h1, bool own = false) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 15, kq = lane >> 4;
-    h0.row = -1;
-    h1.row = -1;
-    auto one = [&](HeldTile& h, int own_blk) -> bool {
-        unsigned e = (unsigned)own_blk;
-        if (own_blk < 0) {
-            int i = 0;
-            if (lane == 0) i = (int)atomicAdd(&pq[0], 1u);
-            i = __builtin_amdgcn_readfirstlane(i);
-            if (i >= tiles) return false;
-            while (true) {  // the i-th report of this layer (the aggregations never wait: it comes)
-                e = __hip_atomic_load(&pq[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
-                if ((e >> 8) == ptag) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } else if (own_blk >= tiles) return false;
-        const int slot = (int)(e & 0xffu) * 16 + r;
-        const int row = slot < ng ? (int)perm[slot] : -1;
-        const int rr = row >= 0 ? row : 0;  // lanes past the graph's end feed some row and write nothing
-        float av[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) av[s] = bufA[rr * kHid + (((s ^ (rr & 7)) << 2) | kq)];
-        f32x4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s][ct], av[s], acc[ct], 0, 0, 0);
-        if (row >= 0) {
-            *reinterpret_cast<float4*>(bufA + row * kHid + ((kq ^ (row & 7)) << 2)) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-            *reinterpret_cast<float4*>(bufA + row * kHid + (((4 + kq) ^ (row & 7)) << 2)) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
-        }
-        h.za = acc[2];
-        h.zb = acc[3];
-        h.row = row;
-        return true;
-    };
-    if (own) {  // (owner-computes form, option "fused_pipe" = 2: the wave's own row blocks, no tickets, no reports)
-        constexpr int kWaves = BLOCK / 64;
-        const int wave = threadIdx.x >> 6;
-        one(h0, wave);
-        one(h1, kWaves + (kWaves - 1 - wave));
-    } else if (one(h0, -1)) one(h1, -1);
-}
-
-__device__ __forceinline__ void store_held(const HeldTile& h, float* bufB) {
-    if (h.row < 0) return;
-    const int kq = (threadIdx.x & 63) >> 4;
-    *reinterpret_cast<float4*>(bufB + h.row * kHid + ((kq ^ keyB(h.row)) << 2)) = make_float4(h.za[0], h.za[1], h.za[2], h.za[3]);
-    *reinterpret_cast<float4*>(bufB + h.row * kHid + (((4 + kq) ^ keyB(h.row)) << 2)) = make_float4(h.zb[0], h.zb[1], h.zb[2], h.zb[3]);
 }
 
 // Block-wide OR through dynamic LDS (hipcc's __syncthreads_or reserves 256 B of STATIC LDS, which would
@@ -1147,11 +1056,9 @@ __device__ __forceinline__ void signal_done(const FusedArgs& a) {
 
 // COMPACT: the batch comes in the compact transfer form (common.h CompactHook): a kernel of its own, also by name - what a
 // profile of the host-to-host path shows (solves of consecutive batches overlapping) does not mix into the resident launch's row.
-// PIPE: the pulled layer loop (pull_transforms above) instead of the lock-step one; never with CLUSTER.
-template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false, bool COMPACT = false, bool PIPE = false>
+template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false, bool COMPACT = false>
 // (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
-    static_assert(!(PIPE && CLUSTER), "the cluster variant keeps the lock-step loop");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int g = blockIdx.x;
     if (!CLUSTER && a.order) g = a.order[g];
@@ -1178,8 +1085,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     unsigned* wflags = reinterpret_cast<unsigned*>(lds_raw + a.flags_off);  // [waves] block-wide OR scratch
     const unsigned zrow = (unsigned)a.flags_off + 128u;  // LDS byte address of 128 zero bytes
     if (threadIdx.x < 32) wflags[32 + threadIdx.x] = 0u;
-    unsigned* pq = wflags + 64;  // PIPE: ready queue of the pulled layer loop: [0] tickets, [1] reports, [4 .. 35] the reports
-    if (PIPE && threadIdx.x < 36) pq[threadIdx.x] = 0u;
     uint2* rec = a.grec + (size_t)g * a.rec_cap;  // (cluster variant: every workgroup of the graph writes the same records)
     float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
@@ -1521,13 +1426,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     RowBlocks rb;
     ClusterRows cr;
     ClusterTile ctile;
-    int pipe_tiles = has_wide ? (ng + 15) >> 4 : 0;  // PIPE: reports (= tickets) per layer
     // (every wave writes the block-major records of its own row blocks: read back by the same lanes, no barrier)
     if constexpr (!CLUSTER) {
-        if (!row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, a.rec_cap, DIAG_ON(a, 4) != 0)) {
+        if (!row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, a.rec_cap, DIAG_ON(a, 4) != 0))
             fault |= DGCN_FAULT_DEGREE_RANGE;  // (a row with more entries than the graph has vertices: results invalid)
-            pipe_tiles = 0;                     // (no records, no blocks, no reports: nothing to pull)
-        }
     }
     if constexpr (CLUSTER) {
         cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
@@ -1622,16 +1524,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         if (a.layers[1].cout == kHid && (CLUSTER || wave_has_tile)) load_bfrag(a.layers[1].W, bfrag, DIAG_ON(a, 3), true);  // layer index 1: the f64 MFMA's lane map
         __syncthreads();
         l_first = 1;
-        if constexpr (PIPE) {
-            // layer index 1's transform (chains in double) runs before the loop, tile by tile as dealt statically: inside the loop
-            // every transform is pulled (the fragments are then defined and used within one iteration - not live through the walks)
-            if (a.layers[1].cout == kHid) {
-                hidden_transform_f64<BLOCK>(bfrag, ng, bufA, bufB);
-                STAMP(a, g, 5, tclk);
-                __syncthreads();
-                STAMP(a, g, 6, tclk);
-            }
-        }
     }
     for (int l = l_first; l < (scores_given ? 0 : a.num_layers); ++l) {
         const FusedLayer& L = a.layers[l];
@@ -1653,40 +1545,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 }
             }
         }
-        if (PIPE && L.cout == kHid) {
-            // Z0 (bufA) and Z1 (bufB) of this layer are complete and seen by every wave.
-            const bool next_hidden = l + 1 < a.num_layers && a.layers[l + 1].cout == kHid;
-            const bool puller = next_hidden && (int)(threadIdx.x >> 6) < pipe_tiles;
-#ifdef DGCN_DIAG
-            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
-            if (a.prio_gather) set_prio(prio_base + a.prio_gather);
-#ifdef DGCN_DIAG
-            if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr, false, (next_hidden && !a.pipe_own) ? pq : nullptr, (unsigned)l);
-#else
-            hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false, nullptr, false, (next_hidden && !a.pipe_own) ? pq : nullptr, (unsigned)l);
-#endif
-#ifdef DGCN_DIAG
-            if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 3] = __builtin_amdgcn_s_memrealtime();
-#endif
-            STAMP(a, g, 7, tclk);  // gather body (wave 0)
-            if (a.prio_second || a.prio_gather) set_prio(prio_base);
-            HeldTile h0, h1;
-            h0.row = -1;
-            h1.row = -1;
-            if (puller) {
-                load_bfrag(a.layers[l + 1].W, bfrag, DIAG_ON(a, 3));
-                if (!DIAG_ON(a, 1)) pull_transforms<BLOCK>(bfrag, ng, pipe_tiles, bufA, perm, pq, (unsigned)l, h0, h1, a.pipe_own != 0);
-            }
-            STAMP(a, g, 5, tclk);  // pulled transforms (wave 0)
-            __syncthreads();       // X: every aggregation of this layer has read Z1, every tile of the next layer is transformed
-            STAMP(a, g, 8, tclk);  // wait at barrier X
-            if (threadIdx.x == 0) { pq[0] = 0u; pq[1] = 0u; }
-            store_held(h0, bufB);
-            store_held(h1, bufB);
-            __syncthreads();       // Y: the next layer's Z1 is in bufB
-            STAMP(a, g, 6, tclk);  // Z1 stores + barrier Y
-        } else if (!PIPE && L.cout == kHid) {
+        if (L.cout == kHid) {
 #ifdef DGCN_DIAG
             if (a.stamps && stamp_wg && threadIdx.x == 0 && l >= 1 && l <= 8) a.stamps[(size_t)g * 64 + 16 + 4 * (l - 1) + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1767,12 +1626,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                     z0 = (float)d0;
                     z1 = (float)d1;
                 } else if (l > 0 && L.cin == kHid) {  // the row as 8 swizzled 16-byte chunks, same k order
-                    int vq = v;
-                    asm volatile("" : "+v"(vq));  // (opaque: the eight chunk addresses are formed here, once per launch, instead of being
-                                                  // hoisted out of the layer loop into registers the loop does not have)
 #pragma unroll
                     for (int c = 0; c < kHid / 4; ++c) {
-                        const float4 h = *reinterpret_cast<const float4*>(bufA + vq * kHid + ((c ^ (vq & 7)) << 2));
+                        const float4 h = *reinterpret_cast<const float4*>(bufA + v * kHid + ((c ^ (v & 7)) << 2));
                         const float hk[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -2270,11 +2126,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
 static int fused_rec_cap(int meta_cap, int max_nodes) { return meta_cap + ((20 * max_nodes + 192 + 15) & ~15); }
 static int fused_meta_cap(int max_graph_nnz, int max_nodes) { return (max_graph_nnz + max_nodes + 2 + 16 + 15) & ~15; }  // 16 records = 128 B: slices never share a cache line
 
-constexpr size_t kFusedTailBytes = 512;
 static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
     const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
     const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
-    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 4 + 127) & ~(size_t)127) + kFusedTailBytes;  // + block-OR flags (128 B) + a zero row (128 B) + the ready queue (256 B)
+    return ((bufs + rinfo + (size_t)meta_cap * (gvals ? 2 : 6) + (size_t)max_nodes * 4 + 127) & ~(size_t)127) + 256;  // + block-OR flags (128 B) + a zero row (128 B)
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -2591,11 +2446,11 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         a->nonce = nonce_src.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed);
     }
     *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
-    a->flags_off = (int32_t)(*lds - kFusedTailBytes);
+    a->flags_off = (int32_t)(*lds - 256);
     return DGCN_OK;
 }
 
-template <bool MASKED, bool GVALS, int BLOCK, bool COMPACT = false, bool PIPE = false>
+template <bool MASKED, bool GVALS, int BLOCK, bool COMPACT = false>
 static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         // raise the kernel's dynamic-LDS limit once per device and size (the attribute call is a driver round trip)
@@ -2604,7 +2459,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
         (void)hipGetDevice(&dev);
         std::atomic<size_t>& have = reserved[dev & 63];
         if (lds > have.load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK, false, COMPACT, PIPE>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK, false, COMPACT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
             if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
             have.store(kLdsLimit, std::memory_order_relaxed);
@@ -2616,7 +2471,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
     if ((MASKED || COMPACT) && a.max_nodes > BLOCK)
         return fail(DGCN_ERR_LAUNCH, "k_fused: %d vertices per graph on %d threads in a variant that keeps a vertex per thread", a.max_nodes, BLOCK);
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT, PIPE>), dim3(B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
 }
 
@@ -2629,12 +2484,6 @@ static int fused_launch_t(FusedArgs& a, int B, size_t lds, const char* family, h
     bool big = ((lds > kLdsLimit / 2 || B <= ncu) && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
     if (const int want = opt(OPT_FUSED_BLOCK); want > 0)
         big = (want == kFusedBlockBig && a.max_nodes >= 128) || a.max_nodes > 16 * kMaxRowBlocks * (kFusedBlock / 64);
-    // the layer loop: transforms pulled by free waves (k_fused<.., PIPE>), or the lock-step loop (option "fused_pipe" = 0)
-    const bool pipe = opt(OPT_FUSED_PIPE) != 0;
-    a.pipe_own = opt(OPT_FUSED_PIPE) == 2 ? 1 : 0;
-    if (pipe)
-        return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig, COMPACT, true>(a, B, lds, family, s)
-                   : fused_launch_b<MASKED, GVALS, kFusedBlock, COMPACT, true>(a, B, lds, family, s);
     return big ? fused_launch_b<MASKED, GVALS, kFusedBlockBig, COMPACT>(a, B, lds, family, s)
                : fused_launch_b<MASKED, GVALS, kFusedBlock, COMPACT>(a, B, lds, family, s);
 }

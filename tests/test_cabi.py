@@ -124,7 +124,7 @@ def test_options_are_the_only_process_state_and_no_environment_is_read():
         for k, v in before.items():
             _lib.set_option(k, v)
     assert lib.dgcn_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.dgcn_last_error()
-    assert lib.dgcn_get_option(b"fused_pipe", None) == -1
+    assert lib.dgcn_get_option(b"fused_block", None) == -1
     assert lib.dgcn_set_option(None, 1) == -1
     csrc = os.path.join(ROOT, "distgcn_amd", "csrc")
     for f in sorted(os.listdir(csrc)):

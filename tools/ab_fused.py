@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of k_fused launch options (dgcn_set_option keys) in ONE process, interleaved rounds (cdna guide rule 24):
-   python tools/ab_fused.py "fused_pipe=0" "fused_pipe=1" ...   (each argument is one variant: key=value,key=value; "" = defaults)
+   python tools/ab_fused.py "fused_block=512" "fused_block=1024" ...   (each argument is one variant: key=value,key=value; "" = defaults)
    DGCN_AB_GRAPHS / DGCN_AB_KIND=er|ba pick the batch (default 500 ER(200, 0.1))"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

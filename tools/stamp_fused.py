@@ -17,12 +17,8 @@ _lib.set_option("diag_stamps", st.data_ptr())
 eng.solve(db, model, mode=MODE_FUSED); torch.cuda.synchronize()
 _lib.set_option("diag_stamps", 0)
 s = st.cpu().numpy().reshape(-1, 64).astype(np.float64) / 2400.0  # s_memtime ticks at the shader clock (2.4 GHz under load: tools/stamp_residual.py) -> us
-pipe = _lib.get_option("fused_pipe") != 0
-names = (["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "pulled transforms (sum; + layer 1's)", "Z1 stores + barrier Y (sum)",
-          "hidden A (sum)", "wait at barrier X (sum)", "last layer", "lgs", "tail"] if pipe else
-         ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
-          "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"])
-print("layer loop: %s" % ("transforms pulled by free waves (fused_pipe=1)" if pipe else "lock-step (fused_pipe=0)"))
+names = ["P0a rowptr", "P0b entries", "P0c order", "first T", "first A", "hidden T (sum)", "barrier after T (sum)",
+         "hidden A (sum)", "barrier after A (sum)", "last layer", "lgs", "tail"]
 print("phase clocks of wave 0, microseconds: mean over graphs / max")
 cols = list(range(12))
 for i, n in zip(cols, names):
