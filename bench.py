@@ -500,7 +500,10 @@ def roofline_objects(args, wl, fam_ms):
             # what paces the kernel (the SURVEY 8d figure below is an EQUIVALENT bandwidth: layer-by-layer bytes / time): the
             # in-LDS deep-stack kernels sit on the LDS array + the fp32 MFMA pipe; the one-layer kernels are chains of dependent
             # round trips (latency); only the stand-alone SpMM lines are HBM-bound
-            roofline = {"kernel": kname, "bound": "latency" if len(layers) == 1 else "lds+mfma",
+            # (`bound` names the roofline `achieved` / `peak` / `frac` are computed against - the contract's HBM roofline, SURVEY 8d;
+            # `paced_by` names what the kernel actually waits for, with its own peak and fraction in on_chip_view / fp32_matrix_view)
+            roofline = {"kernel": kname, "bound": "hbm", "paced_by": "latency" if len(layers) == 1 else "lds+mfma",
+                        "frac_is": "equivalent bandwidth: SURVEY 8d algorithmic bytes / launch time / HBM peak",
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_s * 1e6,
                         "algorithmic_bytes_per_launch": algo,
@@ -518,7 +521,7 @@ def roofline_objects(args, wl, fam_ms):
             if pmc:
                 roofline["on_chip_view"]["pmc_reference"] = pmc
         else:
-            roofline = {"kernel": dom, "bound": "latency", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": dom, "bound": "hbm", "paced_by": "latency", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": traffic, "avg_launch_us": avg_s * 1e6}
     kernel_us = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps} for k, v in fam_ms.items()}
     return roofline, kernel_us, traffic_db
@@ -988,7 +991,8 @@ def main(argv=None, workload_factory=None):
         step_kernel = {"fused_residual": "k_fused<residual graph>", "big_residual": "k_big / k_big2<residual graph> (any-size path)",
                        "wide_residual": "k_wide1 residual mode (any-size path, one- and two-layer models)"}[step_family]
         roofline = {"kernel": "%s (one launch = forward on every residual graph + %d greedy completions + pick)" % (step_kernel, args.beam),
-                    "bound": "latency" if step_family == "wide_residual" else "lds+mfma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+                    "bound": "hbm", "paced_by": "latency" if step_family == "wide_residual" else "lds+mfma",
+                    "frac_is": "equivalent bandwidth: SURVEY 8d algorithmic bytes / launch time / HBM peak", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
                     "traffic": c5_traffic,
                     "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE passes of tools/run_iterative.py --only rollout on this configuration (profiles/hbm_traffic.json): average over ALL launches of the step kernel in a search, the empty ones behind its end included (null: no pass taken for this configuration)", "avg_launch_us": avg_s * 1e6, "steps_per_search": search_steps, "launches_per_search": calls,
                     "empty_launches_per_search": n / max(args.steps, 1) - calls,

@@ -1955,6 +1955,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             rounds = 1;
             __syncthreads();
         }
+        if constexpr (CLUSTER) {
+            // A placement fault anywhere in this launch (a workgroup that never met its peers: its rows - and whatever was computed
+            // from them - are not valid): the step leaves this graph's search AS IT WAS.  The status word says so, the caller
+            // switches the variant off and takes the step again (Engine.solve_residual does): a search survives the fault.
+            // (Whoever reported the fault did so before handing anything on, so the word is set before this workgroup got here.)
+            __syncthreads();
+            const bool lost = threadIdx.x == 0 && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DGCN_FAULT_CLUSTER) != 0;
+            if (block_or<BLOCK>(lost, wflags)) return;
+            __syncthreads();
+        }
         if (tv < ng && was_alive) a.state[n0 + voff + tv] = st[tv];
         if (threadIdx.x == 0 && a.rounds) a.rounds[g] = rounds;
         if (threadIdx.x == 0 && a.progress) atomicAdd(a.progress, 1);
@@ -2290,7 +2300,8 @@ int cluster_setting() { return max(opt(OPT_FUSED_CLUSTER), -1); }
 // How many workgroups per graph (cluster variant of the kernel)?  0 = the ordinary one-workgroup-per-graph launch.
 // Only batches so small that CUs would stay idle otherwise: every workgroup of every graph must be resident at once
 // (they wait for each other), so graphs (in groups of 8) x K may not exceed the CU count.
-static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool off) {
+// `masked`: the residual-graph launch (a step of an iterative solver).
+static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap, bool off, bool masked = false) {
     if (off || !m->layers_host || m->num_layers < 2 || fused_wide_passes(m) > 1) return 0;
     if (fused_variant(max(b->max_nodes, 64), meta_cap) < 0 || b->max_nodes > kFusedBlock) return 0;  // (a vertex per thread in the last layer)
     const int blocks = (b->max_nodes + 15) / 16;
@@ -2318,7 +2329,12 @@ static int fused_cluster_k(const DgcnBatch* b, const DgcnModel* m, int meta_cap,
     // with option "fused_cluster" = 4 - 4 .. 7 %, for a launch that needs EVERY CU of the device free at once (64 x 4 workgroups,
     // one per CU: anything else running makes a workgroup wait for its peers until the spin bound reports a fault).
     // Forced K only: tools/runs/r05_gpu39.sh)
-    if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers || (blocks + K - 1) / K > 4)) return 0;
+    // (Round 6: the residual launch takes five to eight tiles per workgroup by itself when the batch leaves room for FOUR
+    // workgroups per graph - C5's 64 searches on 256 CUs: 10.7 -> 10.3 ms per search in round 5, forced; a search's steps are
+    // launched back to back on one stream, nothing else holds its CUs.  A launch whose workgroups do lose each other reports
+    // DGCN_FAULT_CLUSTER and the caller's recovery switches the variant off, as for every cluster launch.)
+    const int max_tiles = (masked && K >= 4) ? 8 : 4;
+    if (!forced && (K < 3 || blocks < 8 || m->num_layers < min_layers || (blocks + K - 1) / K > max_tiles)) return 0;
     return K;
 }
 
@@ -2331,7 +2347,7 @@ static size_t fused_cluster_bytes(const DgcnBatch* b, int K) {
 
 // Fills the launch arguments shared by both entry points; returns 0 or an error code.
 static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, size_t* lds, const char* who,
-                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool no_cluster = false) {
+                         void* workspace, size_t workspace_bytes, bool* gvals, hipStream_t stream, bool no_cluster = false, bool masked = false) {
     if (!fused_shape_ok(m))
         return fail(DGCN_ERR_UNSUPPORTED, "%s: the fused kernel handles F->c->...->c->1 layer stacks with c <= 32 "
                     "(and two-layer stacks F->c->1 with c <= 128) only", who);
@@ -2421,7 +2437,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace = static_cast<char*>(workspace) + need;
         workspace_bytes -= need;
     }
-    a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster);
+    a->cluster = fused_cluster_k(b, m, a->meta_cap, no_cluster, masked);
     if (a->cluster > 1) a->order = nullptr;
     a->cluster_inject = opt(OPT_TEST_CLUSTER_FAULT);
     if (a->cluster > 1) {
@@ -2532,7 +2548,7 @@ static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap
     if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
     need += (size_t)b->num_graphs * fused_rec_cap(meta_cap, b->max_nodes) * sizeof(uint2) + 256;  // entry records of the hidden aggregation
     need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
-    need += fused_cluster_bytes(b, m->layers_host ? fused_cluster_k(b, m, meta_cap, false) : 0);
+    need += fused_cluster_bytes(b, m->layers_host ? max(fused_cluster_k(b, m, meta_cap, false), fused_cluster_k(b, m, meta_cap, false, true)) : 0);
     return need;
 }
 
@@ -2704,7 +2720,8 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     g_compact_hook = CompactHook{};
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_batch: null argument");
-    if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: only [I, L] supports");
+    if (m->num_supports != 2 && m->num_supports != 3)
+        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_batch: [I, L] and [I, L, L.L] models only (num_supports = %d)", m->num_supports);
     if (b->num_graphs <= 0) return DGCN_OK;
     // graphs whose image does not fit a CU's LDS (or models wider than the fused kernel's 32): the any-size path, same results
     if (dgcn_solve_path(b, m) != 1) {
@@ -2759,7 +2776,8 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
                                          void* workspace, size_t workspace_bytes, void* stream) {
     if (!b || !m || !m->layers_host || !dinv_table || !state || !status)
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: null argument");
-    if (m->num_supports != 2) return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_residual_batch: only [I, L] supports");
+    if (m->num_supports != 2 && m->num_supports != 3)
+        return fail(DGCN_ERR_UNSUPPORTED, "dgcn_solve_residual_batch: [I, L] and [I, L, L.L] models only (num_supports = %d)", m->num_supports);
     if (greedy_mode < 0 || greedy_mode > 2) return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: greedy_mode %d", greedy_mode);
     if (greedy_mode == 2 && (beam < 1 || beam > 64 || !weights))
         return fail(DGCN_ERR_ARG, "dgcn_solve_residual_batch: rollout needs weights and 1 <= beam <= 64");
@@ -2831,7 +2849,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     bool gvals = false;
     // (with given scores no layer runs: nothing for a second workgroup to do)
     int rc = fused_prepare(b, m, &args, &lds, "dgcn_solve_residual_batch", workspace, workspace_bytes, &gvals, (hipStream_t)stream,
-                           (options & DGCN_RESIDUAL_SCORES_GIVEN) != 0);
+                           (options & DGCN_RESIDUAL_SCORES_GIVEN) != 0, true);
     if (rc) return rc;
     return tail(fused_launch(args, b->num_graphs, lds, "fused_residual", (hipStream_t)stream, true, gvals));
 }

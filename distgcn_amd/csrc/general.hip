@@ -519,6 +519,46 @@ static int model_in_dim(const DgcnModel* m) { return m->layers_host[0].in_dim; }
 // the forward workspace of the layer-by-layer path (dgcn_gcn_forward_workspace(b, m, 0))
 static size_t layered_bytes(const DgcnBatch* b, const DgcnModel* m) { return dgcn_gcn_forward_workspace(b, m, 0); }
 
+// ---- [I, L, L.L] models (max_degree = 2: gcn/utils.py:268-271, gcn/layers.py:199-208; the shipped ..cheb2.. checkpoints) ----
+// The second support is formed explicitly on the device (supports2.hip: SciPy's csr_matmat in float64, bit for bit) - the
+// count pass, a scan, the fill pass - into a slice of the workspace sized by what the HOST knows without a round trip: a row
+// of L.L has at most as many entries as its graph has vertices, so num_nodes * max_nodes entries always do.  The forward pass
+// is the layer-by-layer one (forward.hip: Z = H.[W0 | W1 | W2], out = (Z0 + L.Z1) + L2.Z2), then the greedy step as for
+// every other model: one C call, nothing returns to the host.
+static size_t poly_cap2(const DgcnBatch* b) {
+    return (size_t)std::max(b->num_nodes, 1) * (size_t)std::max(b->max_nodes, 1);
+}
+static bool poly_fits(const DgcnBatch* b) { return poly_cap2(b) < (size_t)0x7fffffff; }  // (int32 row pointers)
+
+// the compact batch's ADJACENCY out of its support (k_res_fill writes L, diagonal first): what supports2.hip reads.
+// arow2[v] = lrow[v] - (diagonal entries in front of row v); rows past the last vertex are empty in both.
+__global__ __launch_bounds__(256) void k_lap_to_adj(const int32_t* __restrict__ lrow, const int32_t* __restrict__ lcol,
+                                                    const int32_t* __restrict__ gptr2, int B, int num_nodes,
+                                                    int32_t* __restrict__ arow2, int32_t* __restrict__ acol2) {
+    const int live = gptr2[B];
+    for (int v = blockIdx.x * 256 + threadIdx.x; v <= num_nodes; v += gridDim.x * 256) {
+        const int rs = lrow[v];
+        arow2[v] = rs - min(v, live);
+        if (v < live) {
+            const int re = lrow[v + 1], as = rs - v;
+            for (int j = rs + 1; j < re; ++j) acol2[as + (j - rs - 1)] = lcol[j];
+        }
+    }
+}
+
+// L.L of batch `ab` (adjacency in ab->row_ptr / col_idx) into (l2row, l2col, l2val); the descriptor for the forward pass
+static int poly_second_support(const DgcnBatch* ab, const double* dinv_table, int32_t table_len, int32_t* l2row, int32_t* l2col,
+                               float* l2val, int32_t* status, DgcnCsr* out, hipStream_t s) {
+    if (hipMemsetAsync(l2row, 0, ((size_t)ab->num_nodes + 1) * sizeof(int32_t), s) != hipSuccess)  // (rows no graph owns count 0)
+        return fail(DGCN_ERR_LAUNCH, "dgcn_solve_batch: memset of the second support's row counts failed");
+    if (int rc = dgcn_supports2_count_batch(ab, dinv_table, table_len, l2row, status, s)) return rc;
+    if (int rc = dgcn_supports2_fill_batch(ab, dinv_table, table_len, l2row, l2col, l2val, status, s)) return rc;
+    // (nnz is a hint for the SpMM's LDS carve-up only - a denser tile reads its rows from global memory, same chains)
+    const size_t hint = std::min(poly_cap2(ab), (size_t)8 * ((size_t)ab->num_nodes + (size_t)std::max(ab->num_edges, 0)));
+    *out = DgcnCsr{ab->num_nodes, (int32_t)hint, 0, l2row, l2col, l2val};
+    return DGCN_OK;
+}
+
 size_t general_workspace(const DgcnBatch* b, const DgcnModel* m) {
     const size_t n = (size_t)std::max(b->num_nodes, 1), e = (size_t)std::max(b->num_edges, 0), B = (size_t)std::max(b->num_graphs, 1);
     size_t need = 256;                                                   // alignment slack
@@ -530,13 +570,16 @@ size_t general_workspace(const DgcnBatch* b, const DgcnModel* m) {
     need += al256(n * 8);                                                // priorities
     need += al256(layered_bytes(b, m)) + al256(std::max(big_workspace(b, m), big2_workspace(b, m)));
     need += al256(B * kMaxBeam * 4) + al256((size_t)kMaxBeam * n) + al256((size_t)kMaxBeam * B * 4) + al256((size_t)kMaxBeam * B * 8);
+    if (m->num_supports == 3)  // the second support, and the compact batch's adjacency it is formed from
+        need += 2 * al256((n + 1) * 4) + al256(e * 4 + 4) + al256(poly_cap2(b) * 4) + al256(poly_cap2(b) * 4);
     return need;
 }
 
 // which shapes the general path takes: [I, L] models of any widths (the layer-by-layer kernels), one score per vertex,
 // graphs whose greedy-search state (14 bytes per vertex) fits one workgroup's LDS
 int general_takes(const DgcnBatch* b, const DgcnModel* m) {
-    if (!b || !m || !m->layers_host || m->num_supports != 2 || m->num_layers < 1) return 0;
+    if (!b || !m || !m->layers_host || (m->num_supports != 2 && m->num_supports != 3) || m->num_layers < 1) return 0;
+    if (m->num_supports == 3 && !poly_fits(b)) return 0;
     if (m->layers_host[m->num_layers - 1].out_dim != 1) return 0;
     for (int l = 0; l < m->num_layers; ++l) {
         const DgcnLayer& L = m->layers_host[l];
@@ -582,7 +625,16 @@ int general_solve(const DgcnBatch* b, const DgcnModel* m, const double* dinv_tab
     int rc = dgcn_supports_batch(b, dinv_table, table_len, lrow, lcol, lval, status, s);
     if (rc) return rc;
     DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, lrow, lcol, lval};
-    const DgcnCsr* sup[1] = {&L};
+    DgcnCsr L2 = {};
+    const DgcnCsr* sup[2] = {&L, &L2};
+    if (m->num_supports == 3) {  // [I, L, L.L]
+        int32_t* l2row = w.take<int32_t>(n + 1);
+        int32_t* l2col = w.take<int32_t>(poly_cap2(b));
+        float* l2val = w.take<float>(poly_cap2(b));
+        if (!w.ok) return fail(DGCN_ERR_WORKSPACE, "dgcn_solve_batch: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu",
+                               general_workspace(b, m), workspace_bytes);
+        if ((rc = poly_second_support(b, dinv_table, table_len, l2row, l2col, l2val, status, &L2, s))) return rc;
+    }
     if ((rc = big ? big_forward(b, &L, m, X, x_const, sc, fws, bws, status, s)
               : big2 ? big2_forward(b, &L, m, X, x_const, sc, fws, bws, status, s) : layered_forward(b, sup, m, X, x_const, sc, fws, s))) return rc;
     return lgs_launch_common(b, nullptr, 0, sc, (predict_mwis && weights) ? weights : nullptr, nullptr, 1, 0, state, rounds, nullptr,
@@ -624,6 +676,15 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
     const bool big = !big2 && big_takes(b, m) != 0;
     char* bws = big ? w.take<char>(big_workspace(b, m)) : big2 ? w.take<char>(big2_workspace(b, m)) : nullptr;
     a.cid = w.take<int32_t>(B * kMaxBeam);
+    int32_t *arow2 = nullptr, *acol2 = nullptr, *l2row = nullptr, *l2col = nullptr;
+    float* l2val = nullptr;
+    if (m->num_supports == 3) {
+        arow2 = w.take<int32_t>(n + 1);
+        acol2 = w.take<int32_t>(e + 1);
+        l2row = w.take<int32_t>(n + 1);
+        l2col = w.take<int32_t>(poly_cap2(b));
+        l2val = w.take<float>(poly_cap2(b));
+    }
     uint8_t* inst_state = nullptr;
     int32_t* inst_rounds = nullptr;
     double* inst_totals = nullptr;
@@ -691,7 +752,21 @@ int general_residual(const DgcnBatch* b, const DgcnModel* m, const double* dinv_
         cb.row_ptr = nullptr;
         cb.col_idx = nullptr;
         DgcnCsr L = {b->num_nodes, (int32_t)(n + e), b->max_graph_edges + b->max_nodes, a.lrow, a.lcol, a.lval};
-        const DgcnCsr* sup[1] = {&L};
+        DgcnCsr L2 = {};
+        const DgcnCsr* sup[2] = {&L, &L2};
+        if (m->num_supports == 3) {
+            // [I, L, L.L] on the residual graph: its adjacency out of the support k_res_fill wrote, then L.L as for a full batch
+            {
+                TimedLaunch t("general_prepare", s);
+                const int blocks = (int)std::min<size_t>((n + 256) / 256, 1024);
+                DGCN_LAUNCH(t, k_lap_to_adj, dim3(blocks), dim3(256), 0, s, a.lrow, a.lcol, a.gptr2, b->num_graphs, b->num_nodes, arow2, acol2);
+                if (int rc = check_launch("k_lap_to_adj")) return rc;
+            }
+            DgcnBatch ab = cb;
+            ab.row_ptr = arow2;
+            ab.col_idx = acol2;
+            if (int rc = poly_second_support(&ab, dinv_table, table_len, l2row, l2col, l2val, status, &L2, s)) return rc;
+        }
         if (int rc = big ? big_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s)
                      : big2 ? big2_forward(&cb, &L, m, a.Xc, x_const, sc, fws, bws, status, s) : layered_forward(&cb, sup, m, a.Xc, x_const, sc, fws, s))
             return rc;

@@ -493,7 +493,14 @@ class Engine:
                     done = True
                     break
                 steps += 1
-            if words[k] & ~words[k + 1]:
+            fresh = words[k] & ~words[k + 1]
+            if fresh == 16:
+                # a placement fault of the several-workgroups-per-graph launch (automatic for searches on small batches): the
+                # step left the searches it touched as they were (fused.hip) - switch the variant off, clear the bit, go on
+                self.lib.dgcn_set_cluster(0)
+                out["status"].bitwise_and_(~16)
+                done = False
+            elif fresh:
                 done = True
             group = min(2 * group, 32)  # (a search of ~100 steps: 6 read-backs instead of 14; at most 31 empty launches at its end)
         return {"state": state, "steps": steps, "status": out["status"],

@@ -612,7 +612,7 @@ def test_bench_contract(force_dist):
     rf = d["roofline"]
     # (the C3 launch never leaves the chip: what paces k_fused is the LDS array + the fp32 MFMA pipe; `achieved` stays the
     # SURVEY 8d equivalent bandwidth against the HBM peak - round-4 review, hygiene item)
-    assert rf["bound"] == "lds+mfma" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert rf["bound"] == "hbm" and rf["paced_by"] == "lds+mfma" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"  # (frac belongs to `bound`)
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0.05 < rf["frac"] < 1.0
     assert d["value"] == pytest.approx(500 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
     cb = d["cpu_baseline"]
@@ -1229,6 +1229,36 @@ def test_iterative_solvers_cluster_variant_changes_nothing(engine, which, monkey
         for mode in modes[1:]:
             for a, b in zip(got["0"], got[mode]):
                 assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), (which, mode, hb.num_nodes)
+
+
+@pytest.mark.parametrize("which", ["cit", "rollout"])
+def test_iterative_search_survives_a_cluster_fault(engine, which, cluster_switch):
+    """Round 6: the residual launch takes the several-workgroups-per-graph form BY ITSELF on small batches (two 500-vertex graphs:
+    K = 4, eight tiles per workgroup - C5's regime).  A placement fault in such a launch (injected: option test_cluster_fault)
+    must not cost the search: the faulted step leaves every search it touched as it was (the state is written only when no
+    workgroup of the launch has reported a fault), Engine.solve_residual switches the variant off, clears the bit and goes on -
+    same final sets as with the variant off from the start, and the variant IS off afterwards."""
+    from distgcn_amd import _lib, datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    lib = _lib.load()
+    agent = DQNAgent(_flags(num_layer=12), seed=4)
+    agent.device_iterative = True
+    hb = datagen.er_batch(2, 500, 0.02, first_index=4410)
+    adjs = [hb.scipy_graph(g) for g in range(hb.num_graphs)]
+    ws = [hb.weights[n0:n1] for n0, n1 in hb.graph_slices()]
+    cluster_switch(0)
+    want = agent.solve_iterative_batch(adjs, ws, which, b=8)
+    cluster_switch(None)  # automatic: the residual launch of this batch is a cluster launch
+    auto = agent.solve_iterative_batch(adjs, ws, which, b=8)
+    assert int(lib.dgcn_get_cluster()) == -1  # (no fault: still automatic)
+    _lib.set_option("test_cluster_fault", 1)
+    try:
+        got = agent.solve_iterative_batch(adjs, ws, which, b=8)
+    finally:
+        _lib.set_option("test_cluster_fault", 0)
+    assert int(lib.dgcn_get_cluster()) == 0  # the fault was seen (so the automatic choice WAS a cluster launch) and answered
+    for a, b, c in zip(want, auto, got):
+        assert a[0] == b[0] == c[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])) and np.array_equal(np.asarray(a[1]), np.asarray(c[1])), which
 
 
 def test_host_solver_compact_transfer(engine, monkeypatch):

@@ -162,3 +162,31 @@ def test_big2_residual_step_in_one_launch_agrees_with_the_compaction_path(engine
         else:
             assert np.array_equal(a[k], b[k]), k
     assert a["cit_steps"][0] > 100
+
+
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout"])
+def test_big2_iterative_solvers_restatement_forward(engine, which):
+    """Round-5 review item 5: k_big2<RESID> (977 .. 1 920 vertices) held against the oracle's solvers fed with the RESTATEMENT's
+    own float32 forward (oracle/ref_numpy._default_scores_fn: the NumPy restatement of gcn/layers.py:189-216,
+    mwis_gdpg_call.py:211-216) - one hop from the reference, not two through the twin.  One ER(1 200, 0.005) graph, l = 3,
+    complete dit / cit / rollout (b = 4) searches on the device.  (Chosen on the CPU so that no decision lies inside the two
+    forwards' rounding distance: the oracle's solvers select the same 440 / 470 / 467 vertices with either forward.)"""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from distgcn_amd.runtime_config import FLAGS
+    from oracle import ref_numpy as orc
+    n, p = 1200, 0.005
+    agent = DQNAgent(FLAGS.copy(feature_size=1, hidden1=32, num_layer=3, diver_num=1, max_degree=1, predict="mwis"), seed=21)
+    fn = orc._default_scores_fn(agent.model.layers)
+    rng = np.random.default_rng(20230800 + n)
+    indptr, indices = datagen.er_graph(n, p, rng)
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    w = rng.random(n)
+    got = agent.solve_iterative_batch([adj], [w], which, b=4)
+    assert got is not None
+    want = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit}[which](fn, adj, w) if which != "rollout" else \
+        orc.solve_mwis_rollout(fn, adj, w, b=4)
+    assert len(want[0]) == {"dit": 440, "cit": 470, "rollout": 467}[which]
+    assert got[0][0] == want[0], which
+    assert np.allclose(got[0][1], want[1], rtol=1e-12)

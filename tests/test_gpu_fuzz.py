@@ -1,6 +1,7 @@
 """Randomised parity: random batch shapes x model shapes through the fused path (ordinary launch, cluster variant,
 largest-first dispatch, global-memory entry values - whatever the library picks for the shape) against the CPU twin,
-bit for bit.  DGCN_FUZZ_CASES sets the number of cases (default 16: a few seconds)."""
+bit for bit.  DGCN_FUZZ_CASES sets the number of cases per test (default 100: about a minute for the file; profiles/r05_fuzz_1000.txt,
+r06_fuzz_1000.txt: 1 000 each)."""
 import os
 
 import numpy as np
@@ -14,7 +15,7 @@ def test_random_shapes_match_the_twin(engine):
     from distgcn_amd.batch import HostBatch
     from distgcn_amd.engine import DeviceModel
     from oracle import ctwin
-    cases = int(os.environ.get("DGCN_FUZZ_CASES", "16"))
+    cases = int(os.environ.get("DGCN_FUZZ_CASES", "100"))
     rng = np.random.default_rng(2026)
     for case in range(cases):
         layers_n = int(rng.choice([1, 2, 3, 8, 12, 20]))
@@ -64,7 +65,7 @@ def test_random_calls_through_the_host_solver_match_the_twin(engine):
     from distgcn_amd.engine import DeviceModel
     from distgcn_amd.serving import HostSolver
     from oracle import ctwin
-    calls = int(os.environ.get("DGCN_FUZZ_CASES", "16")) * 4
+    calls = int(os.environ.get("DGCN_FUZZ_CASES", "100")) * 4
     rng = np.random.default_rng(77)
     solvers = {}
     for call in range(calls):
@@ -119,7 +120,7 @@ def test_random_shapes_down_the_any_size_path_match_the_twin(engine):
     from oracle import ctwin
     lib = _lib.load()
     initial = int(lib.dgcn_get_general())
-    cases = int(os.environ.get("DGCN_FUZZ_CASES", "16"))
+    cases = int(os.environ.get("DGCN_FUZZ_CASES", "100"))
     rng = np.random.default_rng(4040)
     try:
         lib.dgcn_set_general(1)
@@ -183,7 +184,7 @@ def test_random_searches_with_and_without_the_tail(engine):
     from distgcn_amd.engine import DeviceModel
     lib = _lib.load()
     initial = int(lib.dgcn_get_general())
-    cases = int(os.environ.get("DGCN_FUZZ_CASES", "16"))
+    cases = int(os.environ.get("DGCN_FUZZ_CASES", "100"))
     rng = np.random.default_rng(6464)
     try:
         for case in range(cases):
@@ -235,3 +236,79 @@ def test_random_searches_with_and_without_the_tail(engine):
                                                  int((st != ref).sum()))
     finally:
         lib.dgcn_set_general(initial)
+
+
+def _hub_graph(n, hubs, p, rng):
+    """ER(n, p) plus hubs [(vertex, degree), ..]: rows far longer than every other row of their sixteen-row tile."""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    ip, ix = datagen.er_graph(n, p, rng)
+    a = sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(n, n)).tolil()
+    for v, d in hubs:
+        others = np.setdiff1d(np.arange(n), [v])
+        for u in rng.choice(others, size=min(d, n - 1), replace=False):
+            a[v, u] = 1.0
+            a[u, v] = 1.0
+    a = a.tocsr()
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def test_random_hub_rows_and_many_tile_graphs_match_the_twin(engine):
+    """The class of round 4's silent wrong-sum bug (rows of 576+ entries in k_big's row-order counting sort) and of round 5's
+    register-indexed tiles: random graphs of 520 .. 1 920 vertices - k_big up to 976, k_big2 with eight / twelve / FIFTEEN
+    tiles per wave beyond - carrying hub rows of 576 .. n - 1 entries (several hubs, some sharing a tile, some at the tile's
+    last row), next to small graphs in the same batch; deep stacks of width 32 and narrower (zero-padded onto the same
+    kernels), biases, explicit input features now and then.  Plain solve against the CPU twin, bit for bit.
+    (A quarter of DGCN_FUZZ_CASES cases: a 1 900-vertex twin forward is not free.)"""
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    cases = max(1, int(os.environ.get("DGCN_FUZZ_CASES", "100")) // 4)
+    rng = np.random.default_rng(57600)
+    for case in range(cases):
+        layers_n = int(rng.choice([3, 3, 4, 5, 8]))
+        hidden = int(rng.choice([32, 32, 32, 16, 5]))
+        fsize = int(rng.choice([1, 1, 1, 3]))
+        layers = datagen.random_model(layers_n, hidden, feature_size=fsize, bias=bool(rng.integers(2)),
+                                      last_act=str(rng.choice(["linear", "leaky_relu"])), seed=900 + case)
+        ps, cs, ws = [], [], []
+        n = int(rng.choice([520, 600, 640, 900, 976, 977, 1024, 1290, 1536, 1537, 1700, 1900, 1920]))
+        nh = int(rng.integers(1, 4))
+        hubs = []
+        for h in range(nh):
+            v = int(rng.choice([0, 15, 16, 17, n // 2, n - 17, n - 16, n - 1])) if rng.random() < 0.6 else int(rng.integers(n))
+            if hubs and rng.random() < 0.4:
+                v = min(n - 1, (hubs[0][0] // 16) * 16 + int(rng.integers(16)))  # a second hub in the first one's tile
+            hubs.append((v, int(rng.integers(576, n))))
+        ip, ix = _hub_graph(n, hubs, float(rng.choice([2.0, 6.0, 12.0])) / n, rng)
+        ps.append(ip); cs.append(ix); ws.append(rng.random(n))
+        for _ in range(int(rng.integers(0, 4))):  # company: small and medium graphs, one of them maybe without edges
+            m = int(rng.choice([1, 16, 17, 200, 513, 700]))
+            g = datagen.er_batch(1, m, min(0.9, float(rng.choice([0.0, 4.0, 10.0])) / max(m, 2)), first_index=int(rng.integers(1 << 20)))
+            ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
+        order = rng.permutation(len(ps))
+        hb = HostBatch.from_csr_lists([ps[i] for i in order], [cs[i] for i in order], [ws[i] for i in order])
+        model = DeviceModel(layers, engine.device)
+        db = engine.upload(hb)
+        assert engine.solve_path(db, model) == 2
+        X = None
+        if rng.random() < 0.25:
+            import torch
+            X = torch.from_numpy(rng.random((hb.num_nodes, fsize)).astype(np.float32)).to(engine.device)
+        out = engine.solve_buffers(db, True)
+        engine.solve_fused(db, model, out=out, want_scores=True, X=X)
+        got = engine.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
+        assert got["status"] == 0, (case, got["status"])
+        if X is None:
+            want = ctwin.solve(hb, layers)
+        else:
+            lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+            sc = ctwin.forward(lap, layers, hb.num_nodes, X=X.cpu().numpy())
+            r = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, sc[:, 0].astype(np.float64) * hb.weights, sum_weights=hb.weights)
+            want = {"scores": sc, "state": r["state"], "rounds": r["rounds"], "totals": r["totals"]}
+        tag = (case, layers_n, hidden, fsize, X is not None, n, hubs, hb.num_graphs)
+        assert np.array_equal(got["scores"].ravel().view(np.uint32), np.asarray(want["scores"], np.float32).ravel().view(np.uint32)), tag
+        assert np.array_equal(got["state"], want["state"]) and np.array_equal(got["rounds"], want["rounds"]), tag
+        assert np.allclose(got["totals"], want["totals"], rtol=1e-12, atol=0), tag

@@ -638,3 +638,77 @@ def test_narrow_deep_stacks_iterative_solvers_agree_with_the_layer_by_layer_path
         solver = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit, "rollout": orc.solve_mwis_rollout}[name]
         want, _ = solver(fn, mats[g], ws[g], 16) if name == "rollout" else solver(fn, mats[g], ws[g])
         assert set(np.flatnonzero(got["padded"][n0:n1] == 1).tolist()) == set(int(v) for v in want), name
+
+
+def _twin_scores_fn_poly(layers):
+    """scores_fn for the oracle's solvers on an [I, L, L.L] model: the twin's forward on the residual graph's own L and L.L."""
+    from distgcn_amd.batch import HostBatch
+    from oracle import ctwin
+    import scipy.sparse as sp
+
+    def fn(adj_nn, wts_nn):
+        a = sp.csr_matrix(adj_nn)
+        a.sort_indices()
+        hb = HostBatch.from_csr_lists([a.indptr.astype(np.int64)], [a.indices.astype(np.int64)])
+        lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        lap2 = ctwin.supports2(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+        return ctwin.forward([lap, lap2], layers, hb.num_nodes)
+    return fn
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (3, 8), (4, 32)])
+def test_three_support_models_in_the_solve_entry_points(engine, golden, all_models, shape):
+    """Round-5 review item 4b.  [I, L, L.L] models (max_degree = 2: gcn/utils.py:268-271, gcn/layers.py:199-208; the two shipped
+    ..cheb2.. checkpoints are c1_l1 and c1_l2) go through dgcn_solve_batch / dgcn_solve_residual_batch like every other model:
+    L.L formed on the device into a workspace slice bounded on the host (no read-back between the count and the fill pass),
+    the layer-by-layer forward, the greedy step - ONE C call, nothing composed in Python.  Plain solve: scores bit-equal to
+    the twin's forward on the twin's L and L.L, sets / rounds / totals equal to the twin's search; shipped weights for the
+    two shipped shapes, random ones for deeper / wider stacks; ragged fixture graphs with an isolated vertex and zero weights.
+    Iterative solvers (dit / cit / rollout): final sets equal to the oracle's solvers fed with the twin's scores."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    from oracle import ref_numpy as orc
+    num_layer, hidden = shape
+    shipped = {(1, 1): "result_IS4SAT_deep_ld1_c1_l1_cheb2_diver1_mwis_dqn", (2, 1): "result_IS4SAT_deep_ld1_c1_l2_cheb2_diver1_mwis_dqn"}
+    layers = all_models.layers(shipped[shape]) if shape in shipped else datagen.random_model(num_layer, hidden, bias=True, seed=77, num_supports=3)
+    assert len(layers[0]["weights"]) == 3
+    ids = [0, 3, 9, 12, 5]
+    hb = golden.host_batch(ids)
+    sl = hb.graph_slices()
+    hb.weights[sl[2][0]:sl[2][0] + 4] = 0.0
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    assert not engine.solve_supported(db, dm) and engine.solve_path(db, dm) == 2
+    lap = ctwin.supports(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    lap2 = ctwin.supports2(hb.graph_ptr, hb.row_ptr, hb.col_idx)[:3]
+    want_sc = ctwin.forward([lap, lap2], layers, hb.num_nodes)
+    prio = want_sc[:, 0].astype(np.float64) * hb.weights
+    want = ctwin.lgs(hb.graph_ptr, hb.row_ptr, hb.col_idx, prio, sum_weights=hb.weights, want_stats=False)
+    engine.timing(True)
+    r = engine.solve_fused(db, dm)
+    engine.torch.cuda.synchronize()
+    engine.timing(False)
+    engine.check_status(r["status"])
+    assert np.array_equal(r["scores"].cpu().numpy().ravel().view(np.uint32), want_sc.ravel().view(np.uint32))
+    assert np.array_equal(r["state"].cpu().numpy(), want["state"]) and np.array_equal(r["rounds"].cpu().numpy(), want["rounds"])
+    assert np.allclose(r["totals"].cpu().numpy(), want["totals"], rtol=1e-12)
+    assert engine.timing_read("supports2_count")[1] == 1 and engine.timing_read("supports2_fill")[1] == 1
+    # the composition in Python that this replaces (forward through the poly entry + dgcn_lgs_batch): same bits
+    old = engine.solve(db, dm, mode=0)
+    assert np.array_equal(old["scores"].cpu().numpy().ravel().view(np.uint32), r["scores"].cpu().numpy().ravel().view(np.uint32))
+    assert np.array_equal(old["state"].cpu().numpy(), r["state"].cpu().numpy())
+    fn = _twin_scores_fn_poly(layers)
+    for name, kw in (("dit", dict(greedy=engine.GREEDY_ROUNDS, max_rounds=1)), ("cit", dict(greedy=engine.GREEDY_CENTRAL)),
+                     ("rollout", dict(greedy=engine.GREEDY_ROLLOUT, beam=16))):
+        state = torch.zeros(hb.num_nodes, dtype=torch.uint8, device=engine.device)
+        res = engine.solve_residual(db, dm, state, **kw)
+        engine.check_status(res["status"])
+        st = state.cpu().numpy()
+        for g in (1, 4):  # two of the graphs against the oracle's pure-Python solver
+            n0, n1 = sl[g]
+            adj, w = _scipy(hb, g), hb.weights[n0:n1]
+            solver = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit, "rollout": orc.solve_mwis_rollout}[name]
+            sel, _ = solver(fn, adj, w, 16) if name == "rollout" else solver(fn, adj, w)
+            assert set(np.flatnonzero(st[n0:n1] == 1).tolist()) == set(int(v) for v in sel), (name, g)

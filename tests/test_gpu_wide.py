@@ -243,6 +243,31 @@ def test_one_layer_iterative_solvers_restatement_forward(engine, which, n, p):
     assert np.allclose(got[0][1], want[1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("which", ["dit", "cit", "rollout"])
+def test_two_layer_iterative_solvers_restatement_forward(engine, which):
+    """Round-5 review item 5: the TWO-layer form of k_wide1 (F -> 32 -> 1 on 900 vertices, every residual step one launch)
+    against the oracle's solvers fed with the restatement's own float32 forward - one hop from the reference.  (Chosen on the
+    CPU: the oracle's solvers select the same 259 / 275 / 269 vertices with the restatement's and with the twin's forward.)"""
+    import scipy.sparse as sp
+    from distgcn_amd import datagen
+    from distgcn_amd.mwis_gdpg_call import DQNAgent
+    from oracle import ref_numpy as orc
+    n, p = 900, 0.01
+    agent = DQNAgent(_flags(num_layer=2, hidden1=32), seed=21)
+    fn = orc._default_scores_fn(agent.model.layers)
+    rng = np.random.default_rng(20230800 + n)
+    indptr, indices = datagen.er_graph(n, p, rng)
+    adj = sp.csr_matrix((np.ones(indices.size), indices, indptr), shape=(n, n))
+    w = rng.random(n)
+    got = agent.solve_iterative_batch([adj], [w], which, b=4)
+    assert got is not None
+    want = {"dit": orc.solve_mwis_dit, "cit": orc.solve_mwis_cit}[which](fn, adj, w) if which != "rollout" else \
+        orc.solve_mwis_rollout(fn, adj, w, b=4)
+    assert len(want[0]) == {"dit": 259, "cit": 275, "rollout": 269}[which]
+    assert got[0][0] == want[0], which
+    assert np.allclose(got[0][1], want[1], rtol=1e-12)
+
+
 def test_wireless_joint_graph_900_one_layer(engine):
     """The multi-channel launcher's own shape and depth (bash/twc_major_wireless_mc_test.sh:3: num_layer=1, num_channels=3):
     the slot loop on two joint 3 x 300 graphs with DGCN-LGS and DGCN-LGS-it against the per-instance restatement."""
