@@ -528,10 +528,10 @@ def roofline_objects(args, wl, fam_ms):
 
 
 def fused_pmc_reference(args, dom):
-    """SQ counters of the C3 launch from a PMC pass of the same kernel build (profiles/r05_fused_pmc.txt: per-launch sums
+    """SQ counters of the C3 launch from a PMC pass of the same kernel build (profiles/r06_fused_pmc.txt: per-launch sums
     over the chip), as fractions: how long the LDS was active, how much of that was bank conflicts, how busy the MFMA pipes
     were.  Only for the configuration the pass was taken on; not measured in this run."""
-    path = os.path.join(ROOT, "profiles", "r05_fused_pmc.txt")  # retaken on the round-5 build (tools/collect_profiles_r05.sh)
+    path = os.path.join(ROOT, "profiles", "r06_fused_pmc.txt")  # retaken on the round-6 build (tools/collect_profiles_r06.sh)
     if not os.path.isfile(path):
         return None
     if dom != "fused_solve" or args.family != "er" or (args.nodes, args.graphs, args.layers) != (200, 500, 20) or not os.path.isfile(path):
@@ -544,7 +544,7 @@ def fused_pmc_reference(args, dom):
     need = ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA")
     if any(k not in c for k in need):
         return None
-    return {"source": "profiles/r05_fused_pmc.txt (rocprofv3 --pmc passes of this kernel on this configuration, retaken on the round-5 build; not measured in this run)",
+    return {"source": "profiles/r06_fused_pmc.txt (rocprofv3 --pmc passes of this kernel on this configuration, retaken on the round-6 build; not measured in this run)",
             "lds_active_frac_of_cu_busy_cycles": c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"],
             "lds_bank_conflict_frac_of_lds_active": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
             "mfma_busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]),

@@ -769,9 +769,10 @@ __global__ __launch_bounds__(kB2Block) void k_big2(BigArgs a) {
         unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(red + kB2Block);  // [4]
         int* rol = reinterpret_cast<int*>(acc64 + 4);                                   // [max_nodes + 1]
         uint8_t* st = reinterpret_cast<uint8_t*>(rol + ((a.max_nodes + 1 + 3) & ~3));
-        uint8_t* nw = st + ((a.max_nodes + 16) & ~15);  // (st has a slot [ng]: where a column outside the graph points, state 3)
+        // (st and nw have a slot [ng] - max_nodes + 1 bytes rounded up, as b2_lgs_lds() sizes them: where a column outside the graph points, state 3)
+        uint8_t* nw = st + ((a.max_nodes + 16) & ~15);
         // the graph's columns as 16-bit local ids in what is left of the Z1h space, when they fit: the rounds then read LDS only
-        uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 15) & ~15));
+        uint16_t* cl = reinterpret_cast<uint16_t*>(nw + ((a.max_nodes + 16) & ~15));
         const int cl_cap = (int)(((size_t)a.max_nodes * 64 - (size_t)(reinterpret_cast<unsigned char*>(cl) - b2_lds)) / 2);
         const int e0 = a.arow[n0], e1 = a.arow[n0 + ng];
         const bool cols_lds = (e1 - e0) <= cl_cap;
@@ -1002,7 +1003,7 @@ static int b2_ahead_rounds() {  // option "wide_ahead" = 0: lgs_rounds.h's three
 }
 
 static size_t b2_lgs_lds(int max_nodes) {
-    const size_t pad = (size_t)((max_nodes + 15) & ~15);
+    const size_t pad = (size_t)((max_nodes + 16) & ~15);  // (state / winner bytes: max_nodes + 1 - the sentinel slot [ng] -, rounded up; the kernel carves the same)
     return big_lgs_base(max_nodes) + (size_t)max_nodes * 8 + kB2Block * 8 + 4 * 8 + (size_t)((max_nodes + 1 + 3) & ~3) * 4 + 2 * pad + 16;
 }
 

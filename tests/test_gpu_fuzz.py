@@ -281,7 +281,7 @@ def test_random_hub_rows_and_many_tile_graphs_match_the_twin(engine):
             v = int(rng.choice([0, 15, 16, 17, n // 2, n - 17, n - 16, n - 1])) if rng.random() < 0.6 else int(rng.integers(n))
             if hubs and rng.random() < 0.4:
                 v = min(n - 1, (hubs[0][0] // 16) * 16 + int(rng.integers(16)))  # a second hub in the first one's tile
-            hubs.append((v, int(rng.integers(576, n))))
+            hubs.append((v, int(rng.integers(min(576, n // 2), n))))  # (520-vertex graphs: hubs of 260 .. 519 entries)
         ip, ix = _hub_graph(n, hubs, float(rng.choice([2.0, 6.0, 12.0])) / n, rng)
         ps.append(ip); cs.append(ix); ws.append(rng.random(n))
         for _ in range(int(rng.integers(0, 4))):  # company: small and medium graphs, one of them maybe without edges

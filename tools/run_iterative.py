@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--p", type=float, default=0.02)
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--beam", type=int, default=16)
+    ap.add_argument("--hidden", type=int, default=32, help="hidden width (narrower than 32: zero-padded onto the one-launch kernels beyond 512 vertices)")
     ap.add_argument("--host", type=int, default=1)
     ap.add_argument("--only", default=None, help="run this solver only (dit / cit / rollout)")
     ap.add_argument("--family", choices=["er", "mc"], default="er", help="mc: joint 3-channel conflict graphs of n // 3 flows (bench.multichannel_batch)")
@@ -37,7 +38,7 @@ def main():
         hb = datagen.multichannel_batch(args.graphs, args.n // 3, args.p)
     else:
         hb = datagen.er_batch(args.graphs, args.n, args.p)
-    flags = FLAGS.copy(feature_size=1, hidden1=32, num_layer=args.layers, diver_num=1, max_degree=1, predict="mwis")
+    flags = FLAGS.copy(feature_size=1, hidden1=args.hidden, num_layer=args.layers, diver_num=1, max_degree=1, predict="mwis")
     agent = DQNAgent(flags, seed=3)
     dm = agent.model.device_model(eng)
     db = eng.upload(hb)
