@@ -2640,9 +2640,20 @@ static bool narrow_describe(const DgcnModel* m, float* base, NarrowModel& nm) {
     nm.m.layers_host = nm.layers;
     return true;
 }
-// ... and only where that is what puts it on a one-launch kernel (layer by layer the narrow model is the cheaper one)
-static bool narrow_wants_pad(const DgcnBatch* b, const DgcnModel* m, float* base, NarrowModel& nm) {
+// ... and only where that is what puts it on a one-launch kernel AND the launch pays (layer by layer the narrow model is the
+// cheaper one).  Measured, kernels per call, padded against the chain (profiles/r06_narrow_and_poly.txt: joint 3 x 300 / 3 x 500
+// graphs, c16): k_big (up to 976 vertices) is never behind - 32 graphs 331 / 342 us, 128 graphs 343 / 465, 256 graphs 372 / 695 at
+// 20 layers, 64 graphs 99 / 99 at four - and every residual step wins (64 graphs: cit 0.185 / 0.290 ms per step, rollout 0.200 /
+// 0.363); k_big2's lone 512-thread workgroup per CU needs a batch that fills the device: 64 graphs 974 / 531 us, 128 graphs
+// 1 011 / 682, 256 graphs 1 069 / 1 372 - its plain solve is padded from three quarters of the CU count on.
+static bool narrow_may_pad(const DgcnBatch* b, const DgcnModel* m, float* base, NarrowModel& nm) {
     return narrow_describe(m, base, nm) && (big_takes(b, &nm.m) || big2_takes(b, &nm.m));
+}
+static bool narrow_wants_pad(const DgcnBatch* b, const DgcnModel* m, float* base, NarrowModel& nm, bool residual) {
+    const int want = opt(OPT_NARROW_PAD);  // (-1 automatic; 0 / 1: the tests' witnesses)
+    if (want == 0 || !narrow_may_pad(b, m, base, nm)) return false;
+    if (want < 0 && big2_takes(b, &nm.m)) return residual || 4 * (long)b->num_graphs >= 3 * (long)device_cus();
+    return true;
 }
 static int narrow_pad_launch(const DgcnModel* m, const NarrowModel& nm, float* base, hipStream_t stream) {
     PadArgs pa = {};
@@ -2665,9 +2676,9 @@ static int narrow_pad_launch(const DgcnModel* m, const NarrowModel& nm, float* b
 // the any-size path's model for this call: the caller's, or its padded copy (written into the head of the workspace, which
 // shrinks by that much).  0 or an error code.
 static int narrow_swap(const DgcnBatch* b, const DgcnModel*& m, NarrowModel& nm, void*& workspace, size_t& workspace_bytes,
-                       const char* who, hipStream_t stream) {
+                       const char* who, hipStream_t stream, bool residual) {
     float* base = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    if (!narrow_wants_pad(b, m, base, nm)) return DGCN_OK;
+    if (!narrow_wants_pad(b, m, base, nm, residual)) return DGCN_OK;
     const size_t need = narrow_pad_bytes(m) + 256;
     if (!workspace || workspace_bytes < need)
         return fail(DGCN_ERR_WORKSPACE, "%s: workspace of %zu bytes needed (dgcn_solve_workspace), got %zu", who, need, workspace ? workspace_bytes : (size_t)0);
@@ -2699,7 +2710,8 @@ extern "C" int dgcn_solve_path(const DgcnBatch* b, const DgcnModel* m) {
 static size_t solve_scratch(const DgcnBatch* b, const DgcnModel* m) {
     if (m->layers_host && dgcn_solve_path(b, m) == 2) {
         NarrowModel nm;
-        if (narrow_wants_pad(b, m, reinterpret_cast<float*>(256), nm)) return narrow_pad_bytes(m) + 256 + general_workspace(b, &nm.m);
+        // (one size for both entry points: the padded copy's where either of them would take it)
+        if (narrow_may_pad(b, m, reinterpret_cast<float*>(256), nm)) return narrow_pad_bytes(m) + 256 + max(general_workspace(b, &nm.m), general_workspace(b, m));
         return general_workspace(b, m);
     }
     return fused_scratch(b, m, fused_meta_cap(b->max_graph_edges + b->max_nodes, b->max_nodes));
@@ -2727,7 +2739,7 @@ extern "C" int dgcn_solve_batch(const DgcnBatch* b, const DgcnModel* m, const do
     if (dgcn_solve_path(b, m) != 1) {
         if (compact.col) return fail(DGCN_ERR_ARG, "dgcn_solve_batch: the any-size path takes expanded batches only");
         NarrowModel nm;  // (deep stacks narrower than 32: zero-padded to 32 where that puts them on k_big / k_big2)
-        if (int rc = narrow_swap(b, m, nm, workspace, workspace_bytes, "dgcn_solve_batch", (hipStream_t)stream)) return rc;
+        if (int rc = narrow_swap(b, m, nm, workspace, workspace_bytes, "dgcn_solve_batch", (hipStream_t)stream, false)) return rc;
         return general_solve(b, m, dinv_table, table_len, X, x_const, weights, predict_mwis, scores, state, rounds, totals, status,
                              workspace, workspace_bytes, (hipStream_t)stream);
     }
@@ -2799,7 +2811,7 @@ extern "C" int dgcn_solve_residual_batch(const DgcnBatch* b, const DgcnModel* m,
     const bool any_size = dgcn_solve_path(b, m) != 1;
     NarrowModel nm;  // (deep stacks narrower than 32 on the any-size path: zero-padded to 32 where that puts them on k_big / k_big2 - and k_tail)
     if (any_size)
-        if (int rc = narrow_swap(b, m, nm, workspace, workspace_bytes, "dgcn_solve_residual_batch", (hipStream_t)stream)) return rc;
+        if (int rc = narrow_swap(b, m, nm, workspace, workspace_bytes, "dgcn_solve_residual_batch", (hipStream_t)stream, true)) return rc;
     bool finish = (options & DGCN_RESIDUAL_FINISH_SMALL) && tail_takes(m, X, options);
     unsigned long long* tail_word = nullptr;
     unsigned long long tail_tag = 0;

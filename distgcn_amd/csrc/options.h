@@ -12,6 +12,7 @@ namespace dgcn {
     X(OPT_FUSED_CLUSTER, "fused_cluster", -1)           /* workgroups per graph of the small-batch launch: -1 auto, 0 / 1 off, K >= 2 forced */ \
     X(OPT_FUSED_BLOCK, "fused_block", -1)               /* threads per workgroup of k_fused: -1 auto, 512, 1024 */    \
     X(OPT_FUSED_ORDER, "fused_order", -1)               /* largest-graphs-first dispatch order: -1 auto, 0 off, 1 on */ \
+    X(OPT_NARROW_PAD, "narrow_pad", -1)                 /* deep stacks narrower than 32 beyond 512 vertices: -1 zero-padded onto k_big / k_big2 where that pays, 0 never, 1 wherever a kernel takes the copy */ \
     X(OPT_GENERAL, "general", -1)                       /* 1: every shape takes the any-size path; 0: never; -1 auto */ \
     X(OPT_SHALLOW, "shallow", -1)                       /* 0: one-layer models do not take k_shallow */              \
     X(OPT_SHALLOW_LONG, "shallow_long", -1)             /* k_shallow's long-row variant: -1 auto, 0 / 1 */            \

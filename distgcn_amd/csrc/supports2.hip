@@ -106,18 +106,33 @@ __global__ __launch_bounds__(256) void k_supports2(const int32_t* __restrict__ g
     if (fault) atomicOr(status, fault);
 }
 
-// Exclusive prefix sum of a[0..n) in place, a[n] = total.  One workgroup: this runs once per batch on
-// an array of num_nodes counts (C3: 100 000 values = 98 chunks).
+// Exclusive prefix sum of a[0..n) in place, a[n] = total.  One workgroup (the entry point has no scratch for a multi-block
+// scan), sixteen consecutive counts per thread and pass - 16 384 per pass: the 230 400 rows of 256 joint 3 x 300 graphs take
+// 15 passes (a count per thread and pass, round 5: 225 passes, 244 us of a 2.3 ms [I, L, L.L] solve).
+constexpr int kScanPer = 16;
 __global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ a, int n) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int x = i < n ? a[i] : 0;
-        int incl = x;
+    for (int base = 0; base < n; base += 1024 * kScanPer) {
+        const int i0 = base + threadIdx.x * kScanPer;
+        int x[kScanPer];
+        if (i0 + kScanPer <= n && (reinterpret_cast<uintptr_t>(a + i0) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < kScanPer / 4; ++q) {
+                const int4 v = *reinterpret_cast<const int4*>(a + i0 + 4 * q);
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kScanPer; ++q) x[q] = i0 + q < n ? a[i0 + q] : 0;
+        }
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < kScanPer; ++q) mine += x[q];
+        int incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
@@ -127,7 +142,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ a, i
         __syncthreads();
         int before = carry_s;
         for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < n) a[i] = before + incl - x;
+        int run = before + incl - mine;  // everything in front of this thread's sixteen
+#pragma unroll
+        for (int q = 0; q < kScanPer; ++q) {
+            const int v = x[q];
+            if (i0 + q < n) a[i0 + q] = run;
+            run += v;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = before + incl;
         __syncthreads();
