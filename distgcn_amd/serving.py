@@ -197,6 +197,27 @@ class SolvePipeline:
                 yield self.result(inflight.popleft(), copy)
 
 
+# Objects that are still open when the interpreter exits (the process-wide one-slot instances behind heuristics.* / solve_mwis
+# are never closed by their users) are closed by an atexit handler - i.e. BEFORE the interpreter starts tearing modules down,
+# while the HIP runtime, the streams and the pinned buffers they own are all still there - not by __del__ at some point of the
+# finalisation.
+import atexit
+import weakref
+
+_LIVE = weakref.WeakSet()
+
+
+def _close_all():
+    for hs in list(_LIVE):
+        try:
+            hs.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
+
+
 class HostSolver:
     """``dgcn_host_solver_*`` (include/dgcn.h): pack -> copy in -> fused launch -> copy out in native code, ``depth``
     batches in flight.  ``submit`` returns a slot number at once; ``result(slot)`` waits for it."""
@@ -227,11 +248,13 @@ class HostSolver:
         helper = _pyptr()
         self._solve_lists = getattr(helper, "solve_lists", None)
         self._fn = (C.cast(self.lib.dgcn_host_solver_submit, C.c_void_p).value, C.cast(self.lib.dgcn_host_solver_result, C.c_void_p).value)
+        _LIVE.add(self)
 
     def close(self):
         if self.handle:
             self.lib.dgcn_host_solver_destroy(self.handle)
             self.handle = C.c_void_p()
+        _LIVE.discard(self)
 
     def __del__(self):
         try:
