@@ -49,6 +49,11 @@ constexpr int kMaxFusedLayers = 64;
 constexpr int kFusedBlock = 512;      // threads per workgroup when two or more graphs share a CU
 constexpr int kFusedBlockBig = 1024;  // ... when one graph's image takes more than half the LDS (it has the CU to itself)
 constexpr int kFusedMaxNodes = 512;
+// k_fused<.., GW>: where the gather words sit in LDS before the layers (inside bufA, behind P0's row starts and the compact
+// form's wave sums) and behind them (inside bufB, behind the z1 scalars / priorities / 512 reduction slots)
+constexpr int kGwWordsP0 = 2304;
+constexpr int kGwWordsTail = 12288;
+constexpr int kGwMaxNodes = 384;  // three row blocks of sixteen rows on each of eight waves
 
 struct FusedLayer {
     const float* W;     // [cin][2*cout]
@@ -63,6 +68,7 @@ struct FusedArgs {
     const float* vals;         // values of the given support CSR; unused when from_adj
     uint2* grec;               // [num_graphs][rec_cap] entry records {value bits, gather word} for the hidden aggregation
     float* gvals;              // k_fused<*, true>: [num_graphs][meta_cap] entry values kept in global memory
+    unsigned short* gwords;    // k_fused<.., GW>: [num_graphs][meta_cap] gather words while the layers run
     const double* dinv_table;  // from_adj: float64 d^-1/2 table
     int32_t table_len;
     int32_t from_adj;          // CSR is the adjacency: build L (diagonal first) on the fly
@@ -81,6 +87,7 @@ struct FusedArgs {
     int32_t meta_cap;
     int32_t rec_cap;           // records per graph in grec: block-major and padded (row_blocks_init), or row-major (cluster variant)
     int32_t prio_second;
+    int32_t gw;                // 1: k_fused<.., GW> runs this launch (values and gather words in global scratch, two workgroups per CU)
     int32_t prio_gather;  // issue priority added during the aggregation phase (0..2)
     int32_t wide_passes;  // > 1: a two-layer stack F -> c -> 1 with 32 < c <= 32 * wide_passes: layers[0..P-1] are the
                           // first layer cut into 32-column blocks, layers[P] is the last layer (see fused_prepare)
@@ -192,13 +199,14 @@ struct RowBlock {
     unsigned base;    // first record of the block (wave-uniform)
     unsigned fx, fy;  // this lane's record of trip 0 {value bits, gather word}
 };
-struct RowBlocks {  // (two named members, not an array: the kernel has no scratch memory, and an array that is not split
+struct RowBlocks {  // (named members, not an array: the kernel has no scratch memory, and an array that is not split
     RowBlock b0, b1;  // into registers early enough would sit there)
-    template <int K> __device__ __forceinline__ RowBlock& at() { if constexpr (K == 0) return b0; else return b1; }
-    template <int K> __device__ __forceinline__ const RowBlock& at() const { if constexpr (K == 0) return b0; else return b1; }
+    RowBlock b2;      // (NB = 3 only - k_fused<.., GW>: 512-thread workgroups on graphs of up to 384 vertices; never touched otherwise)
+    template <int K> __device__ __forceinline__ RowBlock& at() { if constexpr (K == 0) return b0; else if constexpr (K == 1) return b1; else return b2; }
+    template <int K> __device__ __forceinline__ const RowBlock& at() const { if constexpr (K == 0) return b0; else if constexpr (K == 1) return b1; else return b2; }
 };
 
-template <int BLOCK>
+template <int BLOCK, int NB = 2>
 __device__ __forceinline__ bool row_blocks_init(RowBlocks& rb, int ng, const unsigned* rinfo, const unsigned short* perm,
                                                 const float* vals, const unsigned short* words, uint2* rec, unsigned zrow,
                                                 int rec_cap, bool diag_parity = false) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ bool row_blocks_init(RowBlocks& rb, int ng, const uns
         return (unsigned)enc_word(u2);
     };
     constexpr int kWaves = BLOCK / 64;
-    const int blocks = (ng + 15) >> 4;  // <= 32
+    const int blocks = (ng + 15) >> 4;  // <= 32 (NB * kWaves)
     // trips of block `lane` and the records in front of it (every wave computes the same table: one scan, once per graph)
     // (at least one trip for a block that exists: rows without a single entry - removed vertices of a residual graph, empty
     // rows of a caller's support matrix - still get their Z0 (+ bias) through the activation)
@@ -241,7 +249,7 @@ __device__ __forceinline__ bool row_blocks_init(RowBlocks& rb, int ng, const uns
     // pass that turns `rb` into registers has run, and the kernel would keep it in scratch memory)
     auto one_block = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);
+        const int blk = k * kWaves + ((k & 1) ? (kWaves - 1 - wave) : wave);  // (snake: 0 .. W-1, 2W-1 .. W, 2W .. 3W-1)
         const int src = blk < blocks ? blk : 0;
         const int trips = (blk < blocks && fits_slice) ? __shfl(tl, src) : 0;
         const unsigned base = (unsigned)(__shfl(incl, src) - __shfl(tl, src)) * 64u;
@@ -268,6 +276,7 @@ __device__ __forceinline__ bool row_blocks_init(RowBlocks& rb, int ng, const uns
     static_assert(kMaxRowBlocks == 2, "one call per row block");
     one_block(std::integral_constant<int, 0>{});
     one_block(std::integral_constant<int, 1>{});
+    if constexpr (NB == 3) one_block(std::integral_constant<int, 2>{});
     return fits_slice;
 }
 
@@ -524,7 +533,7 @@ template <> struct RowAcc<true> {
 // of 16 lanes = 4 row slots here ({0,3,5,6}, {1,2,4,7}, ... of MI355X_MICROARCH.md's lane sets): two of them read
 // lower halves and two upper halves, so a group collides only where two rows that read the same half have the same
 // parity.  The chunk swizzle inside a half (keyB) only serves the transform's ds_write_b128.
-template <int BLOCK, int ACT, bool BIAS, bool F64 = false>
+template <int BLOCK, int ACT, bool BIAS, bool F64 = false, int NB = 2>
 __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* bufA, const RowBlocks& rb,
                                                  const uint2* rec, const unsigned* rinfo_lds, unsigned long long* st, bool const_rows = false) {
     (void)st;
@@ -684,6 +693,7 @@ __device__ __forceinline__ void aggregate_rows16(const float* bias_ptr, float* b
     };
     one_block(std::integral_constant<int, 0>{});
     one_block(std::integral_constant<int, 1>{});
+    if constexpr (NB == 3) one_block(std::integral_constant<int, 2>{});
 #ifdef DGCN_DIAG
     if (st && threadIdx.x == (BLOCK == 1024 ? 0 : BLOCK - 64)) {
 #pragma unroll
@@ -820,31 +830,31 @@ __device__ __forceinline__ void cluster_aggregate(const FusedLayer& L, float* bu
 }
 
 // The activation is a template argument of the row loop: one uniform branch per layer instead of four per row block.
-template <int BLOCK>
+template <int BLOCK, int NB = 2>
 __device__ __forceinline__ void hidden_aggregate(const FusedLayer& L, float* bufA, const RowBlocks& rb, const uint2* rec,
                                                  const unsigned* rinfo, bool precise, unsigned long long* st = nullptr, bool const_rows = false) {
     const float* bias = L.bias;
     const int act = L.act;
     if (precise) {  // layer index 0: chains in double (once per launch: not worth twelve instantiations, the bias is a runtime test there)
         if (bias) {
-            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
-            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
-            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
         } else {
-            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
-            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
-            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, true>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
+            else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, true, NB>(bias, bufA, rb, rec, rinfo, nullptr, const_rows);
         }
         return;
     }
     if (bias) {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true>(bias, bufA, rb, rec, rinfo, st);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true>(bias, bufA, rb, rec, rinfo, st);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true>(bias, bufA, rb, rec, rinfo, st);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, true, false, NB>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, true, false, NB>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, true, false, NB>(bias, bufA, rb, rec, rinfo, st);
     } else {
-        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false>(bias, bufA, rb, rec, rinfo, st);
-        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false>(bias, bufA, rb, rec, rinfo, st);
-        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false>(bias, bufA, rb, rec, rinfo, st);
+        if (act == DGCN_ACT_RELU) aggregate_rows16<BLOCK, DGCN_ACT_RELU, false, false, NB>(bias, bufA, rb, rec, rinfo, st);
+        else if (act == DGCN_ACT_LEAKY_RELU) aggregate_rows16<BLOCK, DGCN_ACT_LEAKY_RELU, false, false, NB>(bias, bufA, rb, rec, rinfo, st);
+        else aggregate_rows16<BLOCK, DGCN_ACT_LINEAR, false, false, NB>(bias, bufA, rb, rec, rinfo, st);
     }
 }
 
@@ -1056,9 +1066,18 @@ __device__ __forceinline__ void signal_done(const FusedArgs& a) {
 
 // COMPACT: the batch comes in the compact transfer form (common.h CompactHook): a kernel of its own, also by name - what a
 // profile of the host-to-host path shows (solves of consecutive batches overlapping) does not mix into the resident launch's row.
-template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false, bool COMPACT = false>
+// GW (round 6; plain solves of mixed batches such as the BA test mix, whose largest image - 146 KB at 300 vertices / 11 200
+// entries - used to give EVERY graph of the launch a CU to itself, a kernel launch having one LDS size): the image keeps in LDS
+// only what the layers touch - bufA, bufB, the row tables.  The entry VALUES live in global scratch (as in the GVALS variant),
+// the 16-bit gather WORDS are built in the space bufA will occupy, written out to global scratch once the block-major records
+// exist (the layers walk those, not the words) and read back into bufB's tail behind the last hidden layer, where the last
+// layer and the greedy rounds find them as always.  300 vertices: 79.5 KB - TWO workgroups per CU, C3's regime; 512 threads
+// then hold up to three row blocks per wave (384 vertices).  Never with MASKED or CLUSTER.
+template <bool MASKED, bool GVALS, int BLOCK, bool CLUSTER = false, bool COMPACT = false, bool GW = false>
 // (4 waves per SIMD = 128 VGPRs: what lets two 512-thread workgroups share a CU and a 1024-thread one launch at all)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ? 2 : 4))) void k_fused(FusedArgs a) {
+    static_assert(!GW || (GVALS && !MASKED && !CLUSTER && BLOCK == 512), "the words-in-global variant: plain solves, 512 threads, values in global scratch");
+    constexpr int kNB = GW ? 3 : 2;  // row blocks per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int g = blockIdx.x;
     if (!CLUSTER && a.order) g = a.order[g];
@@ -1088,8 +1107,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     uint2* rec = a.grec + (size_t)g * a.rec_cap;  // (cluster variant: every workgroup of the graph writes the same records)
     float* lds_meta = reinterpret_cast<float*>(rinfo + ((a.max_nodes + 3) & ~3));
     float* vals = GVALS ? a.gvals + (size_t)g * a.meta_cap : lds_meta;
-    unsigned short* words = reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
-    unsigned short* perm = words + a.meta_cap;
+    // (GW: the words are built where bufA will be - behind P0's row starts -, see above)
+    unsigned short* words = GW ? reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(bufA) + kGwWordsP0)
+                               : reinterpret_cast<unsigned short*>(GVALS ? lds_meta : lds_meta + a.meta_cap);
+    unsigned short* perm = GW ? reinterpret_cast<unsigned short*>(lds_meta) : words + a.meta_cap;
     unsigned short* ipos = perm + a.max_nodes;  // position of a vertex in `perm`
     if (ng <= 0) {
         if (threadIdx.x == 0 && a.do_lgs) {
@@ -1428,8 +1449,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
     ClusterTile ctile;
     // (every wave writes the block-major records of its own row blocks: read back by the same lanes, no barrier)
     if constexpr (!CLUSTER) {
-        if (!row_blocks_init<BLOCK>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, a.rec_cap, DIAG_ON(a, 4) != 0))
+        if (!row_blocks_init<BLOCK, kNB>(rb, has_wide ? ng : 0, rinfo, perm, vals, words, rec, zrow, a.rec_cap, DIAG_ON(a, 4) != 0))
             fault |= DGCN_FAULT_DEGREE_RANGE;  // (a row with more entries than the graph has vertices: results invalid)
+        if constexpr (GW) {
+            // the words leave the LDS for the duration of the layers (two per 32-bit store; slots are even-aligned per row and
+            // meta_cap is a multiple of 16)
+            const unsigned rl = rinfo[ng - 1];
+            const int used = min(((int)(rl & 0xffff) + (int)(rl >> 16) + 1) >> 1, a.meta_cap >> 1);
+            unsigned* gw = reinterpret_cast<unsigned*>(a.gwords + (size_t)g * a.meta_cap);
+            const unsigned* lw = reinterpret_cast<const unsigned*>(words);
+            for (int j = threadIdx.x; j < used; j += BLOCK) gw[j] = lw[j];
+            __syncthreads();  // every wave has read the words it needs: the first transform may overwrite them
+        }
     }
     if constexpr (CLUSTER) {
         cluster_rows_init<BLOCK>(cr, has_wide ? ng : 0, rinfo, perm, vals, words, K, cw);
@@ -1478,7 +1509,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
         for (int p = 0; p < P; ++p) {
             first_layer_transform<BLOCK>(a, a.layers[p], n0 + voff, ng, bufA, bufB, xfill);
             __syncthreads();
-            hidden_aggregate<BLOCK>(a.layers[p], bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
+            hidden_aggregate<BLOCK, kNB>(a.layers[p], bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));  // (every block is layer index 0)
             __syncthreads();
             if (v < ng) {
 #pragma unroll
@@ -1515,7 +1546,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             cluster_aggregate<BLOCK>(L, bufA, cr, rec, zrow, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
         } else {
-            hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
+            hidden_aggregate<BLOCK, kNB>(L, bufA, rb, rec, rinfo, true, nullptr, !a.X && !(MASKED && a.feature_mode == 1));
         }
         STAMP(a, g, 4, tclk);
         // (a wave without a tile - residual graphs late in a search: a handful of tiles on sixteen waves - fetches nothing: every
@@ -1579,9 +1610,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the "unwritten" marks are in L2 before the next layer starts
             } else {
 #ifdef DGCN_DIAG
-                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
+                if (!DIAG_ON(a, 0)) hidden_aggregate<BLOCK, kNB>(L, bufA, rb, rec, rinfo, false, a.stamps ? a.stamps + (size_t)g * 64 + 48 : nullptr);
 #else
-                hidden_aggregate<BLOCK>(L, bufA, rb, rec, rinfo, false);
+                hidden_aggregate<BLOCK, kNB>(L, bufA, rb, rec, rinfo, false);
 #endif
             }
 #ifdef DGCN_DIAG
@@ -1607,6 +1638,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLUSTER ?
             // previous aggregation finished at the barrier above).
             const int v = threadIdx.x;
             float z0 = 0.f, z1 = 0.f;
+            if constexpr (GW) {
+                // the words come back - into bufB's tail, clear of the z1 scalars, the priorities and the reduction slots the rest
+                // of the kernel keeps at its head (the barrier below, in front of the width-1 aggregation, covers the copy)
+                const unsigned rl = rinfo[ng - 1];
+                const int used = min(((int)(rl & 0xffff) + (int)(rl >> 16) + 1) >> 1, a.meta_cap >> 1);
+                const unsigned* gw = reinterpret_cast<const unsigned*>(a.gwords + (size_t)g * a.meta_cap);
+                unsigned* lw = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(bufB) + kGwWordsTail);
+                for (int j = threadIdx.x; j < used; j += BLOCK) lw[j] = gw[j];
+                words = reinterpret_cast<unsigned short*>(lw);
+            }
             // (cluster variant: the last activations exist only for the rows this workgroup owns; the z1 scalars and
             // then the scores go round through the graph's scalar exchange slots)
             bool owned = v < ng;
@@ -2144,11 +2185,40 @@ static size_t fused_lds_bytes(int max_nodes, int meta_cap, bool gvals) {
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
+// k_fused<.., GW>: bufA, bufB, the row tables, the flag words - nothing per entry
+static size_t fused_lds_bytes_gw(int max_nodes) {
+    const size_t bufs = (size_t)max_nodes * kHid * sizeof(float) * 2;
+    const size_t rinfo = (size_t)((max_nodes + 3) & ~3) * sizeof(unsigned);
+    return ((bufs + rinfo + (size_t)max_nodes * 4 + 127) & ~(size_t)127) + 256;
+}
+
 // 0: everything in LDS; 1: entry values in global scratch; -1: the image does not fit either way
 static int fused_variant(int max_nodes, int meta_cap) {
     if (fused_lds_bytes(max_nodes, meta_cap, false) <= kLdsLimit) return 0;
     if (fused_lds_bytes(max_nodes, meta_cap, true) <= kLdsLimit) return 1;
     return -1;
+}
+
+static int device_cus();
+// Does the words-in-global variant take this (batch, model)?  Plain solves only (the caller knows), a batch of more graphs
+// than CUs (otherwise every graph gets a CU to itself anyway, and sixteen waves serve it better), an image that does NOT leave
+// two workgroups per CU as it is but does so without its entry arrays, graphs of at most 384 vertices, and room for the words
+// in the buffers' space before and behind the layers.
+static bool fused_gw_takes(const DgcnBatch* b, const DgcnModel* m, int meta_cap) {
+    const int want = opt(OPT_FUSED_GW);  // -1 automatic, 0 never, 1 wherever it fits (tests)
+    if (want == 0 || !m->layers_host || m->num_layers < 2) return false;
+    const int mn = max(b->max_nodes, 64);
+    if (b->max_nodes > kGwMaxNodes) return false;
+    if (fused_lds_bytes_gw(mn) > kLdsLimit / 2) return false;
+    if ((size_t)kGwWordsP0 + 2 * (size_t)meta_cap > (size_t)mn * kHid * sizeof(float)) return false;
+    if ((size_t)kGwWordsTail + 2 * (size_t)meta_cap > (size_t)mn * kHid * sizeof(float)) return false;
+    if (want == 1) return true;
+    // Measured on the BA test mix (100 .. 300 vertices, 20 layers; tools/ab_fused.py, profiles/r06_fused_gw.txt), 1 024-thread launch ->
+    // this variant: 500 graphs 299 -> 341 us (every workgroup resident at once: the launch is as long as its largest graph, and that
+    // one is served by eight waves instead of sixteen), 768 graphs 418 -> 360, 1 000: 548 -> 469, 2 000: 1 071 -> 839, 4 000:
+    // 2 116 -> 1 671 - it pays once the CUs are refilled as workgroups finish: from three graphs per CU on.
+    if ((long)b->num_graphs < 3L * device_cus()) return false;
+    return fused_lds_bytes(mn, meta_cap, false) > kLdsLimit / 2;  // (an image that shares a CU as it is stays as it is)
 }
 
 static int device_cus() {
@@ -2397,18 +2467,31 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         workspace = static_cast<char*>(workspace) + pad_bytes;
         workspace_bytes -= pad_bytes;
     }
-    const int variant = fused_variant(a->max_nodes, a->meta_cap);
+    int variant = fused_variant(a->max_nodes, a->meta_cap);
     a->rec_cap = fused_rec_cap(a->meta_cap, b->max_nodes);
     if (variant < 0)
         return fail(DGCN_ERR_UNSUPPORTED, "%s: a graph image of %zu bytes does not fit the 160 KB LDS", who,
                     fused_lds_bytes(a->max_nodes, a->meta_cap, true));
-    *gvals = variant == 1;
+    // plain solves of batches whose images would keep a CU each: values and words out of LDS, two workgroups per CU (k_fused<.., GW>)
+    const bool gw = !masked && fused_gw_takes(b, m, a->meta_cap) && fused_cluster_k(b, m, a->meta_cap, no_cluster, masked) < 2;
+    if (gw) variant = 2;
+    a->gw = gw ? 1 : 0;
+    *gvals = variant >= 1;
     if (*gvals) {
         const size_t need = (size_t)b->num_graphs * a->meta_cap * sizeof(float);
         if (!workspace || workspace_bytes < need)
             return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (entry values of large graphs), got %zu", who,
                         need, workspace ? workspace_bytes : (size_t)0);
         a->gvals = static_cast<float*>(workspace);
+        workspace = static_cast<char*>(workspace) + need;
+        workspace_bytes -= need;
+    }
+    if (gw) {
+        const size_t need = (((size_t)b->num_graphs * a->meta_cap * sizeof(unsigned short)) + 255) & ~(size_t)255;
+        if (!workspace || workspace_bytes < need)
+            return fail(DGCN_ERR_ARG, "%s: workspace of %zu bytes needed (gather words of large graphs), got %zu", who,
+                        need, workspace ? workspace_bytes : (size_t)0);
+        a->gwords = static_cast<unsigned short*>(workspace);
         workspace = static_cast<char*>(workspace) + need;
         workspace_bytes -= need;
     }
@@ -2461,12 +2544,12 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         }()};
         a->nonce = nonce_src.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed);
     }
-    *lds = fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
+    *lds = gw ? fused_lds_bytes_gw(a->max_nodes) : fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals);
     a->flags_off = (int32_t)(*lds - 256);
     return DGCN_OK;
 }
 
-template <bool MASKED, bool GVALS, int BLOCK, bool COMPACT = false>
+template <bool MASKED, bool GVALS, int BLOCK, bool COMPACT = false, bool GW = false>
 static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, hipStream_t s) {
     if (lds > 64 * 1024) {
         // raise the kernel's dynamic-LDS limit once per device and size (the attribute call is a driver round trip)
@@ -2475,7 +2558,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
         (void)hipGetDevice(&dev);
         std::atomic<size_t>& have = reserved[dev & 63];
         if (lds > have.load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK, false, COMPACT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<MASKED, GVALS, BLOCK, false, COMPACT, GW>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
             if (e != hipSuccess) return fail(DGCN_ERR_LAUNCH, "k_fused: cannot reserve %zu bytes of LDS", lds);
             have.store(kLdsLimit, std::memory_order_relaxed);
@@ -2487,7 +2570,7 @@ static int fused_launch_b(FusedArgs& a, int B, size_t lds, const char* family, h
     if ((MASKED || COMPACT) && a.max_nodes > BLOCK)
         return fail(DGCN_ERR_LAUNCH, "k_fused: %d vertices per graph on %d threads in a variant that keeps a vertex per thread", a.max_nodes, BLOCK);
     TimedLaunch t(family, s);
-    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT>), dim3(B), dim3(BLOCK), lds, s, a);
+    DGCN_LAUNCH(t, (k_fused<MASKED, GVALS, BLOCK, false, COMPACT, GW>), dim3(B), dim3(BLOCK), lds, s, a);
     return check_launch("k_fused");
 }
 
@@ -2536,6 +2619,8 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
         if (compact) return gvals ? fused_launch_cluster<false, true, true>(a, B, lds, family, s) : fused_launch_cluster<false, false, true>(a, B, lds, family, s);
         return gvals ? fused_launch_cluster<false, true>(a, B, lds, family, s) : fused_launch_cluster<false, false>(a, B, lds, family, s);
     }
+    if (a.gw) return compact ? fused_launch_b<false, true, kFusedBlock, true, true>(a, B, lds, family, s)
+                             : fused_launch_b<false, true, kFusedBlock, false, true>(a, B, lds, family, s);
     if (masked) return gvals ? fused_launch_t<true, true>(a, B, lds, family, s) : fused_launch_t<true, false>(a, B, lds, family, s);
     if (compact) return gvals ? fused_launch_t<false, true, true>(a, B, lds, family, s) : fused_launch_t<false, false, true>(a, B, lds, family, s);
     return gvals ? fused_launch_t<false, true>(a, B, lds, family, s) : fused_launch_t<false, false>(a, B, lds, family, s);
@@ -2545,7 +2630,8 @@ static int fused_launch(FusedArgs& a, int B, size_t lds, const char* family, hip
 // the LDS, otherwise one float per entry slot
 static size_t fused_scratch(const DgcnBatch* b, const DgcnModel* m, int meta_cap) {
     size_t need = m->layers_host ? fused_pad_bytes(m) : 0;
-    if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1) need += (size_t)b->num_graphs * meta_cap * sizeof(float);
+    if (fused_variant(max(b->max_nodes, 64), meta_cap) == 1 || (m->layers_host && fused_gw_takes(b, m, meta_cap)))
+        need += (size_t)b->num_graphs * meta_cap * (sizeof(float) + sizeof(unsigned short)) + 512;
     need += (size_t)b->num_graphs * fused_rec_cap(meta_cap, b->max_nodes) * sizeof(uint2) + 256;  // entry records of the hidden aggregation
     need += (size_t)b->num_graphs * sizeof(int32_t) + 256;            // dispatch order
     need += fused_cluster_bytes(b, m->layers_host ? max(fused_cluster_k(b, m, meta_cap, false), fused_cluster_k(b, m, meta_cap, false, true)) : 0);

@@ -791,6 +791,92 @@ def test_cluster_variant_survives_foreign_use_of_its_buffers(engine, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ba", "er300", "er308_hubs", "ragged", "two_layers", "features"])
+def test_fused_words_in_global_variant_is_bit_identical(engine, case):
+    """Round 6, C4: k_fused<.., GW> keeps only bufA / bufB / the row tables in LDS - entry values in global scratch, the 16-bit gather
+    words built in bufA's space, written out while the layers run and read back into bufB's tail for the last layer and the greedy
+    rounds - so that graphs of up to ~308 vertices leave TWO 512-thread workgroups per CU (three row blocks per wave beyond 256
+    vertices) instead of one 1 024-thread workgroup per CU for every graph of a mixed batch.  Chosen by itself from three graphs
+    per CU on; here forced (option fused_gw = 1) onto small batches and held against the ordinary launch (fused_gw = 0) and the
+    twin, bit for bit: scores, states, rounds, totals; the BA mix, 300 vertices, 308 vertices with hub rows (rows longer than a
+    tile's neighbours: the third row block), ragged sizes with empty / one-vertex graphs, a two-layer model, explicit features."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    from oracle import ctwin
+    rng = np.random.default_rng(61)
+    layers = datagen.random_model(2 if case == "two_layers" else 6, 32, feature_size=3 if case == "features" else 1,
+                                  bias=case != "ba", last_act="leaky_relu" if case == "ragged" else "linear", seed=17)
+    if case == "ba":
+        hb = datagen.ba_test2_batch(90, first_index=40)
+    elif case == "er300":
+        hb = datagen.er_batch(12, 300, 0.06, first_index=310)
+    elif case == "er308_hubs":
+        import scipy.sparse as sp
+        mats, ws = [], []
+        for i in range(5):
+            ip, ix = datagen.er_graph(308 - i, 0.03, rng)
+            a = sp.csr_matrix((np.ones(ix.size), ix, ip), shape=(308 - i,) * 2).tolil()
+            for v, d in ((0, 200), (17, 120), (307 - i, 250)):
+                for u in rng.choice(np.setdiff1d(np.arange(308 - i), [v]), size=d, replace=False):
+                    a[v, u] = 1.0
+                    a[u, v] = 1.0
+            a = a.tocsr(); a.sort_indices()
+            mats.append(a); ws.append(rng.random(308 - i))
+        hb = HostBatch.from_scipy(mats, ws)
+    else:
+        ps, cs, ws = [], [], []
+        for n in ((0, 1, 2, 17, 64, 129, 257, 300, 305, 200, 16) if case == "ragged" else (257, 290, 120, 300)):
+            if n == 0:
+                ps.append(np.zeros(1, np.int32)); cs.append(np.zeros(0, np.int32)); ws.append(np.zeros(0))
+                continue
+            g = datagen.er_batch(1, n, min(0.9, 9.0 / max(n, 2)), first_index=int(rng.integers(1 << 20)))
+            ps.append(g.row_ptr.astype(np.int32)); cs.append(g.col_idx.astype(np.int32)); ws.append(g.weights)
+        hb = HostBatch.from_csr_lists(ps, cs, ws)
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    assert engine.solve_supported(db, dm)
+    X = None
+    if case == "features":
+        X = torch.from_numpy(rng.random((hb.num_nodes, 3)).astype(np.float32)).to(engine.device)
+    got = {}
+    for gw in (0, 1):
+        with _lib.options(fused_gw=gw, fused_cluster=0):
+            out = engine.solve_buffers(db, True)
+            engine.solve_fused(db, dm, out=out, want_scores=True, X=X)
+            got[gw] = engine.fetch_solve_buffers(out, hb.num_nodes, hb.num_graphs)
+            assert got[gw]["status"] == 0, (case, gw)
+    for k in ("state", "rounds"):
+        assert np.array_equal(got[0][k], got[1][k]), (case, k)
+    assert np.array_equal(got[0]["scores"].ravel().view(np.uint32), got[1]["scores"].ravel().view(np.uint32)), case
+    assert np.array_equal(got[0]["totals"], got[1]["totals"]), case
+    if X is None:
+        want = ctwin.solve(hb, layers)
+        assert np.array_equal(got[1]["scores"].ravel().view(np.uint32), np.asarray(want["scores"], np.float32).ravel().view(np.uint32)), case
+        assert np.array_equal(got[1]["state"], want["state"]) and np.array_equal(got[1]["rounds"], want["rounds"]), case
+    # ... and the forward-only entry point (dgcn_gcn_forward_batch, mode 1) on the same variant
+    if case in ("ba", "er308_hubs"):
+        with _lib.options(fused_gw=1, fused_cluster=0):
+            f1 = engine.forward(db, dm, mode=1).cpu().numpy()
+        with _lib.options(fused_gw=0, fused_cluster=0):
+            f0 = engine.forward(db, dm, mode=1).cpu().numpy()
+        assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32)), case
+    # ... and the host-to-host object's compact transfer form, which the variant's image build reads as it is
+    if case == "ba":
+        from distgcn_amd.serving import HostSolver
+        ps, cs, ws = [], [], []
+        for n0, n1 in hb.graph_slices():
+            e0, e1 = int(hb.row_ptr[n0]), int(hb.row_ptr[n1])
+            ps.append((hb.row_ptr[n0:n1 + 1] - e0).astype(np.int32)); cs.append((hb.col_idx[e0:e1] - n0).astype(np.int32)); ws.append(hb.weights[n0:n1].copy())
+        with _lib.options(fused_gw=1, fused_cluster=0, host_direct_bytes=0):
+            hs = HostSolver(engine, dm, depth=1, want_scores=True)
+            g = hs.solve(ps, cs, ws)
+            hs.close()
+        assert np.array_equal(g["state"], got[0]["state"]) and np.array_equal(g["rounds"], got[0]["rounds"])
+        assert np.array_equal(g["scores"].view(np.uint32), got[0]["scores"].ravel().view(np.uint32))
+
+
 def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatch):
     """k_graph_rank (csrc/fused.hip): a mixed batch that needs several rounds of workgroups is dealt
     largest graph first.  Only the assignment of graphs to workgroups changes: scores, sets, rounds and totals are the
