@@ -2321,7 +2321,7 @@ __device__ __forceinline__ unsigned graph_key(const int32_t* graph_ptr, const in
 constexpr int kRankBlock = 256, kRankTile = 1024;
 __global__ __launch_bounds__(kRankBlock) void k_graph_rank(const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ edge_ptr, int B, int gbits, unsigned kmax,
-                                                            int32_t* __restrict__ order) {
+                                                            int fold, int32_t* __restrict__ order) {
     __shared__ unsigned tile[kRankTile];
     const int g = blockIdx.x * kRankBlock + threadIdx.x;
     const unsigned kg = g < B ? graph_key(graph_ptr, row_ptr, edge_ptr, g, gbits, kmax) : 0u;
@@ -2343,7 +2343,8 @@ __global__ __launch_bounds__(kRankBlock) void k_graph_rank(const int32_t* __rest
             pos += (q.x > kg) + (q.y > kg) + (q.z > kg) + (q.w > kg);
         }
     }
-    if (g < B) order[pos] = g;
+    // `fold` > 0: the positions from `fold` on run smallest first (fused_fold_at)
+    if (g < B) order[fold > 0 && pos >= fold ? fold + (B - 1 - pos) : pos] = g;
 }
 
 // bits for the graph index in the packed key, or -1 if key and index do not fit one word
@@ -2361,6 +2362,21 @@ static bool fused_wants_order(const DgcnBatch* b) {
     if (b->num_graphs <= device_cus()) return false;
     return (double)b->max_nodes * b->num_graphs > 1.25 * (double)b->num_nodes ||
            (double)b->max_graph_edges * b->num_graphs > 1.25 * (double)b->num_edges;
+}
+
+// One-round launches with two workgroups per CU (CUs < graphs <= 2 x CUs): every workgroup is resident from the start, the first
+// `CUs` of the dispatch order take a CU each and the rest join them in the same order, so position i shares its CU with position
+// CUs + i.  Largest first through BOTH halves pairs the largest graph with the median one; with the second half smallest first
+// the largest graph's partner is the smallest, which leaves early and leaves it the CU.  Measured (tools/ab_fused.py, 20 layers,
+// profiles/r06_fold.txt): ER(n, 0.1) with n = 80 .. 200 mixed, 500 graphs 173.0 -> 157.4 us, 400: 166.5 -> 156.8, 320: 160.1 -> 157.7;
+// the BA mix forced onto k_fused<.., GW>, 500 graphs: 341 -> 310 us (fold points 244 / 250 / 256: the CU count is the best).
+// Batches of more than two graphs per CU refill their CUs as workgroups finish: largest first all the way is right there.
+// -> position from which the order runs ascending, 0 = plain largest first.  Option "fused_fold": -1 automatic, 0 off, N forced.
+static int fused_fold_at(const DgcnBatch* b, bool two_per_cu) {
+    const int want = opt(OPT_FUSED_FOLD);
+    if (want == 0) return 0;
+    if (want > 0) return min(want, b->num_graphs);
+    return two_per_cu ? device_cus() : 0;
 }
 
 // The variant's switch: option "fused_cluster" (dgcn_set_option; dgcn_set_cluster is the older name of the same word) - set by
@@ -2506,6 +2522,10 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
     }
     a->num_graphs = b->num_graphs;
     a->order = nullptr;
+    // (two 512-thread workgroups per CU, every workgroup of the launch resident at once?  fused_launch_t's choice, seen from here)
+    const bool two_per_cu = (gw ? fused_lds_bytes_gw(a->max_nodes) : fused_lds_bytes(a->max_nodes, a->meta_cap, *gvals)) <= kLdsLimit / 2 &&
+                            b->num_graphs > device_cus() && b->num_graphs <= 2 * device_cus() && opt(OPT_FUSED_BLOCK) != kFusedBlockBig &&
+                            (gw || a->max_nodes <= 16 * kMaxRowBlocks * (kFusedBlock / 64));
     if (fused_wants_order(b)) {
         const size_t need = (size_t)b->num_graphs * sizeof(int32_t) + 256;
         if (!workspace || workspace_bytes < need)
@@ -2514,7 +2534,7 @@ static int fused_prepare(const DgcnBatch* b, const DgcnModel* m, FusedArgs* a, s
         int32_t* order = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
         const int blocks = (b->num_graphs + kRankBlock - 1) / kRankBlock;
         hipLaunchKernelGGL(k_graph_rank, dim3(blocks), dim3(kRankBlock), 0, stream, b->graph_ptr, a->row_ptr, a->cedge, b->num_graphs,
-                           fused_order_bits(b), (unsigned)(b->max_graph_edges + 16 * b->max_nodes), order);
+                           fused_order_bits(b), (unsigned)(b->max_graph_edges + 16 * b->max_nodes), fused_fold_at(b, two_per_cu), order);
         if (int rc = check_launch("k_graph_rank")) return rc;
         a->order = order;
         workspace = static_cast<char*>(workspace) + need;

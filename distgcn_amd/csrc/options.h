@@ -13,6 +13,7 @@ namespace dgcn {
     X(OPT_FUSED_BLOCK, "fused_block", -1)               /* threads per workgroup of k_fused: -1 auto, 512, 1024 */    \
     X(OPT_FUSED_GW, "fused_gw", -1)                     /* k_fused with values and gather words in global scratch (two workgroups per CU for large images): -1 auto, 0 never, 1 wherever it fits */ \
     X(OPT_FUSED_ORDER, "fused_order", -1)               /* largest-graphs-first dispatch order: -1 auto, 0 off, 1 on */ \
+    X(OPT_FUSED_FOLD, "fused_fold", -1)                 /* one-round launches with two workgroups per CU: the second half of the dispatch order smallest first: -1 auto, 0 off, N >= 1 forced at position N */ \
     X(OPT_NARROW_PAD, "narrow_pad", -1)                 /* deep stacks narrower than 32 beyond 512 vertices: -1 zero-padded onto k_big / k_big2 where that pays, 0 never, 1 wherever a kernel takes the copy */ \
     X(OPT_GENERAL, "general", -1)                       /* 1: every shape takes the any-size path; 0: never; -1 auto */ \
     X(OPT_SHALLOW, "shallow", -1)                       /* 0: one-layer models do not take k_shallow */              \

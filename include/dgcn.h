@@ -98,7 +98,7 @@ const char* dgcn_last_error(void);
  * fault recovery of the small-batch launch) is one word of this table: set / get are atomic, take effect with the next call
  * of any thread, and cost a launch nothing.  -1 = automatic (the default of every path switch).  Keys (csrc/options.h has
  * the full list with defaults; dgcn_option_name enumerates it):
- *   "fused_cluster" (-1 | 0 | K), "fused_block" (512 | 1024), "fused_order", "fused_gw", "narrow_pad", "general" (1: every shape down the any-size path), "shallow", "shallow_long", "shallow_block",
+ *   "fused_cluster" (-1 | 0 | K), "fused_block" (512 | 1024), "fused_order", "fused_fold", "fused_gw", "narrow_pad", "general" (1: every shape down the any-size path), "shallow", "shallow_long", "shallow_block",
  *   "wide1", "wide2", "wide_ahead", "rollout_bits", "big", "big_solve", "big_block", "big_tiles", "big_residual", "big2",
  *   "tail", "layer_fuse", "lgs_lpv", "lgs_block", "spmm_*" (tuning of the stand-alone SpMM), "host_direct_bytes",
  *   "host_compact", "host_compact_direct", "host_done_word", "test_cluster_fault" (test hook: the small-batch launch reports

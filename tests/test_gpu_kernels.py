@@ -907,6 +907,40 @@ def test_largest_first_dispatch_changes_nothing_but_the_order(engine, monkeypatc
                 assert np.array_equal(got["0"][k].view(np.uint8), got[order][k].view(np.uint8)), (layers_n, order, k)
 
 
+def test_folded_dispatch_order_changes_nothing_but_the_order(engine):
+    """Option fused_fold (csrc/fused.hip, fused_fold_at): in a launch whose workgroups are all resident at once, two per CU, the
+    second half of the dispatch order runs smallest first, so that the largest graphs share their CUs with the smallest.  Still a
+    permutation of the graphs - every graph solved exactly once, same bits - with the fold at the CU count (what the library
+    chooses by itself for 257 .. 512 mixed graphs), in the middle of the batch, at its first and last position, and beyond it;
+    mixed ER batch with an empty and a single-vertex graph, and the BA mix on k_fused<.., GW> (forced)."""
+    import torch
+    from distgcn_amd import datagen
+    from distgcn_amd.batch import HostBatch
+    from distgcn_amd.engine import DeviceModel
+    ps, cs, ws = [np.zeros(1, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0)]
+    for g in range(329):
+        rng = np.random.default_rng(4100 + g)
+        ip, ix = datagen.er_graph((80, 1, 120, 160, 200, 100, 140, 180)[g % 8], 0.1, rng)
+        ps.append(ip); cs.append(ix); ws.append(rng.random(len(ip) - 1))
+    mixed = HostBatch.from_csr_lists(ps, cs, ws)
+    for hb, extra in ((mixed, {}), (datagen.ba_test2_batch(300), {"fused_gw": 1})):
+        model = DeviceModel(datagen.random_model(6, 32), engine.device)
+        db = engine.upload(hb)
+        got = {}
+        for fold in (0, -1, 1, 150, hb.num_graphs - 1, hb.num_graphs, 10 * hb.num_graphs):
+            with _lib.options(fused_fold=fold, fused_order=1, fused_cluster=0, **extra):
+                out = engine.solve_buffers(db, True)
+                for k in ("state", "rounds"):
+                    out[k].fill_(77)  # (a graph the permutation skipped would keep this)
+                engine.solve_fused(db, model, out=out, want_scores=True)
+                torch.cuda.synchronize()
+            got[fold] = {k: out[k].cpu().numpy().copy() for k in ("state", "scores", "rounds", "totals", "status")}
+            assert int(got[fold]["status"][0]) == 0
+            for k in got[0]:
+                assert np.array_equal(got[0][k].view(np.uint8), got[fold][k].view(np.uint8)), (fold, k)
+        assert not (got[0]["rounds"] == 77).any()
+
+
 @pytest.mark.parametrize("case", ["ties", "features_bias", "ba", "dense", "n512", "c2"])
 def test_shallow_kernel_equals_fused_and_twin(engine, case, monkeypatch):
     """One-layer models go through the small dedicated kernel (csrc/shallow.hip: no 32-wide image, greedy rounds on the
