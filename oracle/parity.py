@@ -121,6 +121,37 @@ def full_size_configs():
     }
 
 
+def gpu_extra_configs():
+    """More (family, graphs, model fixture, batch maker) rows, held against the restatement by the -m gpu suite only
+    (tests/test_gpu_full_size.py) - the CPU suite's twin runs stay at full_size_configs().  The shapes the other kernels
+    and launch forms take: the launcher's third depth (bash/generalization_dqn_test.sh:20-33: layers 1, 3, 20), 32 input
+    features, hidden widths 16 and 64, the fifteen-tile k_big2, k_wide1 at its largest sizes (one and two layers), deep
+    stacks narrower than 32 on k_big / k_big2, and the two [I, L, L.L] checkpoints."""
+    from distgcn_amd import datagen
+    m = "result_%s_deep_ld%d_c%d_l%d_cheb%d_diver1_mwis_dqn"
+    er = lambda n, p: (lambda c, f: datagen.er_batch(c, n, p, first_index=f))
+    ba = lambda c, f: datagen.ba_test2_batch(c, first_index=f)
+    mc = lambda nf: (lambda c, f: datagen.multichannel_batch(c, nf, 0.03, first_index=f))
+    return {
+        "C3-l3": ("ER N=200 p=0.1, IS4SAT l=3", 500, m % ("IS4SAT", 1, 32, 3, 1), er(200, 0.1)),
+        "C4-l3": ("BA test2 mix, DQNBA l=3", 500, m % ("DQNBA", 1, 32, 3, 1), ba),
+        "C3-ld32": ("ER N=200 p=0.1, IS4SAT 32 input features l=20", 128, m % ("IS4SAT", 32, 32, 20, 1), er(200, 0.1)),
+        "C3-c16-l20": ("ER N=200 p=0.1, IS4SAT c=16 l=20", 128, m % ("IS4SAT", 1, 16, 20, 1), er(200, 0.1)),
+        "BA-c64-l2": ("BA test2 mix, IS4SAT c=64 l=2", 128, m % ("IS4SAT", 1, 64, 2, 1), ba),
+        "N1900": ("ER N=1900 p=0.004, IS4SAT l=20 (k_big2, fifteen tiles)", 16, m % ("IS4SAT", 1, 32, 20, 1), er(1900, 0.004)),
+        "N9600-l1": ("ER N=9600 p=0.0005, IS4SAT l=1 (k_wide1)", 4, m % ("IS4SAT", 1, 32, 1, 1), er(9600, 0.0005)),
+        "N3000-l2": ("ER N=3000 p=0.002, IS4SAT l=2 (k_wide1, two layers)", 8, m % ("IS4SAT", 1, 32, 2, 1), er(3000, 0.002)),
+        "MC900-c16-l20": ("joint 3 x 300-flow conflict graphs, IS4SAT c=16 l=20 (zero-padded onto k_big)", 64, m % ("IS4SAT", 1, 16, 20, 1), mc(300)),
+        "MC1500-c16-l4": ("joint 3 x 500-flow conflict graphs, IS4SAT c=16 l=4 (zero-padded onto k_big2)", 32, m % ("IS4SAT", 1, 16, 4, 1), mc(500)),
+        "ER600-cheb2-l2": ("ER N=600 p=0.02, IS4SAT c=1 l=2 [I, L, L.L]", 32, m % ("IS4SAT", 1, 1, 2, 2), er(600, 0.02)),
+        "ER200-cheb2-l1": ("ER N=200 p=0.1, IS4SAT c=1 l=1 [I, L, L.L]", 64, m % ("IS4SAT", 1, 1, 1, 2), er(200, 0.1)),
+    }
+
+
+def all_configs():
+    return {**full_size_configs(), **gpu_extra_configs()}
+
+
 def _chunk(args):
     """Worker: graphs [first, first + count) of a configuration through the C twin (bit-equal to the HIP kernels: the
     -m gpu suite proves it on these very batches) and the report above."""
@@ -140,7 +171,7 @@ def _chunk_given(args):
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     name, first, count, scores, state = args
-    _, _, model, make = full_size_configs()[name]
+    _, _, model, make = all_configs()[name]
     return batch_report(make(count, first), _model(model), scores, state)
 
 

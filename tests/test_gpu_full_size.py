@@ -45,3 +45,35 @@ def test_full_size_scores_against_the_restatement_on_gpu(engine, name):
     assert summ["sets_differing_not_flagged_by_margin"] == 0, summ
     if name in ("ER500", "MC900", "MC900-l1", "N1500", "MC1500"):
         assert engine.solve_path(db, dm) == 2
+
+
+# the other kernels and launch forms (oracle/parity.gpu_extra_configs): graphs solved on the GPU per row
+EXTRA = {"C3-l3": 500, "C4-l3": 500, "C3-ld32": 128, "C3-c16-l20": 128, "BA-c64-l2": 128, "N1900": 16, "N9600-l1": 4, "N3000-l2": 8,
+         "MC900-c16-l20": 64, "MC1500-c16-l4": 32, "ER600-cheb2-l2": 32, "ER200-cheb2-l1": 64}
+EXTRA_PATH = {"N1900": 2, "N9600-l1": 2, "N3000-l2": 2, "MC900-c16-l20": 2, "MC1500-c16-l4": 2, "ER600-cheb2-l2": 2, "ER200-cheb2-l1": 2}
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA))
+def test_more_shapes_against_the_restatement_on_gpu(engine, name):
+    """HIP output against the restatement DIRECTLY (no twin in between) on the shapes the ten configurations above do not
+    reach: the launcher's third depth, 32 input features, hidden widths 16 / 64, the fifteen-tile k_big2, k_wide1 at 9 600
+    vertices and in its two-layer form, deep narrow stacks zero-padded onto k_big / k_big2, the two [I, L, L.L] checkpoints."""
+    from distgcn_amd.engine import DeviceModel
+    from oracle import parity
+    _, _, model, make = parity.gpu_extra_configs()[name]
+    count = EXTRA[name]
+    layers = parity._model(model)
+    hb = make(count, 0)
+    db = engine.upload(hb)
+    dm = DeviceModel(layers, engine.device)
+    res = engine.solve_fused(db, dm)
+    engine.check_status(res["status"])
+    scores, state = res["scores"].cpu().numpy().ravel(), res["state"].cpu().numpy()
+    summ, _ = parity.scores_report(name, count, hb.graph_ptr, scores, state)
+    assert summ["graphs"] == count
+    assert summ["graphs_over_1e-5_vs_f64"] == 0 and summ["abs_graphs_over_1e-5_vs_f64"] == 0, summ
+    assert summ["graphs_over_1e-5_vs_f32_restatement"] == summ["of_those_restatement_further_from_f64"], summ
+    assert summ["sets_differing_not_flagged_by_margin"] == 0, summ
+    assert summ["sets_differing_ids"] == [], summ
+    if name in EXTRA_PATH:
+        assert engine.solve_path(db, dm) == EXTRA_PATH[name]
