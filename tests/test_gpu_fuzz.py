@@ -21,8 +21,16 @@ def test_random_shapes_match_the_twin(engine):
         layers_n = int(rng.choice([1, 2, 3, 8, 12, 20]))
         hidden = int(rng.choice([16, 32]))
         layers = datagen.random_model(layers_n, hidden, bias=bool(rng.integers(2)), seed=100 + case)
-        kind = int(rng.integers(4))
-        if kind == 0:  # a few graphs of one size: the cluster variant's ground
+        kind = int(rng.integers(5))
+        if kind == 4:  # many graphs of mixed sizes: largest first, and from 257 to 512 graphs the folded order (fused_fold_at)
+            ps, cs, ws = [], [], []
+            sizes = rng.choice([1, 7, 30, 64, 100, 150, 200], size=int(rng.integers(3, 6)), replace=False)
+            for _ in range(int(rng.integers(257, 900))):
+                n = int(rng.choice(sizes))
+                ip, ix = datagen.er_graph(n, min(0.9, 6.0 / max(n, 2)), rng)
+                ps.append(ip); cs.append(ix); ws.append(rng.random(n))
+            hb = HostBatch.from_csr_lists(ps, cs, ws)
+        elif kind == 0:  # a few graphs of one size: the cluster variant's ground
             n = int(rng.choice([60, 113, 150, 200, 257, 300, 400, 500, 512]))
             hb = datagen.er_batch(int(rng.integers(1, 12)), n, min(0.5, 12.0 / n), first_index=5000 + 50 * case)
         elif kind == 1:  # many graphs of one size
