@@ -71,6 +71,16 @@ static std::atomic<bool> g_timing{false};
 static int g_timing_every = 1;      // every N-th launch carries an event pair (dgcn_timing_enable(N)); 1 = every launch
 static unsigned long long g_timing_seq = 0;
 
+// The pairs only measure time: hipEventDisableSystemFence ("events that are only being used to measure timing": no system-scope
+// release - cache write-back and invalidation - when the event completes, so an instrumented launch neither pays for flushing the
+// L2 behind it nor makes the next launch start on a cold one).  Nobody reads memory on the strength of these events: results are
+// fetched behind the caller's own stream synchronisation.
+static bool create_pair(TimingSlot& t) {
+    if (hipEventCreateWithFlags(&t.start, hipEventDisableSystemFence) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&t.stop, hipEventDisableSystemFence) != hipSuccess) { (void)hipEventDestroy(t.start); return false; }
+    return true;
+}
+
 static int current_device() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -87,8 +97,7 @@ TimedLaunch::TimedLaunch(const char* family, hipStream_t s) : slot(-1), device(0
     DeviceSlots& d = g_dev[device];
     if (d.live == d.slots.size()) {
         TimingSlot t;
-        if (hipEventCreate(&t.start) != hipSuccess) return;
-        if (hipEventCreate(&t.stop) != hipSuccess) { (void)hipEventDestroy(t.start); return; }
+        if (!create_pair(t)) return;
         d.slots.push_back(t);
     }
     slot = (int)d.live++;
@@ -145,8 +154,7 @@ extern "C" int dgcn_timing_enable(int32_t on) {
         d.slots.reserve(kPrimed);
         while (d.slots.size() < kPrimed) {
             TimingSlot t;
-            if (hipEventCreate(&t.start) != hipSuccess) break;  // (on demand then, as before)
-            if (hipEventCreate(&t.stop) != hipSuccess) { (void)hipEventDestroy(t.start); break; }
+            if (!create_pair(t)) break;  // (on demand then, as before)
             d.slots.push_back(t);
         }
     }
